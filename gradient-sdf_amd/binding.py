@@ -1,0 +1,285 @@
+"""ctypes binding to the C-ABI of libgsdf.so (include/gsdf.h).
+
+This is the thin host-side mirror used by tests/ and bench.py.  It contains no
+arithmetic of the hot path: every call goes through the C-ABI into the gfx950
+kernels.  If the shared library or a GPU is missing, loading / gsdf_create fail
+loudly -- there is NO CPU fallback.
+
+The library is linked without a DT_NEEDED on libamdhip64 (csrc/Makefile) so that
+a process holds exactly one HIP runtime: when PyTorch (which bundles its own
+copy) is already imported we bind to that one, otherwise to /opt/rocm's.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgsdf.so")
+
+GSDF_OK, ERR_TABLE_FULL, ERR_KEY_RANGE, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4, 5
+
+
+class GsdfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gsdf error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_upd", C.c_int64), ("n_valid", C.c_int64), ("n_hit", C.c_int64),
+                ("track_passes", C.c_int32), ("converged", C.c_int32), ("frames", C.c_int64)]
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of libgsdf.so, in-tree (csrc/Makefile)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "gsdf.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def _hip_runtime_path():
+    if "torch" in sys.modules:
+        import torch
+        p = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            return p
+    for p in (os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"),
+              "/opt/rocm/lib/libamdhip64.so"):
+        if os.path.exists(p):
+            return p
+    raise OSError("libamdhip64.so not found (need ROCm): libgsdf has no CPU fallback")
+
+
+_lib = None
+_hip = None
+
+
+def load():
+    """Load libgsdf.so (must already be built: the .so travels in-tree to the GPU box)."""
+    global _lib, _hip
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("%s missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % LIB_PATH)
+    _hip = C.CDLL(_hip_runtime_path(), mode=C.RTLD_GLOBAL)
+    L = C.CDLL(LIB_PATH)
+    fp, i32p, i64p, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_void_p
+    sig = {
+        "gsdf_last_error": (C.c_char_p, []),
+        "gsdf_version": (C.c_char_p, []),
+        "gsdf_create": (C.c_int, [C.POINTER(vp), C.c_float, C.c_float, C.c_int, C.c_int]),
+        "gsdf_destroy": (None, [vp]),
+        "gsdf_reset": (C.c_int, [vp]),
+        "gsdf_set_zrange": (C.c_int, [vp, C.c_float, C.c_float]),
+        "gsdf_normals_init": (C.c_int, [vp, C.c_int, C.c_int, fp, C.c_int]),
+        "gsdf_normals_cache": (C.c_int, [vp, fp]),
+        "gsdf_normals_compute": (C.c_int, [vp, fp, fp, fp, fp]),
+        "gsdf_update": (C.c_int, [vp, fp, fp, fp]),
+        "gsdf_update_dev": (C.c_int, [vp, vp, fp, fp]),
+        "gsdf_track": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "gsdf_set_pose": (C.c_int, [vp, fp]),
+        "gsdf_get_pose": (C.c_int, [vp, fp]),
+        "gsdf_track_and_fuse_dev": (C.c_int, [vp, vp, fp, C.c_int, C.c_float, C.c_float]),
+        "gsdf_read_frame_log": (C.c_int, [vp, fp, C.c_int64, i64p]),
+        "gsdf_sync": (C.c_int, [vp]),
+        "gsdf_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
+        "gsdf_count": (C.c_int, [vp, i64p]),
+        "gsdf_export": (C.c_int, [vp, i32p, fp, C.c_int64, i64p, C.c_int, C.c_int]),
+        "gsdf_merge_raw": (C.c_int, [vp, i32p, fp, C.c_int64]),
+        "gsdf_query": (C.c_int, [vp, fp, C.c_int64, fp, fp, fp]),
+        "gsdf_dev_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_int64]),
+        "gsdf_dev_free": (C.c_int, [vp, vp]),
+        "gsdf_dev_upload": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "gsdf_timer_start": (C.c_int, [vp]),
+        "gsdf_timer_stop_ms": (C.c_int, [vp, fp]),
+        "gsdf_profile": (C.c_int, [vp, C.c_int]),
+        "gsdf_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), i64p]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)       # AttributeError if the .so does not export a declared symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+ABI_SYMBOLS = [
+    "gsdf_last_error", "gsdf_version", "gsdf_create", "gsdf_destroy", "gsdf_reset", "gsdf_set_zrange",
+    "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
+    "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
+    "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_merge_raw", "gsdf_query",
+    "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_timer_start", "gsdf_timer_stop_ms",
+    "gsdf_profile", "gsdf_profile_read",
+]
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class GradSdf:
+    """MapGradPixelSdf + RigidPointOptimizer + NormalEstimator behind the C-ABI (one GPU)."""
+
+    def __init__(self, voxel_size, trunc_dist, W, H, K, win=11, capacity_log2=22, device=0,
+                 zmin=0.5, zmax=3.5):
+        self.L = load()
+        self.h = C.c_void_p()
+        self._chk(self.L.gsdf_create(C.byref(self.h), np.float32(voxel_size), np.float32(trunc_dist),
+                                     int(capacity_log2), int(device)))
+        self.W, self.H = int(W), int(H)
+        self.K = _f32(K).reshape(9).copy()
+        self._chk(self.L.gsdf_set_zrange(self.h, np.float32(zmin), np.float32(zmax)))
+        self._chk(self.L.gsdf_normals_init(self.h, self.W, self.H, _fp(self.K), int(win)))
+        self._dev = []
+
+    def _chk(self, rc):
+        if rc != GSDF_OK:
+            raise GsdfError(rc, self.L.gsdf_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            for p in self._dev:
+                self.L.gsdf_dev_free(self.h, p)
+            self._dev = []
+            self.L.gsdf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self._chk(self.L.gsdf_reset(self.h))
+
+    # -- normals ------------------------------------------------------------------------------
+    def normals_cache(self):
+        out = np.empty((11, self.H, self.W), np.float32)
+        self._chk(self.L.gsdf_normals_cache(self.h, _fp(out)))
+        return out
+
+    def normals(self, depth):
+        d = _f32(depth).reshape(self.H, self.W)
+        n = np.empty((3, self.H, self.W), np.float32)
+        self._chk(self.L.gsdf_normals_compute(self.h, _fp(d), _fp(n[0]), _fp(n[1]), _fp(n[2])))
+        return n
+
+    # -- fusion -------------------------------------------------------------------------------
+    def update(self, depth, R, t):
+        d = _f32(depth).reshape(self.H, self.W)
+        R = _f32(R).reshape(9)
+        t = _f32(t).reshape(3)
+        self._chk(self.L.gsdf_update(self.h, _fp(d), _fp(R), _fp(t)))
+
+    def upload(self, array):
+        """Stage a host array in HBM; returns the device pointer (freed on close)."""
+        a = np.ascontiguousarray(array)
+        p = C.c_void_p()
+        self._chk(self.L.gsdf_dev_alloc(self.h, C.byref(p), a.nbytes))
+        self._dev.append(p)
+        self._chk(self.L.gsdf_dev_upload(self.h, p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return p
+
+    def update_dev(self, depth_dev, R, t):
+        R = _f32(R).reshape(9)
+        t = _f32(t).reshape(3)
+        self._chk(self.L.gsdf_update_dev(self.h, depth_dev, _fp(R), _fp(t)))
+
+    # -- tracking -----------------------------------------------------------------------------
+    def track(self, depth, pose7, iters=25, conv=1e-3, damping=1.0):
+        d = _f32(depth).reshape(self.H, self.W)
+        p = _f32(pose7).reshape(7).copy()
+        conv_flag, passes = C.c_int(0), C.c_int(0)
+        self._chk(self.L.gsdf_track(self.h, _fp(d), _fp(self.K), _fp(p), int(iters), np.float32(conv),
+                                    np.float32(damping), C.byref(conv_flag), C.byref(passes)))
+        return bool(conv_flag.value), p, passes.value
+
+    def set_pose(self, pose7):
+        p = _f32(pose7).reshape(7)
+        self._chk(self.L.gsdf_set_pose(self.h, _fp(p)))
+
+    def get_pose(self):
+        p = np.empty(7, np.float32)
+        self._chk(self.L.gsdf_get_pose(self.h, _fp(p)))
+        return p
+
+    def track_and_fuse_dev(self, depth_dev, iters=25, conv=1e-3, damping=1.0):
+        self._chk(self.L.gsdf_track_and_fuse_dev(self.h, depth_dev, _fp(self.K), int(iters), np.float32(conv),
+                                                 np.float32(damping)))
+
+    def frame_log(self):
+        n = C.c_int64(0)
+        self._chk(self.L.gsdf_read_frame_log(self.h, None, 0, C.byref(n)))
+        rows = np.zeros((n.value, 10), np.float32)
+        if n.value:
+            self._chk(self.L.gsdf_read_frame_log(self.h, _fp(rows), n.value, C.byref(n)))
+        return rows
+
+    # -- state --------------------------------------------------------------------------------
+    def sync(self):
+        self._chk(self.L.gsdf_sync(self.h))
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.gsdf_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def count(self):
+        n = C.c_int64(0)
+        self._chk(self.L.gsdf_count(self.h, C.byref(n)))
+        return n.value
+
+    def export(self, sorted=True, raw=False):
+        n = self.count()
+        keys = np.empty((n, 3), np.int32)
+        pay = np.empty((n, 5), np.float32)
+        got = C.c_int64(0)
+        if n:
+            self._chk(self.L.gsdf_export(self.h, keys.ctypes.data_as(C.POINTER(C.c_int32)), _fp(pay), n,
+                                         C.byref(got), int(sorted), int(raw)))
+        return keys, pay
+
+    def merge_raw(self, keys, payload_raw):
+        k = np.ascontiguousarray(keys, np.int32).reshape(-1, 3)
+        p = _f32(payload_raw).reshape(-1, 5)
+        self._chk(self.L.gsdf_merge_raw(self.h, k.ctypes.data_as(C.POINTER(C.c_int32)), _fp(p), k.shape[0]))
+
+    def query(self, pts):
+        p = _f32(pts).reshape(-1, 3)
+        n = p.shape[0]
+        dist = np.empty(n, np.float32)
+        grad = np.empty((n, 3), np.float32)
+        w = np.empty(n, np.float32)
+        self._chk(self.L.gsdf_query(self.h, _fp(p), n, _fp(dist), _fp(grad), _fp(w)))
+        return dist, grad, w
+
+    # -- timing -------------------------------------------------------------------------------
+    def timer_start(self):
+        self._chk(self.L.gsdf_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float(0)
+        self._chk(self.L.gsdf_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile(self, enable):
+        self._chk(self.L.gsdf_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        ms = (C.c_double * 3)()
+        n = (C.c_int64 * 3)()
+        self._chk(self.L.gsdf_profile_read(self.h, ms, n))
+        names = ("normals", "fusion", "track_pass")
+        return {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(3)}

@@ -1,0 +1,583 @@
+/*
+ * gsdf_capi.hip -- host side of libgsdf.so: the C-ABI declared in include/gsdf.h.
+ *
+ * Owns the HBM-resident state (voxel hash table, cached normal-estimator planes, frame
+ * scratch, tracker state) and enqueues the gfx950 kernels on one HIP stream.  There is no
+ * CPU implementation behind these entry points: without a GPU gsdf_create fails with
+ * GSDF_ERR_NO_DEVICE.
+ */
+#include "../../include/gsdf.h"
+#include "gsdf_kernels.h"
+#include "gsdf_math.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+struct gsdf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    /* MapGradPixelSdf / Sdf members */
+    float voxel_size = 0, voxel_size_inv = 0, T = 0, inv_T = 0;
+    float zmin = 0.5f, zmax = 3.5f;                /* Sdf.h:67-68 */
+    int factor = 0;
+    /* table */
+    int capacity_log2 = 0;
+    size_t n_slots = 0;
+    gsdf_table tab{ nullptr, 0 };
+    /* normal estimator + frame scratch */
+    int W = 0, H = 0, win = 0;
+    float K[9] = { 0 };
+    float* planes = nullptr;                       /* 11 planes */
+    float* depth_stage = nullptr;                  /* H2D staging for host-pointer entry points */
+    float* normals = nullptr;                      /* 3 planes */
+    /* tracker */
+    gsdf_dev_state* st = nullptr;
+    float* partials = nullptr;
+    int track_blocks = 0;
+    unsigned long long* blk_counters = nullptr;
+    int fuse_blocks = 0;
+    float* frame_log = nullptr;
+    long long frame_log_cap = 0;
+    /* misc */
+    unsigned long long* counter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[3];
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[3] = { 0, 0, 0 };
+    long long prof_n[3] = { 0, 0, 0 };
+
+    gsdf_frame_geom geom() const {
+        gsdf_frame_geom g;
+        g.W = W; g.H = H;
+        g.fx = K[0]; g.fy = K[4]; g.cx = K[2]; g.cy = K[5];
+        g.vs = voxel_size; g.inv_vs = voxel_size_inv; g.T = T; g.inv_T = inv_T;
+        g.zmin = zmin; g.zmax = zmax; g.factor = factor;
+        return g;
+    }
+    gsdf_ncache ncache() const {
+        const size_t N = (size_t)W * H;
+        gsdf_ncache nc;
+        nc.x0 = planes; nc.y0 = planes + N; nc.x0n = planes + 2 * N; nc.y0n = planes + 3 * N;
+        nc.ninv = planes + 4 * N; nc.q11 = planes + 5 * N; nc.q12 = planes + 6 * N; nc.q13 = planes + 7 * N;
+        nc.q22 = planes + 8 * N; nc.q23 = planes + 9 * N; nc.q33 = planes + 10 * N;
+        return nc;
+    }
+};
+
+namespace {
+
+hipEvent_t take_event(gsdf_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct prof_scope {
+    gsdf_ctx* c; int which; hipEvent_t a = nullptr, b = nullptr;
+    prof_scope(gsdf_ctx* c_, int w) : c(c_), which(w) {
+        if (c->profiling) { a = take_event(c); b = take_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~prof_scope() {
+        if (c->profiling) { (void)hipEventRecord(b, c->stream); c->prof_events[which].push_back({ a, b }); }
+    }
+};
+
+void prof_collect(gsdf_ctx* c) {
+    for (int k = 0; k < 3; ++k) {
+        for (auto& pr : c->prof_events[k]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k] += 1; }
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
+        }
+        c->prof_events[k].clear();
+    }
+}
+
+int status_to_code(int status) {
+    if (status & GSDF_STATUS_TABLE_FULL) return fail(GSDF_ERR_TABLE_FULL, "voxel hash table full (probe budget exhausted)");
+    if (status & GSDF_STATUS_KEY_RANGE) return fail(GSDF_ERR_KEY_RANGE, "voxel index outside the packable +-2^20 range");
+    return GSDF_OK;
+}
+
+int require_frame(gsdf_ctx* c) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    if (!c->planes) return fail(GSDF_ERR_INVALID, "gsdf_normals_init must be called first (NEst == nullptr, MapGradPixelSdf.cpp:55-58)");
+    return GSDF_OK;
+}
+
+int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose) {
+    const size_t N = (size_t)c->W * c->H;
+    const gsdf_frame_geom g = c->geom();
+    const gsdf_ncache nc = c->ncache();
+    {
+        prof_scope ps(c, 0);
+        gsdf_launch_normals(c->stream, g, c->win, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N,
+                            use_dev_pose ? c->st : nullptr);
+    }
+    {
+        prof_scope ps(c, 1);
+        gsdf_launch_fuse(c->stream, g, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N, pose,
+                         use_dev_pose, c->tab, c->st, c->blk_counters);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
+    return GSDF_OK;
+}
+
+int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, float damping) {
+    const gsdf_frame_geom g = c->geom();
+    const float conv_sq = conv * conv;                       /* RigidOptimizer.h:72 */
+    gsdf_launch_track_begin(c->stream, c->st, iters, conv_sq, damping);
+    for (int k = 0; k < iters; ++k) {
+        prof_scope ps(c, 2);
+        gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("tracking launch: ") + hipGetErrorString(e));
+    return GSDF_OK;
+}
+
+int read_state(gsdf_ctx* c, gsdf_dev_state* out) {
+    HIP_TRY(hipMemcpyAsync(out, c->st, sizeof(gsdf_dev_state), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* gsdf_last_error(void) { return g_err.c_str(); }
+const char* gsdf_version(void) { return "gsdf-mi355x 0.1 (gfx950)"; }
+
+int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device) {
+    if (!out) return fail(GSDF_ERR_INVALID, "out == NULL");
+    *out = nullptr;
+    if (!(voxel_size > 0.f) || !(trunc_dist > 0.f)) return fail(GSDF_ERR_INVALID, "voxel_size and trunc_dist must be > 0");
+    if (capacity_log2 < 10 || capacity_log2 > 32) return fail(GSDF_ERR_INVALID, "capacity_log2 must be in [10, 32]");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        (void)hipGetLastError();
+        return fail(GSDF_ERR_NO_DEVICE, "no HIP device visible: libgsdf has no CPU fallback");
+    }
+    if (device < 0 || device >= n_dev) return fail(GSDF_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    gsdf_ctx* c = new gsdf_ctx();
+    c->device = device;
+    c->voxel_size = voxel_size;
+    c->voxel_size_inv = (float)(1. / voxel_size);            /* MapGradPixelSdf.h:99-103 */
+    c->T = trunc_dist;
+    c->inv_T = (float)(1. / trunc_dist);                     /* Sdf.h:103-107 */
+    c->factor = (int)std::floor(c->T / c->voxel_size);       /* MapGradPixelSdf.cpp:79 */
+    c->capacity_log2 = capacity_log2;
+    c->n_slots = (size_t)1 << capacity_log2;
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc((void**)&c->tab.slots, c->n_slots * sizeof(gsdf_slot))) != hipSuccess ||
+        (e = hipMalloc((void**)&c->st, sizeof(gsdf_dev_state))) != hipSuccess ||
+        (e = hipMalloc((void**)&c->counter, sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        std::string m = std::string("gsdf_create: ") + hipGetErrorString(e);
+        gsdf_destroy(c);
+        return fail(GSDF_ERR_HIP, m);
+    }
+    c->tab.bucket_mask = (uint32_t)(c->n_slots / GSDF_BUCKET - 1);
+    int rc = gsdf_reset(c);
+    if (rc != GSDF_OK) { gsdf_destroy(c); return rc; }
+    *out = c;
+    return GSDF_OK;
+}
+
+void gsdf_destroy(gsdf_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    void* ptrs[] = { c->tab.slots, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
+                     c->blk_counters, c->frame_log };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int gsdf_reset(gsdf_ctx* c) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_launch_table_clear(c->stream, c->tab, c->n_slots);
+    HIP_TRY(hipMemsetAsync(c->st, 0, sizeof(gsdf_dev_state), c->stream));
+    const float ident[7] = { 0, 0, 0, 0, 0, 0, 1 };          /* pose_ = SE3() -- RigidOptimizer.h:64 */
+    gsdf_launch_set_pose(c->stream, c->st, nullptr, ident);
+    if (c->blk_counters)
+        HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+
+int gsdf_set_zrange(gsdf_ctx* c, float zmin, float zmax) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    c->zmin = zmin; c->zmax = zmax;
+    return GSDF_OK;
+}
+
+int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
+    if (!c || !K) return fail(GSDF_ERR_INVALID, "null argument");
+    if (W <= 0 || H <= 0 || win <= 0 || !(win & 1) || win / 2 > 7)
+        return fail(GSDF_ERR_INVALID, "W,H > 0 and odd window <= 15 required");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    void* old[] = { c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log };
+    for (void* p : old) if (p) (void)hipFree(p);
+    c->planes = c->depth_stage = c->normals = c->partials = nullptr;
+    c->blk_counters = nullptr; c->frame_log = nullptr;
+    c->W = W; c->H = H; c->win = win;
+    std::memcpy(c->K, K, 9 * sizeof(float));
+    const size_t N = (size_t)W * H;
+    HIP_TRY(hipMalloc((void**)&c->planes, 11 * N * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->depth_stage, N * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->normals, 3 * N * sizeof(float)));
+    /* one tracker workgroup per 1024 pixels (4 pixels per lane), at least one */
+    c->track_blocks = (int)std::max<size_t>(1, (N + 1023) / 1024);
+    HIP_TRY(hipMalloc((void**)&c->partials, (size_t)c->track_blocks * 32 * sizeof(float)));
+    c->fuse_blocks = gsdf_fuse_grid_blocks(W, H);
+    HIP_TRY(hipMalloc((void**)&c->blk_counters, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
+    c->frame_log_cap = 1 << 16;
+    HIP_TRY(hipMalloc((void**)&c->frame_log, (size_t)c->frame_log_cap * 10 * sizeof(float)));
+    gsdf_launch_normals_cache(c->stream, W, H, c->K, win, c->planes);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+
+int gsdf_normals_cache(gsdf_ctx* c, float* planes11_host) {
+    int rc = require_frame(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(planes11_host, c->planes, 11 * (size_t)c->W * c->H * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+
+int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float* ny, float* nz) {
+    int rc = require_frame(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t N = (size_t)c->W * c->H;
+    HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), c->depth_stage, c->normals, c->normals + N,
+                        c->normals + 2 * N, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(nx, c->normals, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(ny, c->normals + N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(nz, c->normals + 2 * N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+
+int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const float t[3]) {
+    int rc = require_frame(c);
+    if (rc) return rc;
+    if (!depth_dev || !R || !t) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_pose_arg pose;
+    std::memcpy(pose.R, R, sizeof(pose.R));
+    std::memcpy(pose.t, t, sizeof(pose.t));
+    return enqueue_fuse(c, depth_dev, pose, 0);
+}
+
+int gsdf_update(gsdf_ctx* c, const float* depth_host, const float R[9], const float t[3]) {
+    int rc = require_frame(c);
+    if (rc) return rc;
+    if (!depth_host) return fail(GSDF_ERR_INVALID, "null depth");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, (size_t)c->W * c->H * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = gsdf_update_dev(c, c->depth_stage, R, t);
+    if (rc) return rc;
+    return gsdf_sync(c);
+}
+
+int gsdf_set_pose(gsdf_ctx* c, const float pose7[7]) {
+    if (!c || !pose7) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_launch_set_pose(c->stream, c->st, nullptr, pose7);
+    HIP_TRY(hipGetLastError());
+    return GSDF_OK;
+}
+
+int gsdf_get_pose(gsdf_ctx* c, float pose7[7]) {
+    if (!c || !pose7) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_dev_state s;
+    int rc = read_state(c, &s);
+    if (rc) return rc;
+    std::memcpy(pose7, s.pose7, 7 * sizeof(float));
+    return GSDF_OK;
+}
+
+int gsdf_track(gsdf_ctx* c, const float* depth_host, const float K[9], float pose7[7], int num_iterations,
+               float conv_threshold, float damping, int* converged, int* passes) {
+    int rc = require_frame(c);
+    if (rc) return rc;
+    if (!depth_host || !K || !pose7) return fail(GSDF_ERR_INVALID, "null argument");
+    if (std::memcmp(K, c->K, 9 * sizeof(float)) != 0)
+        return fail(GSDF_ERR_INVALID, "K differs from the intrinsics given to gsdf_normals_init");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, (size_t)c->W * c->H * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    gsdf_launch_set_pose(c->stream, c->st, nullptr, pose7);
+    rc = enqueue_track(c, c->depth_stage, num_iterations, conv_threshold, damping);
+    if (rc) return rc;
+    gsdf_dev_state s;
+    rc = read_state(c, &s);
+    if (rc) return rc;
+    std::memcpy(pose7, s.pose7, 7 * sizeof(float));
+    if (converged) *converged = s.converged;
+    if (passes) *passes = s.passes;
+    return status_to_code(s.status);
+}
+
+int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9], int num_iterations,
+                            float conv_threshold, float damping) {
+    int rc = require_frame(c);
+    if (rc) return rc;
+    if (!depth_dev || !K) return fail(GSDF_ERR_INVALID, "null argument");
+    if (std::memcmp(K, c->K, 9 * sizeof(float)) != 0)
+        return fail(GSDF_ERR_INVALID, "K differs from the intrinsics given to gsdf_normals_init");
+    HIP_TRY(hipSetDevice(c->device));
+    rc = enqueue_track(c, depth_dev, num_iterations, conv_threshold, damping);    /* main_scan_3d.cpp:258 */
+    if (rc) return rc;
+    gsdf_pose_arg unused;
+    std::memset(&unused, 0, sizeof(unused));
+    rc = enqueue_fuse(c, depth_dev, unused, 1);                                   /* :261-265 */
+    if (rc) return rc;
+    gsdf_launch_frame_log(c->stream, c->st, c->frame_log, c->frame_log_cap);      /* :268-280 */
+    HIP_TRY(hipGetLastError());
+    return GSDF_OK;
+}
+
+int gsdf_read_frame_log(gsdf_ctx* c, float* rows10, int64_t max_rows, int64_t* n_rows) {
+    int rc = require_frame(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_dev_state s;
+    rc = read_state(c, &s);
+    if (rc) return rc;
+    int64_t n = std::min<int64_t>(s.log_rows, c->frame_log_cap);
+    if (n_rows) *n_rows = n;
+    n = std::min<int64_t>(n, max_rows);
+    if (n > 0 && rows10) {
+        HIP_TRY(hipMemcpyAsync(rows10, c->frame_log, (size_t)n * 10 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return GSDF_OK;
+}
+
+int gsdf_sync(gsdf_ctx* c) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_dev_state s;
+    int rc = read_state(c, &s);
+    if (rc) return rc;
+    prof_collect(c);
+    return status_to_code(s.status);
+}
+
+int gsdf_get_stats(gsdf_ctx* c, gsdf_stats* out) {
+    if (!c || !out) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_dev_state s;
+    int rc = read_state(c, &s);
+    if (rc) return rc;
+    std::memset(out, 0, sizeof(*out));
+    if (c->blk_counters) {
+        std::vector<unsigned long long> h((size_t)c->fuse_blocks * 4);
+        HIP_TRY(hipMemcpy(h.data(), c->blk_counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long cu = 0, cv = 0;
+        for (int b = 0; b < c->fuse_blocks; ++b) { cu += h[4 * b + 2]; cv += h[4 * b + 3]; }
+        out->n_upd = (int64_t)cu;
+        out->n_valid = (int64_t)cv;
+    }
+    out->n_hit = (int64_t)s.n_hit;
+    out->track_passes = s.passes;
+    out->converged = s.converged;
+    out->frames = s.frames;
+    return GSDF_OK;
+}
+
+int gsdf_count(gsdf_ctx* c, int64_t* n) {
+    if (!c || !n) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+    gsdf_launch_export(c->stream, c->tab, c->n_slots, nullptr, nullptr, c->counter, 0, 0);
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, c->counter, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n = (int64_t)h;
+    return GSDF_OK;
+}
+
+int gsdf_export(gsdf_ctx* c, int32_t* keys, float* payload, int64_t max_n, int64_t* n_out, int sorted, int raw_sums) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int64_t n = 0;
+    int rc = gsdf_count(c, &n);
+    if (rc) return rc;
+    if (n_out) *n_out = n;
+    if (n == 0 || max_n <= 0 || (!keys && !payload)) return GSDF_OK;
+    if (max_n < n) return fail(GSDF_ERR_INVALID, "export buffer too small (call gsdf_count first)");
+    unsigned long long* dkeys = nullptr;
+    float* dpay = nullptr;
+    HIP_TRY(hipMalloc((void**)&dkeys, (size_t)n * sizeof(unsigned long long)));
+    hipError_t e = hipMalloc((void**)&dpay, (size_t)n * 5 * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(dkeys); return fail(GSDF_ERR_HIP, hipGetErrorString(e)); }
+    (void)hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream);
+    gsdf_launch_export(c->stream, c->tab, c->n_slots, dkeys, dpay, c->counter, n, raw_sums);
+    std::vector<unsigned long long> hk((size_t)n);
+    std::vector<float> hp((size_t)n * 5);
+    e = hipMemcpyAsync(hk.data(), dkeys, hk.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hp.data(), dpay, hp.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(dkeys);
+    (void)hipFree(dpay);
+    if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
+    std::vector<size_t> order((size_t)n);
+    std::iota(order.begin(), order.end(), (size_t)0);
+    if (sorted)   /* packed keys order like (z, y, x) */
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return hk[a] < hk[b]; });
+    for (int64_t i = 0; i < n; ++i) {
+        const size_t j = order[(size_t)i];
+        if (keys) {
+            int x, y, z;
+            gsdf_key_unpack(hk[j], &x, &y, &z);
+            keys[3 * i] = x; keys[3 * i + 1] = y; keys[3 * i + 2] = z;
+        }
+        if (payload) std::memcpy(payload + 5 * i, hp.data() + 5 * j, 5 * sizeof(float));
+    }
+    return GSDF_OK;
+}
+
+int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, int64_t n) {
+    if (!c || (n > 0 && (!keys || !payload_raw))) return fail(GSDF_ERR_INVALID, "null argument");
+    if (n <= 0) return GSDF_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t* dk = nullptr;
+    float* dp = nullptr;
+    HIP_TRY(hipMalloc((void**)&dk, (size_t)n * 3 * sizeof(int32_t)));
+    hipError_t e = hipMalloc((void**)&dp, (size_t)n * 5 * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(dk); return fail(GSDF_ERR_HIP, hipGetErrorString(e)); }
+    e = hipMemcpyAsync(dk, keys, (size_t)n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dp, payload_raw, (size_t)n * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        gsdf_launch_merge_raw(c->stream, c->tab, dk, dp, n, c->st);
+        e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(dk);
+    (void)hipFree(dp);
+    if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
+    return gsdf_sync(c);
+}
+
+int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w) {
+    if (!c || (n > 0 && (!pts_host || !dist || !grad || !w))) return fail(GSDF_ERR_INVALID, "null argument");
+    if (n <= 0) return GSDF_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)n * 8 * sizeof(float)));
+    float *dp = d, *dd = d + 3 * n, *dg = d + 4 * n, *dw = d + 7 * n;
+    hipError_t e = hipMemcpyAsync(dp, pts_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        gsdf_launch_query(c->stream, c->tab, c->voxel_size, c->voxel_size_inv, dp, n, dd, dg, dw);
+        e = hipMemcpyAsync(dist, dd, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(grad, dg, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(w, dw, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
+    return GSDF_OK;
+}
+
+int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes) {
+    if (!c || !dev_ptr || bytes <= 0) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(dev_ptr, (size_t)bytes));
+    return GSDF_OK;
+}
+int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(dev_ptr));
+    return GSDF_OK;
+}
+int gsdf_dev_upload(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes) {
+    if (!c || !dev_dst || !host_src || bytes < 0) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+
+int gsdf_timer_start(gsdf_ctx* c) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return GSDF_OK;
+}
+int gsdf_timer_stop_ms(gsdf_ctx* c, float* ms) {
+    if (!c || !ms) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return GSDF_OK;
+}
+
+int gsdf_profile(gsdf_ctx* c, int enable) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    c->profiling = enable != 0;
+    if (enable) for (int k = 0; k < 3; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    return GSDF_OK;
+}
+int gsdf_profile_read(gsdf_ctx* c, double ms[3], int64_t launches[3]) {
+    if (!c || !ms || !launches) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    for (int k = 0; k < 3; ++k) { ms[k] = c->prof_ms[k]; launches[k] = c->prof_n[k]; }
+    return GSDF_OK;
+}
+
+} // extern "C"

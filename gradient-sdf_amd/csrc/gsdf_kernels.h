@@ -1,0 +1,76 @@
+/*
+ * gsdf_kernels.h -- launch interface between the C-ABI host code (gsdf_capi.hip)
+ * and the gfx950 kernels (gsdf_kernels.hip).
+ */
+#ifndef GSDF_KERNELS_H_
+#define GSDF_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gsdf_table.h"
+
+#define GSDF_STATUS_TABLE_FULL 1
+#define GSDF_STATUS_KEY_RANGE  2
+
+#define GSDF_TRACK_BLOCK   256
+#define GSDF_TRACK_NSUM    29     /* E, g[6], H upper triangle[21], count */
+
+/* Device-resident engine state: the tracker's pose (RigidOptimizer::pose_, RigidOptimizer.h:64),
+ * per-optimize flags, sticky launch status and the counters the stats API reports. */
+struct gsdf_dev_state {
+    float pose7[7];               /* tx ty tz qx qy qz qw */
+    float R[9];                   /* rotationMatrix() of pose7, kept in step by whoever writes pose7 */
+    int done;                     /* pass kernels return immediately once set */
+    int converged;
+    int passes;
+    int max_passes;
+    unsigned int ticket;          /* block arrival counter of the running pass */
+    float last_hits;
+    float conv_sq;
+    float damping;
+    int status;                   /* GSDF_STATUS_* bits, sticky */
+    int pad0;
+    unsigned long long n_upd, n_valid, n_hit, n_occupied;
+    long long frames;             /* Sdf::counter_ */
+    long long log_rows;
+};
+
+struct gsdf_frame_geom {
+    int W, H;
+    float fx, fy, cx, cy;
+    float vs, inv_vs, T, inv_T, zmin, zmax;
+    int factor;
+};
+
+/* cached planes of the normal estimator, each W*H floats (NormalEstimator.h:60-64) */
+struct gsdf_ncache {
+    const float *x0, *y0, *x0n, *y0n, *ninv, *q11, *q12, *q13, *q22, *q23, *q33;
+};
+
+struct gsdf_pose_arg { float R[9]; float t[3]; };
+
+void gsdf_launch_table_clear(hipStream_t s, gsdf_table tab, size_t n_slots);
+void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int win, float* planes11);
+void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
+                         const float* depth, float* nx, float* ny, float* nz,
+                         const gsdf_dev_state* gate /* nullable: skip unless converged */);
+/* use_dev_pose: take R,t from st->R / st->pose7 and skip the launch unless st->converged */
+void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
+                      const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
+                      int use_dev_pose, gsdf_table tab, gsdf_dev_state* st,
+                      unsigned long long* blk_counters /* [gsdf_fuse_grid_blocks][4] */);
+int  gsdf_fuse_grid_blocks(int W, int H);
+void gsdf_launch_track_begin(hipStream_t s, gsdf_dev_state* st, int max_passes, float conv_sq, float damping);
+void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
+                            gsdf_dev_state* st, float* partials, int n_blocks);
+void gsdf_launch_frame_log(hipStream_t s, gsdf_dev_state* st, float* log_rows, long long max_rows);
+void gsdf_launch_set_pose(hipStream_t s, gsdf_dev_state* st, const float* pose7_dev_or_null,
+                          const float pose7_host[7]);
+void gsdf_launch_export(hipStream_t s, gsdf_table tab, size_t n_slots, unsigned long long* keys_out,
+                        float* payload_out, unsigned long long* counter, long long max_n, int raw);
+void gsdf_launch_merge_raw(hipStream_t s, gsdf_table tab, const int32_t* keys, const float* payload,
+                           long long n, gsdf_dev_state* st);
+void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, const float* pts, long long n,
+                       float* dist, float* grad, float* w);
+
+#endif /* GSDF_KERNELS_H_ */

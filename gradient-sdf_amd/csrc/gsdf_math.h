@@ -1,0 +1,190 @@
+/*
+ * gsdf_math.h -- float32 arithmetic of the Gradient-SDF hot path with a FIXED
+ * operation order, usable from device kernels and from the host facade.
+ *
+ * Everything here must be compiled with -ffp-contract=off (no FMA contraction)
+ * and correctly rounded fp32 divide/sqrt: the voxel keys the fusion kernel
+ * produces have to be bit-identical to the CPU oracle's, which restates the
+ * reference's x86-64 SSE2 build (cpp/CMakeLists.txt:4).  Reference call sites
+ * are cited per function (paths relative to /root/reference/cpp/include/).
+ */
+#ifndef GSDF_MATH_H_
+#define GSDF_MATH_H_
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GSDF_HD __host__ __device__ __forceinline__
+#else
+#define GSDF_HD inline
+#endif
+
+struct gsdf_v3 { float x, y, z; };
+
+/* 3-term reduction in the order of Eigen 3.4's unrolled scalar redux: x0 + (x1 + x2).
+ * Used for every 3x3*3 product, dot() and squaredNorm() on the path
+ * (MapGradPixelSdf.cpp:91-98,103-105; MapGradPixelSdf.h:113-114; RigidPointOptimizer.cpp:70). */
+GSDF_HD float gsdf_sum3(float a, float b, float c) { return a + (b + c); }
+GSDF_HD float gsdf_dot3(gsdf_v3 a, gsdf_v3 b) { return gsdf_sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
+GSDF_HD gsdf_v3 gsdf_matvec(const float* R, gsdf_v3 v) {       /* R row-major 3x3 */
+    gsdf_v3 r;
+    r.x = gsdf_sum3(R[0] * v.x, R[1] * v.y, R[2] * v.z);
+    r.y = gsdf_sum3(R[3] * v.x, R[4] * v.y, R[5] * v.z);
+    r.z = gsdf_sum3(R[6] * v.x, R[7] * v.y, R[8] * v.z);
+    return r;
+}
+GSDF_HD gsdf_v3 gsdf_cross3(gsdf_v3 a, gsdf_v3 b) {             /* RigidPointOptimizer.cpp:78 */
+    gsdf_v3 r;
+    r.x = a.y * b.z - a.z * b.y;
+    r.y = a.z * b.x - a.x * b.z;
+    r.z = a.x * b.y - a.y * b.x;
+    return r;
+}
+/* Eigen normalized(): n / sqrt(|n|^2) when |n|^2 > 0, else n (MapGradPixelSdf.h:113-114) */
+GSDF_HD gsdf_v3 gsdf_normalized3(gsdf_v3 n) {
+    const float z = gsdf_sum3(n.x * n.x, n.y * n.y, n.z * n.z);
+    if (z > 0.f) {
+        const float s = sqrtf(z);
+        gsdf_v3 r = { n.x / s, n.y / s, n.z / s };
+        return r;
+    }
+    return n;
+}
+
+/* Sdf::weight -- sdf_tracker/Sdf.h:76-85 */
+GSDF_HD float gsdf_weight(float sdf, float T, float inv_T) {
+    float w = 0.f;
+    if (sdf <= 0.f) w = 1.f;
+    else if (sdf <= T) w = 1.f - sdf * inv_T;
+    return w;
+}
+/* Sdf::truncate -- sdf_tracker/Sdf.h:72-74 */
+GSDF_HD float gsdf_truncate(float sdf, float T) { return fmaxf(-T, fminf(T, sdf)); }
+
+/* MapGradPixelSdf::float2vox, one component -- MapGradPixelSdf.h:74-77 (std::round = half away from zero) */
+GSDF_HD int32_t gsdf_float2vox1(float inv_vs, float p) { return (int32_t)roundf(inv_vs * p); }
+
+/* Eigen QuaternionBase::toRotationMatrix (SE3::rotationMatrix(), RigidPointOptimizer.cpp:53) */
+GSDF_HD void gsdf_quat_to_R(const float* q /*x y z w*/, float* R) {
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.f - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
+}
+
+/* Eigen Quaternion(Matrix3) -- used by SE3(Matrix4f) (main_scan_3d.cpp:242,252) */
+GSDF_HD void gsdf_R_to_quat(const float* m, float* q /*x y z w*/) {
+    float t = m[0] + m[4] + m[8];
+    if (t > 0.f) {
+        t = sqrtf(t + 1.0f);
+        q[3] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrtf(m[4 * i] - m[4 * j] - m[4 * k] + 1.0f);
+        q[i] = 0.5f * t;
+        t = 0.5f / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+
+/* pose7 = SE3::exp(xi) * pose7 -- Sophus SO3::expAndTheta, SE3::exp and the SE3 group product
+ * (RigidPointOptimizer.cpp:95 calls it with -xi).  pose7 = tx ty tz qx qy qz qw. */
+GSDF_HD void gsdf_se3_exp_mul(const float* xi, float* pose7) {
+    const float eps = 1e-5f;                                   /* Sophus::Constants<float>::epsilon() */
+    const gsdf_v3 ups = { xi[0], xi[1], xi[2] };
+    const gsdf_v3 om = { xi[3], xi[4], xi[5] };
+    const float theta_sq = gsdf_sum3(om.x * om.x, om.y * om.y, om.z * om.z);
+    float theta, imag, real;
+    if (theta_sq < eps * eps) {
+        theta = 0.f;
+        const float theta_po4 = theta_sq * theta_sq;
+        imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
+        real = 1.f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * theta_po4;
+    } else {
+        theta = sqrtf(theta_sq);
+        const float half = 0.5f * theta;
+        imag = sinf(half) / theta;
+        real = cosf(half);
+    }
+    const float qe[4] = { imag * om.x, imag * om.y, imag * om.z, real };
+    const float Om[9] = { 0.f, -om.z, om.y, om.z, 0.f, -om.x, -om.y, om.x, 0.f };
+    float Om2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Om2[3 * i + j] = gsdf_sum3(Om[3 * i] * Om[j], Om[3 * i + 1] * Om[3 + j], Om[3 * i + 2] * Om[6 + j]);
+    float V[9];
+    if (theta < eps) {
+        gsdf_quat_to_R(qe, V);
+    } else {
+        const float tsq = theta * theta;
+        const float a = (1.f - cosf(theta)) / tsq;
+        const float b = (theta - sinf(theta)) / (tsq * theta);
+        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + a * Om[i] + b * Om2[i];
+    }
+    const gsdf_v3 te = gsdf_matvec(V, ups);
+    const float ax = qe[0], ay = qe[1], az = qe[2], aw = qe[3];
+    const float bx = pose7[3], by = pose7[4], bz = pose7[5], bw = pose7[6];
+    float qn[4];
+    qn[3] = aw * bw - ax * bx - ay * by - az * bz;
+    qn[0] = aw * bx + ax * bw + ay * bz - az * by;
+    qn[1] = aw * by + ay * bw + az * bx - ax * bz;
+    qn[2] = aw * bz + az * bw + ax * by - ay * bx;
+    const float len = sqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    for (int i = 0; i < 4; ++i) qn[i] /= len;
+    const gsdf_v3 qv = { ax, ay, az };
+    const gsdf_v3 tt = { pose7[0], pose7[1], pose7[2] };
+    gsdf_v3 uv = gsdf_cross3(qv, tt);
+    uv.x += uv.x; uv.y += uv.y; uv.z += uv.z;
+    const gsdf_v3 c2 = gsdf_cross3(qv, uv);
+    pose7[0] = te.x + (tt.x + aw * uv.x + c2.x);
+    pose7[1] = te.y + (tt.y + aw * uv.y + c2.y);
+    pose7[2] = te.z + (tt.z + aw * uv.z + c2.z);
+    pose7[3] = qn[0]; pose7[4] = qn[1]; pose7[5] = qn[2]; pose7[6] = qn[3];
+}
+
+/* x = H^-1 g by Cholesky (Eigen H.llt().solve(g), RigidPointOptimizer.cpp:86).  H is the full
+ * symmetric 6x6, row-major.  A non-positive pivot stops the factorisation like Eigen's
+ * llt_inplace; the triangular solves still run (=> inf/NaN for an all-zero H). */
+GSDF_HD void gsdf_llt_solve6(const float* Hin, const float* g, float* x) {
+    float L[36];
+    for (int i = 0; i < 36; ++i) L[i] = Hin[i];
+    for (int k = 0; k < 6; ++k) {
+        float d = L[6 * k + k];
+        for (int j = 0; j < k; ++j) d -= L[6 * k + j] * L[6 * k + j];
+        if (d <= 0.f) break;
+        d = sqrtf(d);
+        L[6 * k + k] = d;
+        for (int i = k + 1; i < 6; ++i) {
+            float s = L[6 * i + k];
+            for (int j = 0; j < k; ++j) s -= L[6 * i + j] * L[6 * k + j];
+            L[6 * i + k] = s / d;
+        }
+    }
+    float y[6];
+    for (int i = 0; i < 6; ++i) {
+        float s = g[i];
+        for (int j = 0; j < i; ++j) s -= L[6 * i + j] * y[j];
+        y[i] = s / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        float s = y[i];
+        for (int j = i + 1; j < 6; ++j) s -= L[6 * j + i] * x[j];
+        x[i] = s / L[6 * i + i];
+    }
+}
+
+#endif /* GSDF_MATH_H_ */

@@ -1,0 +1,139 @@
+/*
+ * gsdf.h -- C-ABI of the MI355X-native Gradient-SDF engine (libgsdf.so).
+ *
+ * This is the drop-in boundary for the hot path of c-sommer/gradient-sdf
+ * (cpp/depth_scanning): per-voxel TSDF+gradient fusion, the voxel-hash point
+ * query and the 6-DoF SDF-tracking normal-equation reduction.  The reference has
+ * no FFI / plugin layer: its seam is two C++ virtual interfaces and one POD
+ * (SURVEY.md 8b).  Every entry point below names the reference interface it
+ * replaces (paths relative to /root/reference/cpp/include/).  The C++ facade in
+ * gradient-sdf_amd/host/ (MapGradPixelSdf, RigidPointOptimizer, SdfVoxel) calls
+ * only these functions; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions (identical to the reference's):
+ *   depth  : float32, row-major H x W, continuous, metres, 0 = invalid
+ *            (cv::Mat CV_32FC1, img_loader/ImageLoader.h:159-175)
+ *   K      : row-major 3x3 float  fx 0 cx; 0 fy cy; 0 0 1
+ *   R, t   : camera->world, p_w = R p_c + t, R row-major (MapGradPixelSdf.cpp:62-64,103)
+ *   pose7  : tx ty tz qx qy qz qw  (Sophus SE3 state; TUM file order, main_scan_3d.cpp:274-280)
+ *   keys   : int32 x,y,z voxel indices (Eigen::Vector3i, MapGradPixelSdf.h:65-68)
+ *   payload: float dist, gx, gy, gz, weight (struct SdfVoxel, sdf_voxel/SdfVoxel.h:45-57)
+ *
+ * Plain C types only, caller-owned buffers, no exceptions across the ABI.
+ * One context = one GPU; a context is not thread-safe (the reference has a
+ * single caller thread).  All functions return GSDF_OK (0) or a GSDF_ERR_* code;
+ * gsdf_last_error() gives the message.  *_dev variants take DEVICE pointers and
+ * only enqueue work on the context's HIP stream (no host synchronisation).
+ */
+#ifndef GSDF_H_
+#define GSDF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSDF_OK               0
+#define GSDF_ERR_TABLE_FULL   1   /* open-addressed table ran out of probe budget (new failure mode) */
+#define GSDF_ERR_KEY_RANGE    2   /* voxel index outside the packable +-2^20 range */
+#define GSDF_ERR_INVALID      3   /* bad argument / call order */
+#define GSDF_ERR_HIP          4   /* HIP runtime error (message in gsdf_last_error) */
+#define GSDF_ERR_NO_DEVICE    5   /* no gfx950 device visible: the engine has NO CPU fallback */
+
+typedef struct gsdf_ctx gsdf_ctx;
+
+/* per-call counters of the last fusion / tracking launches (for algorithmic-bytes accounting) */
+typedef struct gsdf_stats {
+    int64_t n_upd;        /* (pixel,k) samples with w>0 in the last update()            */
+    int64_t n_valid;      /* pixels that passed the z-range and both normal gates       */
+    int64_t n_hit;        /* sum over executed tracker passes of pixels with w0>0       */
+    int32_t track_passes; /* tracker reduction passes executed in the last optimize()   */
+    int32_t converged;    /* result of the last optimize()                              */
+    int64_t frames;       /* Sdf::counter_ (Sdf.h:65)                                   */
+} gsdf_stats;
+
+const char* gsdf_last_error(void);
+const char* gsdf_version(void);
+
+/* MapGradPixelSdf(voxel_size, T) + table allocation -- MapGradPixelSdf.h:99-103, Sdf.h:103-107.
+ * capacity_log2: number of 32-byte slots = 2^capacity_log2 (BASELINE configs: 22 and 25).
+ * device: HIP device ordinal.  Fails with GSDF_ERR_NO_DEVICE when no GPU is present. */
+int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device);
+/* delete tSDF -- main_scan_3d.cpp:314 */
+void gsdf_destroy(gsdf_ctx* c);
+/* drop all voxels, frame counter := 0 (new: lets one context be reused by bench/tests) */
+int gsdf_reset(gsdf_ctx* c);
+
+/* Sdf::set_zmin / Sdf::set_zmax -- Sdf.h:123-129 (defaults 0.5 / 3.5) */
+int gsdf_set_zrange(gsdf_ctx* c, float zmin, float zmax);
+
+/* new cv::NormalEstimator<float>(W, H, K, Size(win,win)) -> cache() -- normals/NormalEstimator.h:81-165,
+ * main_scan_3d.cpp:183.  Also fixes the frame size all later calls must use. */
+int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win);
+/* the 11 cached planes (x0,y0,x0/n2,y0/n2,1/n2,Q11,Q12,Q13,Q22,Q23,Q33) copied to the host */
+int gsdf_normals_cache(gsdf_ctx* c, float* planes11_host);
+/* NormalEstimator::compute(depth, nx, ny, nz) -- NormalEstimator.h:179-204 (host in, host out) */
+int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float* ny, float* nz);
+
+/* Sdf::update(color, depth, K, pose, NEst) -- Sdf.h:117, MapGradPixelSdf.cpp:43-122.
+ * color is ignored by the reference and is not part of this ABI.  Synchronous; returns
+ * GSDF_ERR_TABLE_FULL / GSDF_ERR_KEY_RANGE if the launch reported one. */
+int gsdf_update(gsdf_ctx* c, const float* depth_host, const float R[9], const float t[3]);
+/* same with depth already resident in HBM; enqueue only */
+int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const float t[3]);
+
+/* RigidOptimizer::optimize(depth, K) -- RigidOptimizer.h:106, RigidPointOptimizer.cpp:40-99.
+ * pose7 in/out replaces RigidOptimizer::pose()/set_pose (RigidOptimizer.h:99-103);
+ * num_iterations/conv_threshold/damping replace the setters (RigidOptimizer.h:85-97).
+ * *converged receives the bool the reference returns; *passes the reduction passes executed. */
+int gsdf_track(gsdf_ctx* c, const float* depth_host, const float K[9], float pose7[7],
+               int num_iterations, float conv_threshold, float damping,
+               int* converged, int* passes);
+
+/* The Scan3D loop body without host round trips -- main_scan_3d.cpp:255-266:
+ *   conv = pOpt->optimize(depth, K);  if (conv) tSDF->update(color, depth, K, pOpt->pose(), NEst);
+ * The pose persists on the device between frames (RigidOptimizer::pose_, RigidOptimizer.h:64);
+ * set it with gsdf_set_pose.  Enqueue only; per-frame results are appended to a device log that
+ * gsdf_read_frame_log returns (pose7 + converged + passes per frame). */
+int gsdf_set_pose(gsdf_ctx* c, const float pose7[7]);
+int gsdf_get_pose(gsdf_ctx* c, float pose7[7]);          /* synchronises */
+int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9],
+                            int num_iterations, float conv_threshold, float damping);
+/* log rows = float[10]: pose7, converged, passes, n_hit (of the last pass) */
+int gsdf_read_frame_log(gsdf_ctx* c, float* rows10, int64_t max_rows, int64_t* n_rows);
+
+/* wait for all enqueued work; returns the sticky launch status (table full / key range) */
+int gsdf_sync(gsdf_ctx* c);
+int gsdf_get_stats(gsdf_ctx* c, gsdf_stats* out);        /* synchronises */
+
+/* tsdf_.size() -- number of occupied voxels */
+int gsdf_count(gsdf_ctx* c, int64_t* n);
+/* get_tsdf() -- MapGradPixelSdf.h:133-138: all (key, SdfVoxel) pairs.  sorted!=0 orders rows by
+ * (z,y,x) so exports are diffable.  raw_sums!=0 returns the additive accumulators
+ * (sum w*d, sum w*Rn, sum w) instead of (dist, grad, weight) -- the merge wire format. */
+int gsdf_export(gsdf_ctx* c, int32_t* keys, float* payload, int64_t max_n, int64_t* n,
+                int sorted, int raw_sums);
+/* additive merge of raw sums into this table (frame-sharded fusion) */
+int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, int64_t n);
+
+/* Sdf::weights(point) and Sdf::tsdf(point, &grad) at n points -- MapGradPixelSdf.h:109-125.
+ * w[i]==0 marks a missing voxel (dist/grad are then 0; the reference's .at() would throw). */
+int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w);
+
+/* device-memory plumbing so callers can stage frames in HBM without another runtime */
+int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes);
+int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr);
+int gsdf_dev_upload(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes);
+/* HIP-event timing on the context's stream: t0/t1 bracket whatever is enqueued between them */
+int gsdf_timer_start(gsdf_ctx* c);
+int gsdf_timer_stop_ms(gsdf_ctx* c, float* ms);          /* synchronises */
+/* accumulated per-kernel HIP-event time (ms) and launch counts since the last reset:
+ * index 0 normals, 1 fusion, 2 tracking pass.  Enabled by gsdf_profile(c, 1). */
+int gsdf_profile(gsdf_ctx* c, int enable);
+int gsdf_profile_read(gsdf_ctx* c, double ms[3], int64_t launches[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSDF_H_ */

@@ -1,0 +1,625 @@
+/*
+ * gsdf_oracle.cpp -- CPU ORACLE (test infrastructure, see gsdf_oracle.h).
+ *
+ * Dependency-free C++17 restatement of the reference's SERIAL hot path
+ * (c-sommer/gradient-sdf).  Every function cites the reference file:line it
+ * follows (paths relative to /root/reference/cpp/include/).  Build with
+ *   g++ -O2 -ffp-contract=off -fopenmp        (see oracle/Makefile)
+ * which mirrors the reference's RelWithDebInfo x86-64 build (SSE2 scalar float
+ * arithmetic, no FMA contraction; cpp/CMakeLists.txt:4,60).
+ *
+ * PARITY UNPINNED by the reference (no tests / fixtures exist there).  The float
+ * operation orders written here are the definition the HIP kernels copy:
+ *   - 3-term reductions (3x3*3 products, dot, squaredNorm) are  x0 + (x1 + x2),
+ *     the order produced by Eigen 3.4's unrolled scalar redux (redux_novec_unroller
+ *     splits [0,3) into [0,1) and [1,3));  Eigen itself is absent here.
+ *   - box filter = separable double-precision sums, row pass (ascending dx) then
+ *     column pass (ascending dy), BORDER_REFLECT_101, result rounded to float
+ *     (OpenCV's float boxFilter accumulates in double: sumType CV_64F).
+ */
+#include "gsdf_oracle.h"
+
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+#include <unordered_map>
+#include <algorithm>
+#include <limits>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+struct V3 { float x, y, z; };
+
+/* Eigen 3.4 scalar redux of 3 terms: x0 + (x1 + x2) */
+static inline float sum3(float a, float b, float c) { return a + (b + c); }
+static inline float dot3(V3 a, V3 b) { return sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline V3 matvec(const float R[9], V3 v) {           /* R row-major */
+    V3 r;
+    r.x = sum3(R[0] * v.x, R[1] * v.y, R[2] * v.z);
+    r.y = sum3(R[3] * v.x, R[4] * v.y, R[5] * v.z);
+    r.z = sum3(R[6] * v.x, R[7] * v.y, R[8] * v.z);
+    return r;
+}
+static inline V3 cross3(V3 a, V3 b) {                        /* Eigen cross3 */
+    V3 r;
+    r.x = a.y * b.z - a.z * b.y;
+    r.y = a.z * b.x - a.x * b.z;
+    r.z = a.x * b.y - a.y * b.x;
+    return r;
+}
+/* Eigen MatrixBase::normalized(): n / sqrt(|n|^2) if |n|^2 > 0 else n */
+static inline V3 normalized3(V3 n) {
+    float z = sum3(n.x * n.x, n.y * n.y, n.z * n.z);
+    if (z > 0.f) {
+        float s = std::sqrt(z);
+        V3 r = { n.x / s, n.y / s, n.z / s };
+        return r;
+    }
+    return n;
+}
+
+/* SdfVoxel -- sdf_voxel/SdfVoxel.h:45-57 (20-byte payload, zero-initialised) */
+struct SdfVoxel {
+    float dist = 0.f;
+    float grad[3] = { 0.f, 0.f, 0.f };
+    float weight = 0.f;
+};
+
+struct Key {
+    int32_t x, y, z;
+    bool operator==(const Key& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+/* hash is NOT a parity item: only container iteration order depends on it */
+struct KeyHash {
+    size_t operator()(const Key& k) const {
+        uint64_t h = (uint64_t)(uint32_t)k.x * 0x9E3779B97F4A7C15ull;
+        h ^= (uint64_t)(uint32_t)k.y * 0xC2B2AE3D27D4EB4Full + (h << 6) + (h >> 2);
+        h ^= (uint64_t)(uint32_t)k.z * 0x165667B19E3779F9ull + (h << 6) + (h >> 2);
+        h ^= h >> 29;
+        return (size_t)h;
+    }
+};
+
+static inline int reflect101(int i, int n) {                 /* cv::BORDER_REFLECT_101 */
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        else i = 2 * (n - 1) - i;
+    }
+    return i;
+}
+
+/* unnormalised box sum, double accumulation, separable (row then column) */
+template <typename Tin>
+static void box_sum(const Tin* src, double* dst, int W, int H, int win) {
+    const int r = win / 2;
+    std::vector<double> rows((size_t)W * H);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            double s = 0.0;
+            for (int dx = -r; dx <= r; ++dx)
+                s += (double)src[(size_t)y * W + reflect101(x + dx, W)];
+            rows[(size_t)y * W + x] = s;
+        }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            double s = 0.0;
+            for (int dy = -r; dy <= r; ++dy)
+                s += rows[(size_t)reflect101(y + dy, H) * W + x];
+            dst[(size_t)y * W + x] = s;
+        }
+}
+
+} // namespace
+
+struct gsdfo {
+    /* Sdf.h:63-68 */
+    float T_, inv_T_;
+    size_t counter_ = 0;
+    float z_min_ = 0.5f, z_max_ = 3.5f;
+    /* MapGradPixelSdf.h:61-70 */
+    float voxel_size_, voxel_size_inv_;
+    std::unordered_map<Key, SdfVoxel, KeyHash> tsdf_;
+    std::unordered_map<Key, std::vector<bool>, KeyHash> vis_;
+    /* NormalEstimator.h:55-64 */
+    int W = 0, H = 0, win = 0;
+    std::vector<float> x0_, y0_, x0n_, y0n_, ninv_, Q11_, Q12_, Q13_, Q22_, Q23_, Q33_;
+    int threads = 4;
+
+    /* Sdf::truncate -- Sdf.h:72-74 */
+    float truncate(float sdf) const { return std::max(-T_, std::min(T_, sdf)); }
+    /* Sdf::weight -- Sdf.h:76-85 */
+    float weight(float sdf) const {
+        float w = 0.f;
+        if (sdf <= 0.) w = 1.f;
+        else if (sdf <= T_) w = 1.f - sdf * inv_T_;
+        return w;
+    }
+    /* MapGradPixelSdf::float2vox -- MapGradPixelSdf.h:74-77 (std::round: half away from zero) */
+    Key float2vox(V3 p) const {
+        Key k;
+        k.x = (int32_t)std::round(voxel_size_inv_ * p.x);
+        k.y = (int32_t)std::round(voxel_size_inv_ * p.y);
+        k.z = (int32_t)std::round(voxel_size_inv_ * p.z);
+        return k;
+    }
+    /* MapGradPixelSdf::vox2float -- MapGradPixelSdf.h:79-81 */
+    V3 vox2float(Key k) const {
+        V3 r = { voxel_size_ * (float)k.x, voxel_size_ * (float)k.y, voxel_size_ * (float)k.z };
+        return r;
+    }
+};
+
+extern "C" {
+
+gsdfo* gsdfo_create(float voxel_size, float T) {
+    gsdfo* o = new gsdfo();
+    o->T_ = T;
+    o->inv_T_ = (float)(1. / T);                      /* Sdf.h:103-107 */
+    o->voxel_size_ = voxel_size;
+    o->voxel_size_inv_ = (float)(1. / voxel_size);    /* MapGradPixelSdf.h:99-103 */
+    return o;
+}
+void gsdfo_destroy(gsdfo* o) { delete o; }
+void gsdfo_set_zrange(gsdfo* o, float zmin, float zmax) { o->z_min_ = zmin; o->z_max_ = zmax; }
+void gsdfo_set_threads(gsdfo* o, int threads) { o->threads = threads > 0 ? threads : 1; }
+
+/* NormalEstimator::cache -- NormalEstimator.h:81-154 (all in double, then cast to float) */
+int gsdfo_normals_init(gsdfo* o, int W, int H, const float K[9], int win) {
+    if (W <= 0 || H <= 0 || win <= 0 || !(win & 1)) return -1;
+    o->W = W; o->H = H; o->win = win;
+    const size_t N = (size_t)W * H;
+    const double fx_inv = 1. / (double)K[0];
+    const double fy_inv = 1. / (double)K[4];
+    const double cx = (double)K[2];
+    const double cy = (double)K[5];
+    std::vector<double> x0(N), y0(N), ninv(N), x0n(N), y0n(N);
+    std::vector<double> m11(N), m12(N), m13(N), m22(N), m23(N), m33(N);
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) {
+            const size_t i = (size_t)v * W + u;
+            const double x = fx_inv * ((double)u - cx);      /* :94,98 */
+            const double y = fy_inv * ((double)v - cy);      /* :96,100 */
+            const double x_sq = x * x, y_sq = y * y, xy = x * y;
+            const double n_sq = 1. + x_sq + y_sq;            /* :104 */
+            const double ni = 1. / n_sq;                     /* :105 */
+            x0[i] = x; y0[i] = y; ninv[i] = ni;
+            x0n[i] = x * ni; y0n[i] = y * ni;                /* :106-107 */
+            m11[i] = x_sq * ni; m12[i] = xy * ni; m22[i] = y_sq * ni;   /* :109,110,112 */
+        }
+    std::vector<double> M11(N), M12(N), M13(N), M22(N), M23(N), M33(N);
+    box_sum(m11.data(), M11.data(), W, H, win);              /* :109-114 */
+    box_sum(m12.data(), M12.data(), W, H, win);
+    box_sum(x0n.data(), M13.data(), W, H, win);
+    box_sum(m22.data(), M22.data(), W, H, win);
+    box_sum(y0n.data(), M23.data(), W, H, win);
+    box_sum(ninv.data(), M33.data(), W, H, win);
+    o->x0_.resize(N); o->y0_.resize(N); o->x0n_.resize(N); o->y0n_.resize(N); o->ninv_.resize(N);
+    o->Q11_.resize(N); o->Q12_.resize(N); o->Q13_.resize(N); o->Q22_.resize(N); o->Q23_.resize(N); o->Q33_.resize(N);
+    for (size_t i = 0; i < N; ++i) {
+        const double a11 = M11[i], a12 = M12[i], a13 = M13[i], a22 = M22[i], a23 = M23[i], a33 = M33[i];
+        /* :116-118 */
+        const double det = a11 * (a22 * a33) + 2 * (a12 * (a23 * a13))
+                         - (a13 * (a13 * a22) + a12 * (a12 * a33) + a23 * (a23 * a11));
+        const double det_inv = 1. / det;
+        o->Q11_[i] = (float)(det_inv * (a22 * a33 - a23 * a23));   /* :120-125 */
+        o->Q12_[i] = (float)(det_inv * (a13 * a23 - a12 * a33));
+        o->Q13_[i] = (float)(det_inv * (a12 * a23 - a13 * a22));
+        o->Q22_[i] = (float)(det_inv * (a11 * a33 - a13 * a13));
+        o->Q23_[i] = (float)(det_inv * (a12 * a13 - a11 * a23));
+        o->Q33_[i] = (float)(det_inv * (a11 * a22 - a12 * a12));
+        o->x0_[i] = (float)x0[i]; o->y0_[i] = (float)y0[i];        /* :128-132 */
+        o->x0n_[i] = (float)x0n[i]; o->y0n_[i] = (float)y0n[i]; o->ninv_[i] = (float)ninv[i];
+    }
+    return 0;
+}
+
+void gsdfo_normals_cache(const gsdfo* o, float* p) {
+    const size_t N = (size_t)o->W * o->H;
+    const std::vector<float>* v[11] = { &o->x0_, &o->y0_, &o->x0n_, &o->y0n_, &o->ninv_,
+        &o->Q11_, &o->Q12_, &o->Q13_, &o->Q22_, &o->Q23_, &o->Q33_ };
+    for (int k = 0; k < 11; ++k) std::memcpy(p + k * N, v[k]->data(), N * sizeof(float));
+}
+
+/* NormalEstimator::compute -- NormalEstimator.h:179-204 */
+void gsdfo_normals_compute(const gsdfo* o, const float* depth, float* nx, float* ny, float* nz) {
+    const int W = o->W, H = o->H;
+    const size_t N = (size_t)W * H;
+    std::vector<float> p1(N), p2(N), p3(N);
+    for (size_t i = 0; i < N; ++i) {
+        const float zi = depth[i] != 0.f ? 1.f / depth[i] : 0.f;   /* :183-187 */
+        p1[i] = o->x0n_[i] * zi;                                   /* :191-193 (.mul) */
+        p2[i] = o->y0n_[i] * zi;
+        p3[i] = o->ninv_[i] * zi;
+    }
+    std::vector<double> b1(N), b2(N), b3(N);
+    box_sum(p1.data(), b1.data(), W, H, o->win);
+    box_sum(p2.data(), b2.data(), W, H, o->win);
+    box_sum(p3.data(), b3.data(), W, H, o->win);
+    for (size_t i = 0; i < N; ++i) {
+        const float c1 = (float)b1[i], c2 = (float)b2[i], c3 = (float)b3[i];
+        const float x = (c1 * o->Q11_[i] + c2 * o->Q12_[i]) + c3 * o->Q13_[i];   /* :195-197 */
+        const float y = (c1 * o->Q12_[i] + c2 * o->Q22_[i]) + c3 * o->Q23_[i];
+        const float z = (c1 * o->Q13_[i] + c2 * o->Q23_[i]) + c3 * o->Q33_[i];
+        const float n = std::sqrt((x * x + y * y) + z * z);                      /* :199 */
+        nx[i] = x / n; ny[i] = y / n; nz[i] = z / n;                             /* :201-203, IEEE: 0/0 = NaN */
+    }
+}
+
+/* MapGradPixelSdf::update -- MapGradPixelSdf.cpp:43-122 (omp: MapGradPixelSdfOmp.cpp:44-130).
+ * cv::medianBlur at :53 is dead work (result never read) and is not restated. */
+int64_t gsdfo_update(gsdfo* o, const float* depth, const float R[9], const float t[3],
+                     int omp, int64_t* n_valid_out) {
+    const int W = o->W, H = o->H;
+    const size_t N = (size_t)W * H;
+    std::vector<float> nx(N), ny(N), nz(N);
+    gsdfo_normals_compute(o, depth, nx.data(), ny.data(), nz.data());   /* :60 */
+
+    const float z_min = o->z_min_, z_max = o->z_max_;
+    const float vs = o->voxel_size_;
+    const V3 tv = { t[0], t[1], t[2] };
+    const int factor = (int)std::floor(o->T_ / vs);                     /* :79 */
+    int64_t n_upd = 0, n_valid = 0;
+
+    auto body = [&](size_t idx, int64_t& upd, int64_t& valid, bool locked) {
+        const float z = depth[idx];
+        if (z <= z_min || z >= z_max) return;                            /* :87 */
+        const V3 xy_hom = { o->x0_[idx], o->y0_[idx], 1.f };            /* :90 */
+        const V3 R_xy_hom = matvec(R, xy_hom);                          /* :91 */
+        const V3 normal = { nx[idx], ny[idx], nz[idx] };                /* :92 */
+        const V3 Rn = matvec(R, normal);                                /* :93 */
+        if ((double)dot3(normal, normal) < .1) return;                  /* :95 */
+        const float nd = dot3(normal, xy_hom);
+        if (nd * nd * o->ninv_[idx] < .25) return;                      /* :98 */
+        ++valid;
+        for (float k = (float)-factor; k <= (float)factor; ++k) {       /* :101 */
+            const float s = z + k * vs;
+            V3 point = { s * R_xy_hom.x + tv.x, s * R_xy_hom.y + tv.y, s * R_xy_hom.z + tv.z };  /* :103 */
+            const Key vi = o->float2vox(point);                         /* :104 */
+            const V3 c = o->vox2float(vi);
+            const V3 d = { c.x - tv.x, c.y - tv.y, c.z - tv.z };
+            /* point = Rt * d, only component 2 is used (:105-106); Rt(2,j) = R(j,2) */
+            const float pz = sum3(R[2] * d.x, R[5] * d.y, R[8] * d.z);
+            const float sdf = pz - z;
+            const float w = o->weight(sdf);                             /* :107 */
+            if (w > 0) {
+                auto apply = [&]() {
+                    SdfVoxel& v = o->tsdf_[vi];                         /* :109 */
+                    v.weight += w;                                      /* :110 */
+                    v.dist += (o->truncate(sdf) - v.dist) * w / v.weight;   /* :111 */
+                    v.grad[0] += w * Rn.x;                              /* :112 */
+                    v.grad[1] += w * Rn.y;
+                    v.grad[2] += w * Rn.z;
+                    std::vector<bool>& vis = o->vis_[vi];               /* :113-115 */
+                    vis.resize(o->counter_);
+                    vis.push_back(true);
+                };
+                if (locked) {
+#ifdef _OPENMP
+#pragma omp critical(gsdfo_fuse)
+#endif
+                    apply();
+                } else apply();
+                ++upd;
+            }
+        }
+    };
+
+    if (omp) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(o->threads) reduction(+ : n_upd, n_valid) schedule(static)
+#endif
+        for (int64_t i = 0; i < (int64_t)N; ++i) body((size_t)i, n_upd, n_valid, true);
+    } else {
+        for (size_t i = 0; i < N; ++i) body(i, n_upd, n_valid, false);   /* :81 row-major */
+    }
+    ++o->counter_;                                                       /* :120 */
+    if (n_valid_out) *n_valid_out = n_valid;
+    return n_upd;
+}
+
+int64_t gsdfo_count(const gsdfo* o) { return (int64_t)o->tsdf_.size(); }
+int64_t gsdfo_frame_counter(const gsdfo* o) { return (int64_t)o->counter_; }
+
+static std::vector<Key> sorted_keys(const gsdfo* o) {
+    std::vector<Key> ks;
+    ks.reserve(o->tsdf_.size());
+    for (const auto& kv : o->tsdf_) ks.push_back(kv.first);
+    std::sort(ks.begin(), ks.end(), [](const Key& a, const Key& b) {
+        if (a.z != b.z) return a.z < b.z;
+        if (a.y != b.y) return a.y < b.y;
+        return a.x < b.x;
+    });
+    return ks;
+}
+
+void gsdfo_export(const gsdfo* o, int32_t* keys, float* payload) {
+    std::vector<Key> ks = sorted_keys(o);
+    for (size_t i = 0; i < ks.size(); ++i) {
+        const SdfVoxel& v = o->tsdf_.at(ks[i]);
+        keys[3 * i + 0] = ks[i].x; keys[3 * i + 1] = ks[i].y; keys[3 * i + 2] = ks[i].z;
+        payload[5 * i + 0] = v.dist;
+        payload[5 * i + 1] = v.grad[0]; payload[5 * i + 2] = v.grad[1]; payload[5 * i + 3] = v.grad[2];
+        payload[5 * i + 4] = v.weight;
+    }
+}
+
+void gsdfo_export_vis(const gsdfo* o, uint32_t* words, int wpv) {
+    std::vector<Key> ks = sorted_keys(o);
+    for (size_t i = 0; i < ks.size(); ++i) {
+        for (int w = 0; w < wpv; ++w) words[i * wpv + w] = 0u;
+        auto it = o->vis_.find(ks[i]);
+        if (it == o->vis_.end()) continue;
+        const std::vector<bool>& b = it->second;
+        for (size_t f = 0; f < b.size() && f < (size_t)wpv * 32; ++f)
+            if (b[f]) words[i * wpv + f / 32] |= 1u << (f % 32);
+    }
+}
+
+/* MapGradPixelSdf::weights -- MapGradPixelSdf.h:117-125 */
+static inline float oracle_weights(const gsdfo* o, V3 p, const SdfVoxel** vout, Key* kout) {
+    const Key idx = o->float2vox(p);
+    auto it = o->tsdf_.find(idx);
+    if (it != o->tsdf_.end()) { *vout = &it->second; *kout = idx; return it->second.weight; }
+    *vout = nullptr;
+    return 0.f;
+}
+/* MapGradPixelSdf::tsdf -- MapGradPixelSdf.h:109-115 */
+static inline float oracle_tsdf(const gsdfo* o, const SdfVoxel& v, Key idx, V3 p, V3* grad) {
+    const V3 gn = normalized3(V3{ v.grad[0], v.grad[1], v.grad[2] });
+    const V3 g = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };       /* 1.2 is promoted to float by Eigen */
+    if (grad) *grad = g;
+    const V3 c = o->vox2float(idx);
+    const V3 d = { c.x - p.x, c.y - p.y, c.z - p.z };
+    return v.dist + dot3(g, d);
+}
+
+void gsdfo_query(const gsdfo* o, const float* pts, int64_t n, float* dist, float* grad, float* w) {
+    for (int64_t i = 0; i < n; ++i) {
+        const V3 p = { pts[3 * i], pts[3 * i + 1], pts[3 * i + 2] };
+        const SdfVoxel* v; Key k;
+        const float w0 = oracle_weights(o, p, &v, &k);
+        w[i] = w0;
+        V3 g = { 0.f, 0.f, 0.f };
+        float phi = 0.f;
+        if (v) phi = oracle_tsdf(o, *v, k, p, &g);
+        dist[i] = phi;
+        grad[3 * i] = g.x; grad[3 * i + 1] = g.y; grad[3 * i + 2] = g.z;
+    }
+}
+
+/* ---- Eigen / Sophus restatements (third-party code absent, unpinned) ---------------------- */
+
+/* Eigen::QuaternionBase::toRotationMatrix */
+void gsdfo_quat_to_R(const float q[4], float R[9]) {
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.f - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
+}
+
+/* Eigen quaternionbase_assign_impl<Matrix3> (rotation matrix -> quaternion) */
+void gsdfo_R_to_quat(const float m[9], float q[4]) {
+    float t = m[0] + m[4] + m[8];
+    if (t > 0.f) {
+        t = std::sqrt(t + 1.0f);
+        q[3] = 0.5f * t;
+        t = 0.5f / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0f);
+        q[i] = 0.5f * t;
+        t = 0.5f / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+
+/* Sophus: SO3::expAndTheta, SE3::exp, SE3 group product (quaternion product + normalisation,
+ * translation t1 + q1*t2 via Eigen's _transformVector).  pose = exp(xi) * pose. */
+void gsdfo_se3_exp_mul(const float xi[6], float pose7[7]) {
+    const float eps = 1e-5f;                                   /* Sophus::Constants<float>::epsilon() */
+    const V3 ups = { xi[0], xi[1], xi[2] };
+    const V3 om = { xi[3], xi[4], xi[5] };
+    const float theta_sq = sum3(om.x * om.x, om.y * om.y, om.z * om.z);
+    float theta, imag, real;
+    if (theta_sq < eps * eps) {
+        theta = 0.f;
+        const float theta_po4 = theta_sq * theta_sq;
+        imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
+        real = 1.f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * theta_po4;
+    } else {
+        theta = std::sqrt(theta_sq);
+        const float half = 0.5f * theta;
+        imag = std::sin(half) / theta;
+        real = std::cos(half);
+    }
+    const float qe[4] = { imag * om.x, imag * om.y, imag * om.z, real };   /* x y z w */
+    /* V matrix */
+    float Om[9] = { 0.f, -om.z, om.y, om.z, 0.f, -om.x, -om.y, om.x, 0.f };
+    float Om2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Om2[3 * i + j] = sum3(Om[3 * i] * Om[j], Om[3 * i + 1] * Om[3 + j], Om[3 * i + 2] * Om[6 + j]);
+    float V[9];
+    if (theta < eps) {
+        gsdfo_quat_to_R(qe, V);                                /* V = so3.matrix() */
+    } else {
+        const float tsq = theta * theta;
+        const float a = (1.f - std::cos(theta)) / tsq;
+        const float b = (theta - std::sin(theta)) / (tsq * theta);
+        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + a * Om[i] + b * Om2[i];
+    }
+    const V3 te = matvec(V, ups);
+    /* group product: (qe, te) * (q, t) */
+    const float ax = qe[0], ay = qe[1], az = qe[2], aw = qe[3];
+    const float bx = pose7[3], by = pose7[4], bz = pose7[5], bw = pose7[6];
+    float qn[4];
+    qn[3] = aw * bw - ax * bx - ay * by - az * bz;
+    qn[0] = aw * bx + ax * bw + ay * bz - az * by;
+    qn[1] = aw * by + ay * bw + az * bx - ax * bz;
+    qn[2] = aw * bz + az * bw + ax * by - ay * bx;
+    const float len = std::sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+    for (int i = 0; i < 4; ++i) qn[i] /= len;
+    /* t_new = te + qe * t  (uv = qv x t; uv += uv; t + w*uv + qv x uv) */
+    const V3 qv = { ax, ay, az };
+    const V3 tt = { pose7[0], pose7[1], pose7[2] };
+    V3 uv = cross3(qv, tt);
+    uv.x += uv.x; uv.y += uv.y; uv.z += uv.z;
+    const V3 c2 = cross3(qv, uv);
+    pose7[0] = te.x + (tt.x + aw * uv.x + c2.x);
+    pose7[1] = te.y + (tt.y + aw * uv.y + c2.y);
+    pose7[2] = te.z + (tt.z + aw * uv.z + c2.z);
+    pose7[3] = qn[0]; pose7[4] = qn[1]; pose7[5] = qn[2]; pose7[6] = qn[3];
+}
+
+/* 6x6 LLT solve restating Eigen's unblocked llt_inplace<float,Lower> + triangular solves.
+ * On a non-positive pivot Eigen stops the factorisation and solve() still runs on what is
+ * there (=> inf/NaN for an all-zero H, SURVEY.md gotcha 9). */
+static void llt_solve6(const float Hin[36], const float g[6], float x[6]) {
+    float L[36];
+    std::memcpy(L, Hin, sizeof(L));
+    for (int k = 0; k < 6; ++k) {
+        float d = L[6 * k + k];
+        for (int j = 0; j < k; ++j) d -= L[6 * k + j] * L[6 * k + j];
+        if (d <= 0.f) break;
+        d = std::sqrt(d);
+        L[6 * k + k] = d;
+        for (int i = k + 1; i < 6; ++i) {
+            float s = L[6 * i + k];
+            for (int j = 0; j < k; ++j) s -= L[6 * i + j] * L[6 * k + j];
+            L[6 * i + k] = s / d;
+        }
+    }
+    float y[6];
+    for (int i = 0; i < 6; ++i) {          /* L y = g */
+        float s = g[i];
+        for (int j = 0; j < i; ++j) s -= L[6 * i + j] * y[j];
+        y[i] = s / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; --i) {         /* L^T x = y */
+        float s = y[i];
+        for (int j = i + 1; j < 6; ++j) s -= L[6 * j + i] * x[j];
+        x[i] = s / L[6 * i + i];
+    }
+}
+
+/* RigidPointOptimizer::optimize_sampled(depth, K, sampling=1) -- RigidPointOptimizer.cpp:40-99 */
+int gsdfo_track(gsdfo* o, const float* depth, const float K[9], float pose7[7],
+                int num_iterations, float conv_threshold, float damping,
+                int omp, int* iters_used, float* trace, int64_t* hits) {
+    const float z_min = o->z_min_, z_max = o->z_max_;
+    const int w = o->W, h = o->H;
+    const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const float fx_inv = 1.f / fx, fy_inv = 1.f / fy;                 /* :46-47 */
+    const float conv_sq = conv_threshold * conv_threshold;            /* RigidOptimizer.h:72 */
+    int used = 0;
+    for (int k = 0; k < num_iterations; ++k) {                        /* :51 */
+        float R[9];
+        gsdfo_quat_to_R(pose7 + 3, R);                                /* :53 pose_.rotationMatrix() */
+        const V3 t = { pose7[0], pose7[1], pose7[2] };
+        float E = 0.f;
+        float g[6] = { 0 }, Hm[36] = { 0 };
+        size_t counter = 0;
+
+        auto pixel = [&](int x, int y, float& E_, float* g_, float* H_, size_t& c_) {
+            const float z = depth[(size_t)y * w + x];
+            if (z <= z_min || z >= z_max) return;                     /* :64-65 */
+            const float x0 = ((float)x - cx) * fx_inv;                /* :67-68 */
+            const float y0 = ((float)y - cy) * fy_inv;
+            V3 p = { x0 * z, y0 * z, z };
+            const V3 Rp = matvec(R, p);
+            p = V3{ Rp.x + t.x, Rp.y + t.y, Rp.z + t.z };             /* :70 */
+            const SdfVoxel* v; Key idx;
+            const float w0 = oracle_weights(o, p, &v, &idx);          /* :72 */
+            if (w0 > 0) {
+                V3 gc;
+                const float phi0 = oracle_tsdf(o, *v, idx, p, &gc);   /* :75 */
+                E_ += phi0 * phi0;                                    /* :76 */
+                const V3 pxg = cross3(p, gc);
+                const float J[6] = { gc.x, gc.y, gc.z, pxg.x, pxg.y, pxg.z };   /* :77-78 */
+                for (int i = 0; i < 6; ++i) g_[i] += phi0 * J[i];     /* :79 */
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) H_[6 * i + j] += J[i] * J[j];   /* :80 */
+                ++c_;
+            }
+        };
+
+        if (omp) {
+#ifdef _OPENMP
+            const int nt = o->threads;
+            std::vector<float> Es(nt, 0.f), gs(6 * nt, 0.f), Hs(36 * nt, 0.f);
+            std::vector<size_t> cs(nt, 0);
+#pragma omp parallel num_threads(nt)
+            {
+                const int tid = omp_get_thread_num();
+                float E_ = 0.f, g_[6] = { 0 }, H_[36] = { 0 };
+                size_t c_ = 0;
+#pragma omp for schedule(static)
+                for (int y = 0; y < h; ++y)
+                    for (int x = 0; x < w; ++x) pixel(x, y, E_, g_, H_, c_);
+                Es[tid] = E_; cs[tid] = c_;
+                std::memcpy(&gs[6 * tid], g_, sizeof(g_));
+                std::memcpy(&Hs[36 * tid], H_, sizeof(H_));
+            }
+            for (int tdx = 0; tdx < nt; ++tdx) {
+                E += Es[tdx]; counter += cs[tdx];
+                for (int i = 0; i < 6; ++i) g[i] += gs[6 * tdx + i];
+                for (int i = 0; i < 36; ++i) Hm[i] += Hs[36 * tdx + i];
+            }
+#else
+            for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) pixel(x, y, E, g, Hm, counter);
+#endif
+        } else {
+            for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) pixel(x, y, E, g, Hm, counter);   /* :62 */
+        }
+
+        float xi[6];
+        llt_solve6(Hm, g, xi);                                        /* :86 */
+        for (int i = 0; i < 6; ++i) xi[i] = damping * xi[i];
+        float nrm = 0.f;                                              /* Eigen redux of 6: (x0+(x1+x2)) + (x3+(x4+x5)) */
+        nrm = sum3(xi[0] * xi[0], xi[1] * xi[1], xi[2] * xi[2]) + sum3(xi[3] * xi[3], xi[4] * xi[4], xi[5] * xi[5]);
+        if (trace) {
+            float* tr = trace + 36 * k;
+            tr[0] = E;
+            for (int i = 0; i < 6; ++i) tr[1 + i] = g[i];
+            int q = 7;
+            for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) tr[q++] = Hm[6 * i + j];
+            tr[28] = (float)counter;
+            for (int i = 0; i < 6; ++i) tr[29 + i] = xi[i];
+            tr[35] = nrm;
+        }
+        if (hits) hits[k] = (int64_t)counter;
+        used = k + 1;
+        if (nrm < conv_sq) {                                          /* :88-91: xi NOT applied */
+            if (iters_used) *iters_used = used;   /* passes executed; the reference prints k */
+            return 1;
+        }
+        bool nan = false;
+        for (int i = 0; i < 6; ++i) if (std::isnan(xi[i])) nan = true;
+        if (!nan) {                                                   /* :94-95 pose_ = SE3::exp(-xi) * pose_ */
+            float mxi[6];
+            for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
+            gsdfo_se3_exp_mul(mxi, pose7);
+        }
+    }
+    if (iters_used) *iters_used = used;
+    return 0;                                                         /* :98 */
+}
+
+} // extern "C"

@@ -1,0 +1,171 @@
+"""ctypes wrapper around the CPU ORACLE (oracle/libgsdf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/gsdf_oracle.h.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module,
+and only as the checker / the timed CPU baseline.  PARITY UNPINNED by the
+reference (it ships no tests or fixtures); pinned by analytic known-answer tests.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgsdf_oracle.so")
+
+
+def build(force=False):
+    """Compile the oracle with g++ (oracle/Makefile).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "gsdf_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libgsdf_oracle.so"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.gsdfo_create.restype = C.c_void_p
+        L.gsdfo_create.argtypes = [C.c_float, C.c_float]
+        L.gsdfo_destroy.argtypes = [C.c_void_p]
+        L.gsdfo_set_zrange.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.gsdfo_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.gsdfo_normals_init.restype = C.c_int
+        L.gsdfo_normals_init.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, C.c_int]
+        L.gsdfo_normals_cache.argtypes = [C.c_void_p, fp]
+        L.gsdfo_normals_compute.argtypes = [C.c_void_p, fp, fp, fp, fp]
+        L.gsdfo_update.restype = C.c_int64
+        L.gsdfo_update.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.POINTER(C.c_int64)]
+        L.gsdfo_count.restype = C.c_int64
+        L.gsdfo_count.argtypes = [C.c_void_p]
+        L.gsdfo_frame_counter.restype = C.c_int64
+        L.gsdfo_frame_counter.argtypes = [C.c_void_p]
+        L.gsdfo_export.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp]
+        L.gsdfo_export_vis.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
+        L.gsdfo_query.argtypes = [C.c_void_p, fp, C.c_int64, fp, fp, fp]
+        L.gsdfo_track.restype = C.c_int
+        L.gsdfo_track.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_float, C.c_float, C.c_int,
+                                  C.POINTER(C.c_int), fp, C.POINTER(C.c_int64)]
+        L.gsdfo_quat_to_R.argtypes = [fp, fp]
+        L.gsdfo_R_to_quat.argtypes = [fp, fp]
+        L.gsdfo_se3_exp_mul.argtypes = [fp, fp]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Oracle:
+    """CPU restatement of MapGradPixelSdf + RigidPointOptimizer + NormalEstimator."""
+
+    def __init__(self, voxel_size, trunc_dist, W, H, K, win=11, zmin=0.5, zmax=3.5, threads=4):
+        self.L = lib()
+        self.h = self.L.gsdfo_create(np.float32(voxel_size), np.float32(trunc_dist))
+        self.W, self.H = int(W), int(H)
+        self.K = _f32(K).reshape(9)
+        self.L.gsdfo_set_zrange(self.h, np.float32(zmin), np.float32(zmax))
+        self.L.gsdfo_set_threads(self.h, int(threads))
+        rc = self.L.gsdfo_normals_init(self.h, self.W, self.H, _fp(self.K), int(win))
+        if rc != 0:
+            raise ValueError("gsdfo_normals_init failed")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.gsdfo_destroy(self.h)
+            self.h = None
+
+    def normals_cache(self):
+        out = np.empty((11, self.H, self.W), np.float32)
+        self.L.gsdfo_normals_cache(self.h, _fp(out))
+        return out
+
+    def normals(self, depth):
+        d = _f32(depth).reshape(self.H, self.W)
+        n = np.empty((3, self.H, self.W), np.float32)
+        self.L.gsdfo_normals_compute(self.h, _fp(d), _fp(n[0]), _fp(n[1]), _fp(n[2]))
+        return n
+
+    def update(self, depth, R, t, omp=False):
+        d = _f32(depth).reshape(self.H, self.W)
+        R = _f32(R).reshape(9)
+        t = _f32(t).reshape(3)
+        nv = C.c_int64(0)
+        n_upd = self.L.gsdfo_update(self.h, _fp(d), _fp(R), _fp(t), int(bool(omp)), C.byref(nv))
+        return int(n_upd), int(nv.value)
+
+    def count(self):
+        return int(self.L.gsdfo_count(self.h))
+
+    def frame_counter(self):
+        return int(self.L.gsdfo_frame_counter(self.h))
+
+    def export(self):
+        n = self.count()
+        keys = np.empty((n, 3), np.int32)
+        pay = np.empty((n, 5), np.float32)
+        if n:
+            self.L.gsdfo_export(self.h, keys.ctypes.data_as(C.POINTER(C.c_int32)), _fp(pay))
+        return keys, pay
+
+    def export_vis(self, words_per_voxel):
+        n = self.count()
+        out = np.zeros((n, words_per_voxel), np.uint32)
+        if n:
+            self.L.gsdfo_export_vis(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)), int(words_per_voxel))
+        return out
+
+    def query(self, pts):
+        p = _f32(pts).reshape(-1, 3)
+        n = p.shape[0]
+        dist = np.empty(n, np.float32)
+        grad = np.empty((n, 3), np.float32)
+        w = np.empty(n, np.float32)
+        self.L.gsdfo_query(self.h, _fp(p), n, _fp(dist), _fp(grad), _fp(w))
+        return dist, grad, w
+
+    def track(self, depth, pose7, iters=25, conv=1e-3, damping=1.0, omp=False):
+        """Returns (converged, pose7, iters_used, trace[iters_used,36], hits[iters_used])."""
+        d = _f32(depth).reshape(self.H, self.W)
+        p = _f32(pose7).reshape(7).copy()
+        used = C.c_int(0)
+        trace = np.zeros((iters, 36), np.float32)
+        hits = np.zeros(iters, np.int64)
+        conv_flag = self.L.gsdfo_track(self.h, _fp(d), _fp(self.K), _fp(p), int(iters), np.float32(conv),
+                                       np.float32(damping), int(bool(omp)), C.byref(used), _fp(trace),
+                                       hits.ctypes.data_as(C.POINTER(C.c_int64)))
+        u = used.value
+        return bool(conv_flag), p, u, trace[:u], hits[:u]
+
+
+def quat_to_R(q_xyzw):
+    q = _f32(q_xyzw).reshape(4)
+    R = np.empty(9, np.float32)
+    lib().gsdfo_quat_to_R(_fp(q), _fp(R))
+    return R.reshape(3, 3)
+
+
+def R_to_quat(R):
+    R = _f32(R).reshape(9)
+    q = np.empty(4, np.float32)
+    lib().gsdfo_R_to_quat(_fp(R), _fp(q))
+    return q
+
+
+def se3_exp_mul(xi, pose7):
+    xi = _f32(xi).reshape(6)
+    p = _f32(pose7).reshape(7).copy()
+    lib().gsdfo_se3_exp_mul(_fp(xi), _fp(p))
+    return p
