@@ -175,6 +175,9 @@ int read_state(gsdf_ctx* c, gsdf_dev_state* out) {
 extern "C" {
 
 const char* gsdf_last_error(void) { return g_err.c_str(); }
+extern int g_fuse_debug;
+/* experiment switch for kernel ablations (tools/); not part of include/gsdf.h */
+void gsdf_debug_flags(int flags) { g_fuse_debug = flags; }
 const char* gsdf_version(void) { return "gsdf-mi355x 0.1 (gfx950)"; }
 
 int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device) {
@@ -200,7 +203,7 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
     c->n_slots = (size_t)1 << capacity_log2;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc((void**)&c->tab.slots, c->n_slots * sizeof(gsdf_slot))) != hipSuccess ||
+        (e = hipMalloc((void**)&c->tab.buckets, (c->n_slots / GSDF_BUCKET) * sizeof(gsdf_bucket))) != hipSuccess ||
         (e = hipMalloc((void**)&c->st, sizeof(gsdf_dev_state))) != hipSuccess ||
         (e = hipMalloc((void**)&c->counter, sizeof(unsigned long long))) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
@@ -221,7 +224,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    void* ptrs[] = { c->tab.slots, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
+    void* ptrs[] = { c->tab.buckets, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -265,8 +268,8 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipMalloc((void**)&c->planes, 11 * N * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->depth_stage, N * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->normals, 3 * N * sizeof(float)));
-    /* one tracker workgroup per 1024 pixels (4 pixels per lane), at least one */
-    c->track_blocks = (int)std::max<size_t>(1, (N + 1023) / 1024);
+    /* tracker grid: a multiple of the 256 CUs when the frame is large enough, 1-4 pixels per lane */
+    c->track_blocks = N >= (size_t)1 << 20 ? 1024 : N >= (size_t)1 << 18 ? 512 : (int)std::max<size_t>(1, (N + 511) / 512);
     HIP_TRY(hipMalloc((void**)&c->partials, (size_t)c->track_blocks * 32 * sizeof(float)));
     c->fuse_blocks = gsdf_fuse_grid_blocks(W, H);
     HIP_TRY(hipMalloc((void**)&c->blk_counters, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long)));

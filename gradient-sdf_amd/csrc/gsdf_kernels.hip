@@ -47,22 +47,21 @@ __device__ __forceinline__ int reflect101(int i, int n) {      /* cv::BORDER_REF
 }
 
 /* ------------------------------------------------------------------------------------------------
- * table clear
+ * table clear: keys = EMPTY, payloads = 0 (so an insert never has to initialise a payload)
  * ---------------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__(256) void k_table_clear(gsdf_slot* slots, size_t n) {
+__global__ __launch_bounds__(256) void k_table_clear(gsdf_bucket* buckets, size_t n_buckets) {
+    /* 8 lanes per 128-byte bucket, one 16-byte store each: fully coalesced */
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    /* one 32-byte slot = two 16-byte stores */
-    const uint4 a = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-    const uint4 b = make_uint4(0u, 0u, 0u, 0u);
-    for (; i < n; i += stride) {
-        uint4* p = reinterpret_cast<uint4*>(slots + i);
-        p[0] = a;
-        p[1] = b;
+    const size_t n16 = n_buckets * 8;
+    uint4* p = reinterpret_cast<uint4*>(buckets);
+    for (; i < n16; i += stride) {
+        const uint32_t v = (i & 7) < 2 ? 0xFFFFFFFFu : 0u;
+        p[i] = make_uint4(v, v, v, v);
     }
 }
 void gsdf_launch_table_clear(hipStream_t s, gsdf_table tab, size_t n_slots) {
-    hipLaunchKernelGGL(k_table_clear, dim3(2048), dim3(256), 0, s, tab.slots, n_slots);
+    hipLaunchKernelGGL(k_table_clear, dim3(2048), dim3(256), 0, s, tab.buckets, n_slots / GSDF_BUCKET);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -188,14 +187,22 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
  *
  * One workgroup = one 16x16 pixel tile (4 waves, each an 8x8 sub-tile so that a wave's 64 rays
  * stay spatially compact).  Each lane walks its ray's 2*factor+1 samples.  Neighbouring pixels and
- * consecutive samples hit the same voxels (~10 updates per distinct voxel per frame), so updates
- * are first combined in a workgroup-private open-addressed table in LDS with LDS atomics and only
- * the distinct voxels of the tile are flushed to the HBM table (1 probe + 5 float atomics each).
- * Samples that do not fit the LDS table go to HBM directly.
+ * consecutive samples hit the same voxels (~5-10 updates per distinct voxel per frame), so updates
+ * are first combined in a workgroup-private open-addressed table in LDS and only the distinct
+ * voxels of the tile are flushed to the HBM table (1 probe + 5 float atomics each).
+ *
+ * Measured on MI355X (tools/atomics_bench.hip): ds_add_f32 is lane-serial (~190 cycles per
+ * wave instruction) while ds_add_u64 costs 8-29 cycles, so the LDS accumulators are 64-bit
+ * FIXED POINT (2^-40): every float term converts exactly, the per-tile sums are exact and
+ * order-independent, and one rounding to float happens at the flush.  Lanes start their ray walk
+ * at skewed sample indices so that neighbouring lanes (same voxel at the same k) do not hit the
+ * same LDS address in the same instruction.  Samples that do not fit the LDS table go to HBM
+ * directly.
  * ---------------------------------------------------------------------------------------------- */
 #define FUSE_T 16
-#define FUSE_LCAP 2048
-#define FUSE_LPROBE 16
+#define FUSE_LCAP 1536
+#define FUSE_LPROBE 12
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 struct fuse_args {
     gsdf_frame_geom g;
@@ -207,14 +214,33 @@ struct fuse_args {
     gsdf_table tab;
     gsdf_dev_state* st;
     unsigned long long* blk_counters;   /* [n_blocks][4]: last n_upd, last n_valid, cum n_upd, cum n_valid */
+    int debug;                          /* experiment switches (gsdf_debug_flags); 0 in production */
 };
+
+struct fuse_lds {
+    unsigned long long key[FUSE_LCAP] __attribute__((aligned(16)));
+    unsigned long long w[FUSE_LCAP], s[FUSE_LCAP], gx[FUSE_LCAP], gy[FUSE_LCAP], gz[FUSE_LCAP];
+    float red[8];
+};
+
+/* float -> signed 2^-40 fixed point, exact for 2^-17 <= |x| < 2^23 (smaller terms keep 2^-40 resolution) */
+__device__ __forceinline__ unsigned long long f2fix(float x) {
+    const int b = __float_as_int(x);
+    const int e = (b >> 23) & 0xFF;
+    const long long m = (long long)((b & 0x7FFFFF) | (e ? 0x800000 : 0));
+    const int sh = e - 110;                       /* value = m * 2^(e-150); fixed = value * 2^40 */
+    long long v = sh >= 0 ? (m << (sh > 38 ? 38 : sh)) : (m >> (-sh > 63 ? 63 : -sh));
+    if (b < 0) v = -v;
+    return (unsigned long long)v;
+}
+__device__ __forceinline__ float fix2f(unsigned long long v) {
+    return __ll2float_rn((long long)v) * 9.094947017729282e-13f;   /* 2^-40 */
+}
 
 __device__ __forceinline__ void hbm_accumulate(const gsdf_table& T, unsigned long long key, float w, float s,
                                                float gx, float gy, float gz, gsdf_dev_state* st) {
-    bool inserted;
-    const long long slot = gsdf_find_or_insert(T, key, &inserted);
-    if (slot < 0) { atomicOr(&st->status, GSDF_STATUS_TABLE_FULL); return; }
-    gsdf_slot* p = T.slots + slot;
+    gsdf_payload* p = gsdf_find_or_insert(T, key);
+    if (!p) { atomicOr(&st->status, GSDF_STATUS_TABLE_FULL); return; }
     unsafeAtomicAdd(&p->w, w);
     unsafeAtomicAdd(&p->s, s);
     unsafeAtomicAdd(&p->gx, gx);
@@ -222,15 +248,15 @@ __device__ __forceinline__ void hbm_accumulate(const gsdf_table& T, unsigned lon
     unsafeAtomicAdd(&p->gz, gz);
 }
 
+int g_fuse_debug = 0;
 __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
-    __shared__ unsigned long long lkey[FUSE_LCAP];
-    __shared__ float lw[FUSE_LCAP], ls[FUSE_LCAP], lgx[FUSE_LCAP], lgy[FUSE_LCAP], lgz[FUSE_LCAP];
-    __shared__ float red[8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    fuse_lds& L = *reinterpret_cast<fuse_lds*>(smem_raw);
     if (a.use_dev_pose && !a.st->converged) return;        /* main_scan_3d.cpp:261: if (conv) update */
     const int tid = threadIdx.x;
     for (int i = tid; i < FUSE_LCAP; i += 256) {
-        lkey[i] = GSDF_KEY_EMPTY;
-        lw[i] = 0.f; ls[i] = 0.f; lgx[i] = 0.f; lgy[i] = 0.f; lgz[i] = 0.f;
+        L.key[i] = GSDF_KEY_EMPTY;
+        L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
     }
     float R[9], t[3];
     if (a.use_dev_pose) {
@@ -248,8 +274,9 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
 
     const gsdf_frame_geom& g = a.g;
     const int wave = tid >> 6, lane = tid & 63;
-    const int px = blockIdx.x * FUSE_T + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * FUSE_T + (wave >> 1) * 8 + (lane >> 3);
+    const int lx = lane & 7, ly = lane >> 3;
+    const int px = blockIdx.x * FUSE_T + (wave & 1) * 8 + lx;
+    const int py = blockIdx.y * FUSE_T + (wave >> 1) * 8 + ly;
     bool valid = px < g.W && py < g.H;
     float z = 0.f;
     gsdf_v3 Rxy = { 0.f, 0.f, 0.f }, Rn = { 0.f, 0.f, 0.f };
@@ -269,7 +296,12 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
     }
     float n_upd = 0.f;
     if (valid) {
-        for (int kk = -g.factor; kk <= g.factor; ++kk) {                   /* :101 */
+        const int nk = 2 * g.factor + 1;
+        /* skew: lanes of a 3x3 pixel neighbourhood walk different samples in the same instruction */
+        int it = (2 * ((lx % 3) + 3 * (ly % 3))) % nk;
+        for (int c = 0; c < nk; ++c) {                                     /* :101 (order is free: sums) */
+            const int kk = it - g.factor;
+            it = it + 1 == nk ? 0 : it + 1;
             const float s = z + (float)kk * g.vs;
             const float pxw = s * Rxy.x + t[0], pyw = s * Rxy.y + t[1], pzw = s * Rxy.z + t[2];   /* :103 */
             const int vx = gsdf_float2vox1(g.inv_vs, pxw);                 /* :104 */
@@ -285,39 +317,80 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
                 const unsigned long long key = gsdf_key_pack(vx, vy, vz);
                 const float ws = w * gsdf_truncate(sdf, g.T);              /* :111 as additive sum */
                 const float wgx = w * Rn.x, wgy = w * Rn.y, wgz = w * Rn.z;   /* :112 */
-                uint32_t h = (gsdf_hash(key) >> 11) & (FUSE_LCAP - 1);
-                bool done = false;
-                for (int p = 0; p < FUSE_LPROBE; ++p) {
-                    unsigned long long cur = *(volatile unsigned long long*)&lkey[h];
-                    if (cur == GSDF_KEY_EMPTY) cur = atomicCAS(&lkey[h], GSDF_KEY_EMPTY, key);
-                    if (cur == GSDF_KEY_EMPTY || cur == key) {
-                        atomicAdd(&lw[h], w);
-                        atomicAdd(&ls[h], ws);
-                        atomicAdd(&lgx[h], wgx);
-                        atomicAdd(&lgy[h], wgy);
-                        atomicAdd(&lgz[h], wgz);
-                        done = true;
-                        break;
-                    }
-                    h = (h + 1) & (FUSE_LCAP - 1);
+                /* LDS table = FUSE_LCAP/4 buckets of 4 keys; one probe = two ds_read_b128 of one bucket */
+                uint32_t hh = (a.debug & 256) ? ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) : gsdf_hash(key ^ 0x9E3779B97F4A7C15ull);
+                uint32_t b = (uint32_t)(((unsigned long long)hh * (FUSE_LCAP / 4)) >> 32);
+                const bool cheapfix = (a.debug & 128) != 0;
+                const unsigned long long qw = cheapfix ? (unsigned long long)__float_as_uint(w) : f2fix(w);
+                const unsigned long long qs = cheapfix ? (unsigned long long)__float_as_uint(ws) : f2fix(ws);
+                const unsigned long long qx = cheapfix ? (unsigned long long)__float_as_uint(wgx) : f2fix(wgx);
+                const unsigned long long qy = cheapfix ? (unsigned long long)__float_as_uint(wgy) : f2fix(wgy);
+                const unsigned long long qz = cheapfix ? (unsigned long long)__float_as_uint(wgz) : f2fix(wgz);
+                if (a.debug & 512) {
+                    atomicAdd(&L.w[4 * b], qw); atomicAdd(&L.s[4 * b], qs); atomicAdd(&L.gx[4 * b], qx);
+                    atomicAdd(&L.gy[4 * b], qy); atomicAdd(&L.gz[4 * b], qz);
+                    continue;
                 }
-                if (!done) hbm_accumulate(a.tab, key, w, ws, wgx, wgy, wgz, a.st);
+                bool done = (a.debug & 2) != 0;
+                for (int p = 0; p < FUSE_LPROBE && !done; ++p) {
+                    /* plain (non-volatile) LDS reads -> ds_read_b128; a stale EMPTY is resolved by the CAS,
+                     * and a volatile access here would be lowered to a slow flat_load sc0 sc1 */
+                    const u64x2 k01 = *reinterpret_cast<const u64x2*>(&L.key[4 * b]);
+                    const u64x2 k23 = *reinterpret_cast<const u64x2*>(&L.key[4 * b + 2]);
+                    /* branch-free: index of the matching key, else of the first empty slot */
+                    int hit = k23.y == key ? 3 : -1;
+                    hit = k23.x == key ? 2 : hit;
+                    hit = k01.y == key ? 1 : hit;
+                    hit = k01.x == key ? 0 : hit;
+                    int emp = k23.y == GSDF_KEY_EMPTY ? 3 : -1;
+                    emp = k23.x == GSDF_KEY_EMPTY ? 2 : emp;
+                    emp = k01.y == GSDF_KEY_EMPTY ? 1 : emp;
+                    emp = k01.x == GSDF_KEY_EMPTY ? 0 : emp;
+                    int slot = hit >= 0 ? 4 * b + hit : -1;
+                    if (hit < 0 && emp >= 0) {                      /* at most ONE CAS per probe */
+                        const unsigned long long old = atomicCAS(&L.key[4 * b + emp], GSDF_KEY_EMPTY, key);
+                        if (old == GSDF_KEY_EMPTY || old == key) slot = 4 * b + emp;
+                        /* else: lost the slot to another voxel -> re-read the same bucket */
+                    } else if (hit < 0) {
+                        b = b + 1 == FUSE_LCAP / 4 ? 0 : b + 1;     /* bucket full of other voxels */
+                    }
+                    if (slot >= 0) {
+                        if (!(a.debug & 32))
+                        atomicAdd(&L.w[slot], qw);
+                        atomicAdd(&L.s[slot], qs);
+                        atomicAdd(&L.gx[slot], qx);
+                        atomicAdd(&L.gy[slot], qy);
+                        atomicAdd(&L.gz[slot], qz);
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    if (a.debug & 64) atomicAdd(&a.st->n_hit, 1ull);      /* experiment: count LDS overflows */
+                    if (!(a.debug & 16)) hbm_accumulate(a.tab, key, w, ws, wgx, wgy, wgz, a.st);
+                }
             }
         }
     }
     __syncthreads();
     /* flush the tile's distinct voxels to the HBM table */
+    if (!(a.debug & 1))
     for (int i = tid; i < FUSE_LCAP; i += 256) {
-        const unsigned long long key = lkey[i];
-        if (key != GSDF_KEY_EMPTY) hbm_accumulate(a.tab, key, lw[i], ls[i], lgx[i], lgy[i], lgz[i], a.st);
+        const unsigned long long key = L.key[i];
+        if (key != GSDF_KEY_EMPTY) {
+            const float fw = fix2f(L.w[i]), fs = fix2f(L.s[i]), fx = fix2f(L.gx[i]), fy = fix2f(L.gy[i]), fz = fix2f(L.gz[i]);
+            if (a.debug & 4) {
+                if (!gsdf_find_or_insert(a.tab, key)) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
+            } else
+                hbm_accumulate(a.tab, key, fw, fs, fx, fy, fz, a.st);
+        }
     }
     /* per-workgroup counters (plain stores into this workgroup's own row: no hot atomics) */
     const float wu = wave_sum(n_upd), wv = wave_sum(valid ? 1.f : 0.f);
-    if (lane == 0) { red[wave] = wu; red[4 + wave] = wv; }
+    if (lane == 0) { L.red[wave] = wu; L.red[4 + wave] = wv; }
     __syncthreads();
     if (tid == 0) {
-        const unsigned long long nu = (unsigned long long)(red[0] + red[1] + red[2] + red[3]);
-        const unsigned long long nv = (unsigned long long)(red[4] + red[5] + red[6] + red[7]);
+        const unsigned long long nu = (unsigned long long)(L.red[0] + L.red[1] + L.red[2] + L.red[3]);
+        const unsigned long long nv = (unsigned long long)(L.red[4] + L.red[5] + L.red[6] + L.red[7]);
         unsigned long long* c = a.blk_counters + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
         c[0] = nu; c[1] = nv; c[2] += nu; c[3] += nv;
         if (blockIdx.x == 0 && blockIdx.y == 0) a.st->frames += 1;        /* :120 increase_counter() */
@@ -325,13 +398,20 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
 }
 
 void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
-                         const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
-                         int use_dev_pose, gsdf_table tab, gsdf_dev_state* st, unsigned long long* blk_counters) {
+                      const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
+                      int use_dev_pose, gsdf_table tab, gsdf_dev_state* st, unsigned long long* blk_counters) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fuse), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sizeof(fuse_lds));
+        attr_set = true;
+    }
     fuse_args a;
+    a.debug = g_fuse_debug;
     a.g = g; a.nc = nc; a.depth = depth; a.nx = nx; a.ny = ny; a.nz = nz; a.pose = pose;
     a.use_dev_pose = use_dev_pose; a.tab = tab; a.st = st; a.blk_counters = blk_counters;
     dim3 grid((g.W + FUSE_T - 1) / FUSE_T, (g.H + FUSE_T - 1) / FUSE_T);
-    hipLaunchKernelGGL(k_fuse, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_fuse, grid, dim3(256), sizeof(fuse_lds), s, a);
 }
 int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T); }
 
@@ -364,6 +444,8 @@ void gsdf_launch_track_begin(hipStream_t s, gsdf_dev_state* st, int max_passes, 
     hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st, max_passes, conv_sq, damping);
 }
 
+#define TRK_PPT 4          /* pixels per lane handled as one batch: 4 independent gathers in flight */
+
 __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
                                                                  gsdf_table tab, gsdf_dev_state* st,
                                                                  float* partials) {
@@ -384,38 +466,89 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
 
     const int N = g.W * g.H;
-    for (int pix = blockIdx.x * GSDF_TRACK_BLOCK + tid; pix < N; pix += gridDim.x * GSDF_TRACK_BLOCK) {
-        const float z = depth[pix];
-        if (z <= g.zmin || z >= g.zmax) continue;                         /* :64-65 */
-        const int y = pix / g.W, x = pix - y * g.W;
-        const float x0 = ((float)x - g.cx) * fx_inv;                      /* :67-68 */
-        const float y0 = ((float)y - g.cy) * fy_inv;
-        const gsdf_v3 pc = { x0 * z, y0 * z, z };
-        const gsdf_v3 Rp = gsdf_matvec(R, pc);
-        const gsdf_v3 p = { Rp.x + t[0], Rp.y + t[1], Rp.z + t[2] };     /* :70 */
-        const int vx = gsdf_float2vox1(g.inv_vs, p.x), vy = gsdf_float2vox1(g.inv_vs, p.y),
-                  vz = gsdf_float2vox1(g.inv_vs, p.z);
-        if (!gsdf_key_in_range(vx, vy, vz)) continue;
-        const gsdf_slot* sl = gsdf_find(tab, gsdf_key_pack(vx, vy, vz)); /* weights(): MapGradPixelSdf.h:117-125 */
-        if (!sl) continue;
-        const float w0 = sl->w;
-        if (!(w0 > 0.f)) continue;                                        /* :73 */
-        /* tsdf(): MapGradPixelSdf.h:109-115 */
-        const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ sl->gx, sl->gy, sl->gz });
-        const gsdf_v3 gr = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };
-        const gsdf_v3 d = { g.vs * (float)vx - p.x, g.vs * (float)vy - p.y, g.vs * (float)vz - p.z };
-        const float phi = sl->s / w0 + gsdf_dot3(gr, d);
-        const gsdf_v3 pxg = gsdf_cross3(p, gr);                           /* :78 */
-        const float J[6] = { gr.x, gr.y, gr.z, pxg.x, pxg.y, pxg.z };
-        acc[0] += phi * phi;                                              /* :76 */
+    const int nthreads = gridDim.x * GSDF_TRACK_BLOCK;
+    for (int base = blockIdx.x * GSDF_TRACK_BLOCK + tid; base < N; base += TRK_PPT * nthreads) {
+        /* stage A: depth */
+        float z[TRK_PPT];
+        bool ok[TRK_PPT];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[1 + i] += phi * J[i];             /* :79 */
-        int q = 7;
+        for (int j = 0; j < TRK_PPT; ++j) {
+            const int pix = base + j * nthreads;
+            ok[j] = pix < N;
+            z[j] = ok[j] ? depth[pix] : 0.f;
+        }
+        /* stage B: back-project, voxel key, the 4 keys of the home bucket (one 128-byte line) */
+        gsdf_v3 p[TRK_PPT];
+        int vx[TRK_PPT], vy[TRK_PPT], vz[TRK_PPT];
+        unsigned long long key[TRK_PPT];
+        const gsdf_bucket* B[TRK_PPT];
+        ulonglong2 k01[TRK_PPT], k23[TRK_PPT];
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < TRK_PPT; ++j) {
+            const int pix = base + j * nthreads;
+            ok[j] = ok[j] && !(z[j] <= g.zmin || z[j] >= g.zmax);         /* :64-65 */
+            const int y = pix / g.W, x = pix - y * g.W;
+            const float x0 = ((float)x - g.cx) * fx_inv;                  /* :67-68 */
+            const float y0 = ((float)y - g.cy) * fy_inv;
+            const gsdf_v3 pc = { x0 * z[j], y0 * z[j], z[j] };
+            const gsdf_v3 Rp = gsdf_matvec(R, pc);
+            p[j] = gsdf_v3{ Rp.x + t[0], Rp.y + t[1], Rp.z + t[2] };      /* :70 */
+            vx[j] = gsdf_float2vox1(g.inv_vs, p[j].x);
+            vy[j] = gsdf_float2vox1(g.inv_vs, p[j].y);
+            vz[j] = gsdf_float2vox1(g.inv_vs, p[j].z);
+            ok[j] = ok[j] && gsdf_key_in_range(vx[j], vy[j], vz[j]);
+            key[j] = gsdf_key_pack(vx[j], vy[j], vz[j]);
+            B[j] = tab.buckets + (gsdf_hash(key[j]) & tab.bucket_mask);
+            if (ok[j]) {
+                k01[j] = *reinterpret_cast<const ulonglong2*>(&B[j]->key[0]);
+                k23[j] = *reinterpret_cast<const ulonglong2*>(&B[j]->key[2]);
+            } else {
+                k01[j] = make_ulonglong2(GSDF_KEY_EMPTY, GSDF_KEY_EMPTY);
+                k23[j] = k01[j];
+            }
+        }
+        /* stage C: payload of the hit (same line as the keys) */
+        const gsdf_payload* P[TRK_PPT];
+        float2 pa[TRK_PPT], pb[TRK_PPT], pc2[TRK_PPT];
 #pragma unroll
-            for (int j = i; j < 6; ++j) acc[q++] += J[i] * J[j];          /* :80 */
-        acc[28] += 1.f;                                                   /* :81 */
+        for (int j = 0; j < TRK_PPT; ++j) {
+            P[j] = nullptr;
+            if (ok[j]) {
+                if (k01[j].x == key[j]) P[j] = &B[j]->pay[0];
+                else if (k01[j].y == key[j]) P[j] = &B[j]->pay[1];
+                else if (k23[j].x == key[j]) P[j] = &B[j]->pay[2];
+                else if (k23[j].y == key[j]) P[j] = &B[j]->pay[3];
+                else if (k23[j].y != GSDF_KEY_EMPTY) P[j] = gsdf_find(tab, key[j]);   /* full bucket: probe on (rare) */
+            }
+            if (P[j]) {
+                const float2* q = reinterpret_cast<const float2*>(P[j]);
+                pa[j] = q[0]; pb[j] = q[1]; pc2[j] = q[2];
+            } else {
+                pa[j] = make_float2(0.f, 0.f); pb[j] = pa[j]; pc2[j] = pa[j];
+            }
+        }
+        /* stage D: residual, Jacobian, normal-equation sums */
+#pragma unroll
+        for (int j = 0; j < TRK_PPT; ++j) {
+            const float w0 = pa[j].x;                                     /* weights(): MapGradPixelSdf.h:117-125 */
+            if (!(w0 > 0.f)) continue;                                    /* :73 */
+            /* tsdf(): MapGradPixelSdf.h:109-115 */
+            const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ pb[j].x, pb[j].y, pc2[j].x });
+            const gsdf_v3 gr = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };
+            const gsdf_v3 d = { g.vs * (float)vx[j] - p[j].x, g.vs * (float)vy[j] - p[j].y, g.vs * (float)vz[j] - p[j].z };
+            const float phi = pa[j].y / w0 + gsdf_dot3(gr, d);
+            const gsdf_v3 pxg = gsdf_cross3(p[j], gr);                    /* :78 */
+            const float J[6] = { gr.x, gr.y, gr.z, pxg.x, pxg.y, pxg.z };
+            acc[0] += phi * phi;                                          /* :76 */
+#pragma unroll
+            for (int i = 0; i < 6; ++i) acc[1 + i] += phi * J[i];         /* :79 */
+            int q = 7;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int jj = i; jj < 6; ++jj) acc[q++] += J[i] * J[jj];  /* :80 */
+            acc[28] += 1.f;                                               /* :81 */
+        }
     }
 #pragma unroll
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) {
@@ -423,10 +556,13 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
         if (lane == 0) wsum[wave][i] = v;
     }
     __syncthreads();
-    if (tid < GSDF_TRACK_NSUM) {
-        float v = wsum[0][tid];
+    if (tid < 32) {
+        float v = 0.f;
+        if (tid < GSDF_TRACK_NSUM) {
+            v = wsum[0][tid];
 #pragma unroll
-        for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
+            for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
+        }
         partials[(size_t)blockIdx.x * 32 + tid] = v;
     }
     __syncthreads();
@@ -440,17 +576,31 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
     __syncthreads();
     if (!is_last) return;
 
-    /* ---- last workgroup: fixed-order sum over workgroups, solve, pose update ---- */
+    /* ---- last workgroup: fixed-order sum of the per-workgroup rows, solve, pose update ---- */
     {
-        const int j = tid >> 3, sub = tid & 7;
-        float v = 0.f;
-        if (j < GSDF_TRACK_NSUM)
-            for (unsigned int b = sub; b < gridDim.x; b += 8)
-                v += __hip_atomic_load(&partials[(size_t)b * 32 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        if (j < GSDF_TRACK_NSUM && sub == 0) tot[j] = v;
+        float r[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) r[i] = 0.f;
+        for (unsigned int b = tid; b < gridDim.x; b += GSDF_TRACK_BLOCK) {
+            const float4* row = reinterpret_cast<const float4*>(partials + (size_t)b * 32);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 v = row[i];
+                r[4 * i] += v.x; r[4 * i + 1] += v.y; r[4 * i + 2] += v.z; r[4 * i + 3] += v.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GSDF_TRACK_NSUM; ++i) {
+            const float v = wave_sum(r[i]);
+            if (lane == 0) wsum[wave][i] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < GSDF_TRACK_NSUM) {
+        float v = wsum[0][tid];
+#pragma unroll
+        for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
+        tot[tid] = v;
     }
     __syncthreads();
     if (tid == 0) {
@@ -458,11 +608,14 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
         for (int i = 0; i < 6; ++i) gvec[i] = tot[1 + i];
         int q = 7;
+#pragma unroll
         for (int i = 0; i < 6; ++i)
+#pragma unroll
             for (int j = i; j < 6; ++j) { Hm[6 * i + j] = tot[q]; Hm[6 * j + i] = tot[q]; ++q; }
         float xi[6];
         gsdf_llt_solve6(Hm, gvec, xi);                                    /* :86 */
         const float damping = st->damping;
+#pragma unroll
         for (int i = 0; i < 6; ++i) xi[i] = damping * xi[i];
         const float nrm = gsdf_sum3(xi[0] * xi[0], xi[1] * xi[1], xi[2] * xi[2]) +
                           gsdf_sum3(xi[3] * xi[3], xi[4] * xi[4], xi[5] * xi[5]);
@@ -475,13 +628,17 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
             st->done = 1;
         } else {
             bool nan = false;
+#pragma unroll
             for (int i = 0; i < 6; ++i) nan = nan || isnan(xi[i]);
             if (!nan) {                                                   /* :94-95 */
                 float mxi[6];
+#pragma unroll
                 for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
                 float pose[7];
+#pragma unroll
                 for (int i = 0; i < 7; ++i) pose[i] = st->pose7[i];
                 gsdf_se3_exp_mul(mxi, pose);
+#pragma unroll
                 for (int i = 0; i < 7; ++i) st->pose7[i] = pose[i];
                 gsdf_quat_to_R(pose + 3, st->R);
             }
@@ -533,11 +690,13 @@ __global__ __launch_bounds__(256) void k_export(gsdf_table tab, size_t n_slots, 
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n_slots; i += stride) {
-        const gsdf_slot sl = tab.slots[i];
-        if (sl.key == GSDF_KEY_EMPTY) continue;
+        const gsdf_bucket* B = tab.buckets + (i >> 2);
+        const unsigned long long key = B->key[i & 3];
+        if (key == GSDF_KEY_EMPTY) continue;
+        const gsdf_payload sl = B->pay[i & 3];
         const unsigned long long o = atomicAdd(counter, 1ull);
         if ((long long)o >= max_n) continue;
-        if (keys_out) keys_out[o] = sl.key;
+        if (keys_out) keys_out[o] = key;
         if (payload_out) {
             float* p = payload_out + 5 * o;
             if (raw) { p[0] = sl.s; p[1] = sl.gx; p[2] = sl.gy; p[3] = sl.gz; p[4] = sl.w; }
@@ -579,7 +738,7 @@ __global__ __launch_bounds__(256) void k_query(gsdf_table tab, float vs, float i
         float ow = 0.f, od = 0.f;
         gsdf_v3 og = { 0.f, 0.f, 0.f };
         if (gsdf_key_in_range(vx, vy, vz)) {
-            const gsdf_slot* sl = gsdf_find(tab, gsdf_key_pack(vx, vy, vz));
+            const gsdf_payload* sl = gsdf_find(tab, gsdf_key_pack(vx, vy, vz));
             if (sl) {
                 ow = sl->w;
                 const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ sl->gx, sl->gy, sl->gz });

@@ -4,19 +4,22 @@
  * Replaces the reference's two CPU containers
  *   tsdf_ : phmap::parallel_node_hash_map<Vector3i, SdfVoxel>   (MapGradPixelSdf.h:65-68)
  *   vis_  : phmap::parallel_flat_hash_map<Vec3i, vector<bool>>  (MapGradPixelSdf.h:70)
- * with ONE open-addressed table of 32-byte slots:
+ * with ONE open-addressed table of 128-byte buckets (= one HBM / L2 line) of 4 voxels:
  *
- *   +0  u64  key    x,y,z + 2^20 packed 21 bits each (x low, z high); ~0 = empty
- *   +8  f32  w      sum of weights                      (SdfVoxel::weight)
- *   +12 f32  s      sum of w * truncated sdf            (SdfVoxel::dist  = s / w)
- *   +16 f32  gx,gy,gz  sum of w * R n                   (SdfVoxel::grad)
- *   +28 u32  aux    last frame index that touched the voxel + 1 (vis_ stand-in)
+ *   +0   u64 key[4]     x,y,z + 2^20 packed 21 bits each (x low, z high); ~0 = empty
+ *   +32  payload[4]     6 x 4 bytes each:
+ *          f32 w          sum of weights                      (SdfVoxel::weight)
+ *          f32 s          sum of w * truncated sdf            (SdfVoxel::dist  = s / w)
+ *          f32 gx,gy,gz   sum of w * R n                      (SdfVoxel::grad)
+ *          u32 aux        index+1 of the last frame that touched the voxel (vis_ stand-in,
+ *                         and the per-frame ownership tag of the fusion flush)
  *
- * Four slots form one 128-byte bucket = one HBM/L2 line, so a probe fetches a
- * whole bucket with one coalesced line read; probing is linear over buckets.
- * The running mean of the reference (MapGradPixelSdf.cpp:111) equals s / w, so
- * storing the additive sums makes fusion order-free (atomics) and shard-mergeable.
- * The packed key orders like (z, y, x), the order exports are sorted in.
+ * A probe reads the 4 keys of a bucket with two 16-byte loads of ONE line (coalesced probe);
+ * the payload of a hit sits in the same line.  Probing is linear over buckets; a capacity of
+ * 2^c "slots" means 2^(c-2) buckets.  The running mean of the reference
+ * (MapGradPixelSdf.cpp:111) equals s / w, so storing the additive sums makes fusion
+ * order-free (atomics) and shard-mergeable.  Packed keys order like (z, y, x), the order
+ * exports are sorted in.
  */
 #ifndef GSDF_TABLE_H_
 #define GSDF_TABLE_H_
@@ -27,17 +30,20 @@
 #define GSDF_KEY_EMPTY   0xFFFFFFFFFFFFFFFFull
 #define GSDF_KEY_OFF     (1 << 20)
 #define GSDF_KEY_MASK    0x1FFFFFull
-#define GSDF_BUCKET      4            /* slots per 128-byte bucket */
+#define GSDF_BUCKET      4            /* voxels per 128-byte bucket */
 #define GSDF_MAX_PROBE   128          /* buckets probed before reporting TABLE_FULL */
 
-struct __attribute__((aligned(32))) gsdf_slot {
-    unsigned long long key;
+struct gsdf_payload {
     float w, s, gx, gy, gz;
     uint32_t aux;
 };
+struct __attribute__((aligned(128))) gsdf_bucket {
+    unsigned long long key[GSDF_BUCKET];
+    gsdf_payload pay[GSDF_BUCKET];
+};
 
 struct gsdf_table {
-    gsdf_slot* slots;
+    gsdf_bucket* buckets;
     uint32_t bucket_mask;             /* number of buckets - 1 */
 };
 
@@ -65,39 +71,43 @@ __host__ __device__ __forceinline__ uint32_t gsdf_hash(unsigned long long k) {
 
 #if defined(__HIPCC__)
 /* tsdf_[vi] (operator[]: find, insert zero-initialised if absent) -- MapGradPixelSdf.cpp:109.
- * Returns the slot index or -1 when the probe budget is exhausted.  Keys never change once
- * written, so a stale read can only show EMPTY, and then the CAS is authoritative.
- * *inserted is set when this call created the voxel. */
-__device__ __forceinline__ long long gsdf_find_or_insert(const gsdf_table& T, unsigned long long key, bool* inserted) {
+ * Returns the payload slot or nullptr when the probe budget is exhausted.  Keys never change
+ * once written and payloads are zeroed by the table clear, so the 4 keys are read with plain
+ * 16-byte loads: a stale read can only show EMPTY, and then the CAS is authoritative. */
+__device__ __forceinline__ gsdf_payload* gsdf_find_or_insert(const gsdf_table& T, unsigned long long key) {
     uint32_t b = gsdf_hash(key) & T.bucket_mask;
-    *inserted = false;
     for (int probe = 0; probe < GSDF_MAX_PROBE; ++probe) {
-        gsdf_slot* base = T.slots + (size_t)b * GSDF_BUCKET;
+        gsdf_bucket* B = T.buckets + b;
+        const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&B->key[0]);
+        const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&B->key[2]);
+        const unsigned long long ks[4] = { k01.x, k01.y, k23.x, k23.y };
 #pragma unroll
         for (int j = 0; j < GSDF_BUCKET; ++j) {
-            unsigned long long k = __hip_atomic_load(&base[j].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long k = ks[j];
             if (k == GSDF_KEY_EMPTY) {
-                k = atomicCAS(&base[j].key, GSDF_KEY_EMPTY, key);
-                if (k == GSDF_KEY_EMPTY) { *inserted = true; return (long long)((size_t)b * GSDF_BUCKET + j); }
+                k = atomicCAS(&B->key[j], GSDF_KEY_EMPTY, key);
+                if (k == GSDF_KEY_EMPTY) return &B->pay[j];
             }
-            if (k == key) return (long long)((size_t)b * GSDF_BUCKET + j);
+            if (k == key) return &B->pay[j];
         }
         b = (b + 1) & T.bucket_mask;
     }
-    return -1;
+    return nullptr;
 }
 
-/* tsdf_.find(idx) -- MapGradPixelSdf.h:119.  Read-only kernels only (plain loads). */
-__device__ __forceinline__ const gsdf_slot* gsdf_find(const gsdf_table& T, unsigned long long key) {
+/* tsdf_.find(idx) -- MapGradPixelSdf.h:119.  Read-only kernels only. */
+__device__ __forceinline__ const gsdf_payload* gsdf_find(const gsdf_table& T, unsigned long long key) {
     uint32_t b = gsdf_hash(key) & T.bucket_mask;
     for (int probe = 0; probe < GSDF_MAX_PROBE; ++probe) {
-        const gsdf_slot* base = T.slots + (size_t)b * GSDF_BUCKET;
-#pragma unroll
-        for (int j = 0; j < GSDF_BUCKET; ++j) {
-            const unsigned long long k = base[j].key;
-            if (k == key) return base + j;
-            if (k == GSDF_KEY_EMPTY) return nullptr;
-        }
+        const gsdf_bucket* B = T.buckets + b;
+        const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&B->key[0]);
+        const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&B->key[2]);
+        if (k01.x == key) return &B->pay[0];
+        if (k01.y == key) return &B->pay[1];
+        if (k23.x == key) return &B->pay[2];
+        if (k23.y == key) return &B->pay[3];
+        /* slots fill in order and are never freed: an empty slot ends the probe sequence */
+        if (k23.y == GSDF_KEY_EMPTY) return nullptr;
         b = (b + 1) & T.bucket_mask;
     }
     return nullptr;

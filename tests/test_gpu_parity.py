@@ -100,7 +100,7 @@ def test_query_matches_oracle(pkg, O):
 
 
 def test_tracker_matches_oracle(pkg, O):
-    seq, g, o = _mk(pkg, O, W=320, H=240, vs=0.01, trunc=10, cap=21, n=3)
+    seq, g, o = _mk(pkg, O, W=640, H=480, vs=0.01, trunc=10, cap=21, n=3, seed=0)
     d0, R0, t0 = seq.frame(0)
     g.update(d0, R0, t0)
     o.update(d0, R0, t0)
@@ -128,7 +128,7 @@ def test_tracker_no_overlap_returns_false(pkg, O):
 
 def test_track_and_fuse_stream_matches_oracle_loop(pkg, O):
     """The device-side Scan3D loop (main_scan_3d.cpp:255-266) against the oracle's host loop."""
-    seq, g, o = _mk(pkg, O, W=320, H=240, vs=0.01, trunc=10, cap=21, n=6)
+    seq, g, o = _mk(pkg, O, W=640, H=480, vs=0.01, trunc=10, cap=21, n=6, seed=0)
     frames = [seq.frame(i) for i in range(seq.n)]
     d0, R0, t0 = frames[0]
     p = pose7_from(O, R0, t0)

@@ -1,0 +1,37 @@
+"""Ablation of the fusion kernel (debug switches in k_fuse): where does the time go?"""
+import sys, os, ctypes
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as G
+pkg = G.package()
+kind = sys.argv[1] if len(sys.argv) > 1 else "tum"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+W, H = 640, 480
+seq = pkg.synth.Sequence(kind, W, H, n_frames=n, seed=0)
+vs = np.float32(0.01); T = np.float32(10) * vs
+frames = [seq.frame(i) for i in range(n)]
+g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=22)
+L = pkg.binding.load()
+dev = [g.upload(f[0]) for f in frames]
+names = {0: "full", 1: "no flush", 2: "no LDS accumulate (flush empty)", 3: "compute only", 4: "flush: probe only",
+         8: "flush: plain RMW", 17: "no flush, no overflow-to-HBM", 65: "no flush, count overflows", 16: "no overflow-to-HBM",
+         49: "no flush, no overflow, LDS w-add skipped"}
+names.update({1+128: 'no flush, cheap fix', 1+256: 'no flush, cheap hash', 1+128+256: 'no flush, cheap fix+hash', 1+512: 'no flush, no probe (direct add)', 1+512+128+256: 'no flush, direct add, cheap fix+hash', 2+128+256: 'no LDS, cheap fix+hash'})
+for flags in (1, 1+128, 1+256, 1+128+256, 1+512, 1+512+128+256, 2, 2+128+256):
+    L.gsdf_debug_flags(flags)
+    g.reset()
+    for rep in range(2):
+        g.profile(1)
+        for i in range(n):
+            g.update_dev(dev[i], frames[i][1], frames[i][2])
+        try:
+            g.sync()
+        except Exception as e:
+            print("  status:", e)
+        pr = g.profile_read()
+        if flags == 65: print("   overflow samples/frame:", g.stats()["n_hit"] / n / (rep + 1), "of n_upd/frame", g.stats()["n_upd"] / n / (rep + 1))
+        g.profile(0)
+        print("flags=%d %-34s rep%d fusion %.1f us/frame  normals %.1f us" % (flags, names[flags], rep,
+              pr["fusion"]["ms"] / n * 1e3, pr["normals"]["ms"] / n * 1e3))
+L.gsdf_debug_flags(0)
+g.close()
