@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- depth frames/sec fused+tracked on MI355X (BASELINE.json metric).
+
+A *step* = one pass of the hot path over one depth frame of the synthetic stream:
+RigidPointOptimizer::optimize (<= 25 Gauss-Newton passes) + MapGradPixelSdf::update when it
+converged (main_scan_3d.cpp:255-266), enqueued through the C-ABI entry gsdf_track_and_fuse_dev
+with the frame already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]:
+TUM fr1/xyz-format synthetic stream, 640x480, 1 cm voxels, trunc = 10 voxels, capacity 2^22.
+
+Multi-GPU: tracking makes frame i depend on the map of all frames < i, so the fused+tracked path
+does not shard ("replicas only"): --gpus N runs N independent streams (seed = rank),
+one process per GPU, and `value` = all frames of all ranks / max-over-ranks time ("weak").
+
+Output: ONE JSON line on rank 0 (contract in the task statement) including
+  roofline      dominant kernel (k_fuse): algorithmic bytes per launch / mean HIP-event duration
+  cpu_baseline  the CPU oracle ("port" of the reference's serial path) timed on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md), ~6300 achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--voxel-size", type=float, default=0.01)
+    ap.add_argument("--trunc", type=float, default=10.0)
+    ap.add_argument("--hash-capacity-log2", type=int, default=22)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # torch first: libgsdf binds to the HIP runtime already in the process (gradient-sdf_amd/binding.py)
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    import __graft_entry__ as graft
+    pkg = graft.package()
+
+    W, H = args.width, args.height
+    K, Wm = args.steps, args.warmup
+    n_frames = 1 + Wm + K
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=n_frames, seed=rank)
+    vs = np.float32(args.voxel_size)
+    T = np.float32(args.trunc) * vs
+    frames = [seq.frame(i) for i in range(n_frames)]
+
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=args.hash_capacity_log2, device=local_rank)
+    dev = [g.upload(f[0]) for f in frames]          # inputs resident in HBM before the timed region
+
+    def q_from_R(R):
+        return pkg.synth.R_to_quat_np(R).astype(np.float32)
+
+    def quat_to_R(q):
+        x, y, z, w = [np.float32(v) for v in q]
+        tx, ty, tz = 2 * x, 2 * y, 2 * z
+        return np.array([[1 - (ty * y + tz * z), ty * x - tz * w, tz * x + ty * w],
+                         [ty * x + tz * w, 1 - (tx * x + tz * z), tz * y - tx * w],
+                         [tz * x - ty * w, tz * y + tx * w, 1 - (tx * x + ty * y)]], np.float32)
+
+    def sync_all():
+        g.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def run_stream(first, last):
+        for i in range(first, last):
+            g.track_and_fuse_dev(dev[i])
+
+    # frame 0: setup at the ground-truth pose (main_scan_3d.cpp:242), then W untimed warm-up steps
+    d0, R0, t0 = frames[0]
+    p0 = np.concatenate([t0, q_from_R(R0)]).astype(np.float32)
+    g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
+    g.set_pose(p0)
+    run_stream(1, 1 + Wm)
+    sync_all()
+    st_w = g.stats()
+
+    # ---- timed region: exactly K steps --------------------------------------------------------
+    sync_all()
+    t_start = time.perf_counter()
+    run_stream(1 + Wm, 1 + Wm + K)
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    st = g.stats()
+    log = g.frame_log()
+    timed = log[Wm:Wm + K]
+    n_conv = int(timed[:, 7].sum())
+    passes = float(timed[:, 8].mean()) if len(timed) else 0.0
+    gt_t = np.array([frames[i][2] for i in range(1 + Wm, 1 + Wm + K)])
+    trans_err = float(np.abs(timed[:, :3] - gt_t).max()) if len(timed) else 0.0
+    n_upd_timed = st["n_upd"] - st_w["n_upd"]
+    n_hit_timed = st["n_hit"] - st_w["n_hit"]
+    voxels = g.count()
+
+    # ---- roofline of the dominant kernel: replay the same K frames with HIP events around k_fuse ---
+    # (a separate pass so that event records do not perturb `value`; same frames, same poses)
+    poses = log[:, :7].copy()
+    g.reset()
+    g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
+    for i in range(1, 1 + Wm):
+        if log[i - 1, 7] > 0:
+            g.update_dev(dev[i], quat_to_R(poses[i - 1, 3:]), poses[i - 1, :3])
+    g.sync()
+    st_a = g.stats()
+    g.profile(1)
+    n_fuse = 0
+    for i in range(1 + Wm, 1 + Wm + K):
+        if log[i - 1, 7] > 0:
+            g.update_dev(dev[i], quat_to_R(poses[i - 1, 3:]), poses[i - 1, :3])
+            n_fuse += 1
+    g.sync()
+    prof = g.profile_read()
+    g.profile(0)
+    st_b = g.stats()
+    fuse_ms = prof["fusion"]["ms"] / max(prof["fusion"]["launches"], 1)
+    n_upd_launch = (st_b["n_upd"] - st_a["n_upd"]) / max(n_fuse, 1)
+    alg_bytes = 16.0 * W * H + 52.0 * n_upd_launch            # fusion = 16 N_pix + 52 N_upd
+    achieved = alg_bytes / (fuse_ms * 1e-3) / 1e9 if fuse_ms > 0 else 0.0
+
+    # fused-only flavour (GT poses, update only) over the same K frames
+    g.reset()
+    sync_all()
+    tf = time.perf_counter()
+    for i in range(1 + Wm, 1 + Wm + K):
+        g.update_dev(dev[i], frames[i][1], frames[i][2])
+    sync_all()
+    fused_fps = K / (time.perf_counter() - tf)
+    g.close()
+
+    # ---- CPU baseline: the oracle (port of the reference's serial path) on a bounded sample --------
+    cpu = None
+    if rank == 0 and args.cpu_frames > 0:
+        O = graft.oracle_module()
+        nc = min(args.cpu_frames, n_frames)
+        o = O.Oracle(vs, T, W, H, seq.K)
+        tc = time.perf_counter()
+        o.update(frames[0][0], quat_to_R(p0[3:]), t0)
+        pose = p0.copy()
+        for i in range(1, nc):
+            conv, pose, _, _, _ = o.track(frames[i][0], pose)
+            if conv:
+                o.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3])
+        dt = time.perf_counter() - tc
+        cpu = {"value": round((nc - 1) / dt, 3) if nc > 1 else 0.0, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "first %d frames of the same stream (1 setup + %d tracked+fused), serial oracle, %s host cores present"
+                         % (nc, nc - 1, os.cpu_count())}
+
+    if rank == 0:
+        total_frames = K * world
+        out = {
+            "metric": "depth frames/sec fused+tracked, 640x480 @1cm voxels",
+            "value": round(total_frames / elapsed, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "S-tum: TUM fr1/xyz-format synthetic stream (BASELINE.json configs[1])",
+                "width": W, "height": H, "voxel_size_m": float(vs), "trunc_voxels": args.trunc,
+                "hash_capacity_log2": args.hash_capacity_log2, "tracker": "25 iters, conv 1e-3, damping 1",
+                "parallelism": "replicas x%d (tracked path does not shard)" % world,
+                "converged_frames": n_conv, "mean_tracker_passes": round(passes, 2),
+                "max_abs_translation_error_m": round(trans_err, 5), "voxels": voxels,
+                "n_upd_per_frame": round(n_upd_timed / max(n_conv, 1)), "n_hit_per_pass": round(n_hit_timed / max(passes * K, 1)),
+                "fused_only_fps": round(fused_fps * world, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_fuse", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(fuse_ms * 1e3, 2),
+                "launches": prof["fusion"]["launches"],
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

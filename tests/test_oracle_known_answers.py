@@ -1,0 +1,181 @@
+"""Analytic known-answer tests that pin the CPU oracle: the reference ships
+no tests or golden vectors, so these are what the oracle's restatement is anchored on."""
+import numpy as np
+import pytest
+
+from conftest import pose7_from
+
+VS = np.float32(0.01)
+T10 = np.float32(10) * VS
+
+
+def round_half_away(x):
+    return np.where(x >= 0, np.floor(x + np.float32(0.5)), -np.floor(-x + np.float32(0.5)))
+
+
+def test_constants_match_survey(O, pkg):
+    # T = 10 * 0.01 in float32 = 0.099999994, inv_vs = 100.0
+    assert float(T10) == pytest.approx(0.099999994, abs=1e-9)
+    assert np.float32(1.0 / float(VS)) == np.float32(100.0)
+    assert int(np.floor(T10 / VS)) == 10
+    assert np.float32(1.0 / float(T10)) == np.float32(10.000001)
+
+
+def test_plane_keys_dist_and_normals(O, pkg):
+    """Fronto-parallel plane at z0, identity pose: keys = round((z0 + k vs) (x0,y0,1) / vs), dist =
+    clamp(vs*vz - z0) for EVERY voxel, FALS normal = (0,0,+1) (inward-pointing)."""
+    W, H = 160, 120
+    K = pkg.synth.intrinsics(W, H)
+    z0 = np.float32(1.5)
+    depth = np.full((H, W), z0, np.float32)
+    o = O.Oracle(VS, T10, W, H, K)
+    n = o.normals(depth)
+    inner = (slice(8, H - 8), slice(8, W - 8))
+    # Q*b in float32 cancels ~4 digits (|Q||b| >> |n|): the reference's own formulation, not the oracle's
+    assert np.abs(n[0][inner]).max() < 5e-4 and np.abs(n[1][inner]).max() < 5e-4
+    assert np.abs(n[2][inner] - 1).max() < 1e-6
+    n_upd, n_valid = o.update(depth, np.eye(3), np.zeros(3))
+    assert n_valid == W * H
+    keys, pay = o.export()
+    c = o.normals_cache()
+    x0, y0 = c[0], c[1]
+    exp = set()
+    for k in range(-10, 11):
+        s = z0 + np.float32(k) * VS
+        vx = round_half_away(np.float32(100.0) * (s * x0)).astype(np.int64)
+        vy = round_half_away(np.float32(100.0) * (s * y0)).astype(np.int64)
+        vz = round_half_away(np.float32(100.0) * (s * np.ones_like(x0))).astype(np.int64)
+        sdf = VS * vz.astype(np.float32) - z0
+        keep = sdf <= T10          # weight > 0
+        exp |= set(zip(vx[keep].tolist(), vy[keep].tolist(), vz[keep].tolist()))
+    got = set(map(tuple, keys.tolist()))
+    assert got == exp
+    sdf = VS * keys[:, 2].astype(np.float32) - z0
+    assert np.abs(pay[:, 0] - np.clip(sdf, -T10, T10)).max() < 1e-6
+    # gradient = (0,0,1) * sum of weights (up to normal rounding)
+    assert np.abs(pay[:, 3] - pay[:, 4]).max() <= 1e-4 * pay[:, 4].max()
+    assert np.abs(pay[:, 1:3]).max() <= 1e-3 * pay[:, 4].max()
+
+
+def test_sphere_gradient_direction(O, pkg):
+    """Stored gradients point along the analytic sphere normal, inward (MapGradPixelSdf.cpp:112)."""
+    W, H = 320, 240
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=4, seed=3, noise=False, step_deg=2.0)
+    seq.spheres = np.array([[0.05, 0.1, -0.05, 0.45]])
+    o = O.Oracle(VS, T10, W, H, seq.K)
+    for i in range(seq.n):
+        d, R, t = seq.frame(i)
+        o.update(d, R, t)
+    keys, pay = o.export()
+    m = (pay[:, 4] >= 5) & (np.abs(pay[:, 0]) < 0.02)
+    assert m.sum() > 2000
+    ctr = seq.spheres[0, :3]
+    pos = keys[m].astype(np.float64) * float(VS)
+    radial = ctr - pos
+    radial /= np.linalg.norm(radial, axis=1, keepdims=True)          # inward = towards the centre
+    gdir = pay[m, 1:4].astype(np.float64)
+    gdir /= np.linalg.norm(gdir, axis=1, keepdims=True)
+    ang = np.degrees(np.arccos(np.clip((radial * gdir).sum(1), -1, 1)))
+    assert np.median(ang) < 3.0 and np.percentile(ang, 95) < 10.0
+
+
+def test_tracker_recovers_known_twist(O, pkg):
+    W, H = 640, 480
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=1, seed=0, noise=False)
+    o = O.Oracle(VS, T10, W, H, seq.K)
+    d, R, t = seq.frame(0)
+    p_true = pose7_from(O, R, t)
+    o.update(d, O.quat_to_R(p_true[3:]), t)
+    xi = np.array([0.012, -0.008, 0.01, 0.004, -0.006, 0.005], np.float32)   # small twist
+    p_start = O.se3_exp_mul(xi, p_true)
+    conv, p, used, trace, hits = o.track(d, p_start)
+    assert conv and used < 25
+    assert np.abs(p[:3] - p_true[:3]).max() < 2e-3
+    assert np.abs(p[3:] - p_true[3:]).max() < 1e-3
+    assert trace[0, 35] > trace[used - 1, 35]              # |xi|^2 shrinks
+    assert trace[used - 1, 35] < 1e-6
+
+
+def test_tracker_no_overlap_is_not_converged(O, pkg):
+    """All-zero H -> llt gives NaN -> 25 idle passes -> false (SURVEY.md gotcha 9)."""
+    W, H = 64, 48
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=1, seed=0)
+    o = O.Oracle(VS, T10, W, H, seq.K)
+    d, R, t = seq.frame(0)
+    p0 = pose7_from(O, R, t)
+    conv, p, used, trace, hits = o.track(d, p0, iters=7)
+    assert not conv and used == 7 and np.array_equal(p, p0) and hits.sum() == 0
+
+
+def test_fusion_order_independent_and_omp_equals_serial(O, pkg):
+    W, H = 160, 120
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=4, seed=2, step_deg=3.0)
+    fr = [seq.frame(i) for i in range(seq.n)]
+    outs = []
+    for order, omp in (([0, 1, 2, 3], False), ([3, 1, 0, 2], False), ([0, 1, 2, 3], True)):
+        o = O.Oracle(np.float32(0.02), np.float32(0.1), W, H, seq.K, threads=4)
+        for i in order:
+            o.update(*fr[i], omp=omp)
+        outs.append(o.export())
+    k0, p0 = outs[0]
+    for k, p in outs[1:]:
+        assert np.array_equal(k0, k)
+        assert np.abs(p - p0).max() <= 1e-4 * max(1.0, np.abs(p0).max())
+    vis = o.export_vis(1)
+    assert vis.max() < 16 and vis.min() >= 1               # every voxel was seen by at least one frame
+
+
+def test_holes_produce_finite_or_nan_normals_only_where_expected(O, pkg):
+    W, H = 96, 72
+    K = pkg.synth.intrinsics(W, H)
+    depth = np.full((H, W), 1.2, np.float32)
+    depth[20:50, 30:70] = 0.0                              # hole larger than the 11x11 window
+    o = O.Oracle(VS, T10, W, H, K)
+    n = o.normals(depth)
+    nan = ~np.isfinite(n[2])
+    assert nan.any() and not nan[depth > 0].any()          # 0/0 only deep inside the hole
+    n_upd, n_valid = o.update(depth, np.eye(3), np.zeros(3))
+    assert n_valid <= int((depth > 0).sum())
+    keys, pay = o.export()
+    assert np.isfinite(pay).all()
+
+
+def test_se3_helpers(O):
+    q = np.array([0.1, -0.2, 0.3, 0.9], np.float32)
+    q /= np.linalg.norm(q)
+    R = O.quat_to_R(q)
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-6 and abs(np.linalg.det(R) - 1) < 1e-6
+    q2 = O.R_to_quat(R)
+    assert np.abs(q2 - q).max() < 1e-6
+    ident = np.array([0, 0, 0, 0, 0, 0, 1], np.float32)
+    assert np.array_equal(O.se3_exp_mul(np.zeros(6, np.float32), ident), ident)
+    xi = np.array([0.1, 0.2, -0.1, 0.05, -0.02, 0.03], np.float32)
+    p = O.se3_exp_mul(-xi, O.se3_exp_mul(xi, ident))
+    assert np.abs(p - ident).max() < 1e-6
+    # pure translation twist: exp moves t by exactly the twist
+    p = O.se3_exp_mul(np.array([0.5, -1, 2, 0, 0, 0], np.float32), ident)
+    assert np.allclose(p[:3], [0.5, -1, 2]) and np.array_equal(p[3:], ident[3:])
+    # rotation about z by 90 degrees
+    p = O.se3_exp_mul(np.array([0, 0, 0, 0, 0, np.pi / 2], np.float32), ident)
+    assert np.abs(O.quat_to_R(p[3:]) - np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]])).max() < 1e-6
+
+
+def test_query_is_first_order_taylor(O, pkg):
+    W, H = 160, 120
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=1, seed=1)
+    vs = np.float32(0.02)
+    o = O.Oracle(vs, np.float32(0.1), W, H, seq.K)
+    o.update(*seq.frame(0))
+    keys, pay = o.export()
+    k = keys[:200]
+    ctr = k.astype(np.float32) * vs
+    d, g, w = o.query(ctr)
+    assert np.array_equal(w, pay[:200, 4])
+    assert np.abs(d - pay[:200, 0]).max() < 1e-7                 # at the voxel centre phi = dist
+    gn = pay[:200, 1:4] / np.linalg.norm(pay[:200, 1:4], axis=1, keepdims=True)
+    assert np.abs(g - 1.2 * gn).max() < 1e-5                    # 1.2 * normalized gradient (MapGradPixelSdf.h:113)
+    off = np.float32(0.004) * np.ones(3, np.float32)
+    d2, _, _ = o.query(ctr + off)
+    assert np.abs(d2 - (d - g @ off)).max() < 1e-6
+    dm, gm, wm = o.query(np.array([[50.0, 50.0, 50.0]], np.float32))
+    assert wm[0] == 0 and dm[0] == 0
