@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -56,6 +57,14 @@ struct gsdf_ctx {
     int track_blocks = 0;
     unsigned long long* blk_counters = nullptr;
     int fuse_blocks = 0;
+    gsdf_deferred* deferred = nullptr;
+    unsigned int* deferred_count = nullptr;
+    unsigned int deferred_cap = 0;
+    unsigned int fuse_tag = 0;                     /* ownership tag of the last fusion launch */
+    unsigned int track_serial = 0;                 /* optimize() call counter */
+    volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */
+    unsigned int* progress_dev = nullptr;
+    int adaptive = 1;                              /* issue tracker passes only as far as the device needs */
     float* frame_log = nullptr;
     long long frame_log_cap = 0;
     /* misc */
@@ -139,25 +148,58 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
     {
         prof_scope ps(c, 0);
         gsdf_launch_normals(c->stream, g, c->win, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N,
-                            use_dev_pose ? c->st : nullptr);
+                            use_dev_pose ? c->st : nullptr, c->deferred_count);
     }
     {
         prof_scope ps(c, 1);
+        c->fuse_tag += 1;
+        if (c->fuse_tag == 0) c->fuse_tag = 1;
         gsdf_launch_fuse(c->stream, g, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N, pose,
-                         use_dev_pose, c->tab, c->st, c->blk_counters);
+                         use_dev_pose, c->tab, c->st, c->blk_counters, c->deferred, c->deferred_count,
+                         c->deferred_cap, c->fuse_tag, c->frame_log, c->frame_log_cap);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
     return GSDF_OK;
 }
 
+/* RigidPointOptimizer::optimize_sampled as a chain of per-pass launches.  The convergence test,
+ * the pose update and the done/converged flags live on the device; launches after `done` return
+ * immediately.  To avoid queueing all num_iterations launches (an empty launch still costs ~4 us
+ * on the stream), the host follows the device through two pinned words the pass epilogue writes and
+ * stays at most GSDF_AHEAD passes ahead; correctness never depends on what the host sees. */
+#define GSDF_AHEAD 3
 int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, float damping) {
     const gsdf_frame_geom g = c->geom();
-    const float conv_sq = conv * conv;                       /* RigidOptimizer.h:72 */
-    gsdf_launch_track_begin(c->stream, c->st, iters, conv_sq, damping);
+    if (iters <= 0) {
+        gsdf_launch_track_none(c->stream, c->st);
+        return GSDF_OK;
+    }
+    gsdf_track_params tp;
+    tp.max_passes = iters;
+    tp.conv_sq = conv * conv;                                /* RigidOptimizer.h:72 */
+    tp.damping = damping;
+    tp.serial = (++c->track_serial) & 0xFFFFFFu;
+    if (tp.serial == 0) tp.serial = c->track_serial = 1;
+    const bool adaptive = c->adaptive && c->progress;
+    tp.progress = adaptive ? c->progress_dev : nullptr;
     for (int k = 0; k < iters; ++k) {
-        prof_scope ps(c, 2);
-        gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks);
+        if (adaptive && c->progress[1] == tp.serial) break;  /* device finished this optimize() */
+        tp.pass_index = k;
+        {
+            prof_scope ps(c, 2);
+            gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks, tp);
+        }
+        if (adaptive && k + 1 >= GSDF_AHEAD) {
+            /* throttle: wait until the device is within GSDF_AHEAD passes (bounded spin) */
+            for (long spin = 0; spin < 20000000L; ++spin) {
+                if (c->progress[1] == tp.serial) break;
+                const unsigned int pr = c->progress[0];
+                const int done_passes = (pr >> 8) == tp.serial ? (int)(pr & 0xFFu) : 0;
+                if (k + 1 - done_passes < GSDF_AHEAD) break;
+                __builtin_ia32_pause();
+            }
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("tracking launch: ") + hipGetErrorString(e));
@@ -212,6 +254,18 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         return fail(GSDF_ERR_HIP, m);
     }
     c->tab.bucket_mask = (uint32_t)(c->n_slots / GSDF_BUCKET - 1);
+    {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+            std::memset(hp, 0, 64);
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) { c->progress = (volatile unsigned int*)hp; c->progress_dev = (unsigned int*)dp; }
+            else (void)hipHostFree(hp);
+        }
+        (void)hipGetLastError();
+        const char* env = getenv("GSDF_ADAPTIVE");
+        if (env) c->adaptive = atoi(env);
+    }
     int rc = gsdf_reset(c);
     if (rc != GSDF_OK) { gsdf_destroy(c); return rc; }
     *out = c;
@@ -225,8 +279,9 @@ void gsdf_destroy(gsdf_ctx* c) {
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     void* ptrs[] = { c->tab.buckets, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
-                     c->blk_counters, c->frame_log };
+                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->progress) (void)hipHostFree((void*)c->progress);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -258,10 +313,11 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
         return fail(GSDF_ERR_INVALID, "W,H > 0 and odd window <= 15 required");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    void* old[] = { c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log };
+    void* old[] = { c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log, c->deferred,
+                    c->deferred_count };
     for (void* p : old) if (p) (void)hipFree(p);
     c->planes = c->depth_stage = c->normals = c->partials = nullptr;
-    c->blk_counters = nullptr; c->frame_log = nullptr;
+    c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr;
     c->W = W; c->H = H; c->win = win;
     std::memcpy(c->K, K, 9 * sizeof(float));
     const size_t N = (size_t)W * H;
@@ -274,6 +330,11 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     c->fuse_blocks = gsdf_fuse_grid_blocks(W, H);
     HIP_TRY(hipMalloc((void**)&c->blk_counters, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
+    /* deferred list: contributions to voxels owned by another tile; bounded by the samples of a frame */
+    c->deferred_cap = (unsigned int)std::min<size_t>((size_t)1 << 24, std::max<size_t>((size_t)1 << 18, N * 8));
+    HIP_TRY(hipMalloc((void**)&c->deferred, (size_t)c->deferred_cap * sizeof(gsdf_deferred)));
+    HIP_TRY(hipMalloc((void**)&c->deferred_count, sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(c->deferred_count, 0, sizeof(unsigned int), c->stream));
     c->frame_log_cap = 1 << 16;
     HIP_TRY(hipMalloc((void**)&c->frame_log, (size_t)c->frame_log_cap * 10 * sizeof(float)));
     gsdf_launch_normals_cache(c->stream, W, H, c->K, win, c->planes);
@@ -298,7 +359,7 @@ int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float*
     const size_t N = (size_t)c->W * c->H;
     HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), c->depth_stage, c->normals, c->normals + N,
-                        c->normals + 2 * N, nullptr);
+                        c->normals + 2 * N, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(nx, c->normals, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(ny, c->normals + N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -382,8 +443,7 @@ int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9
     std::memset(&unused, 0, sizeof(unused));
     rc = enqueue_fuse(c, depth_dev, unused, 1);                                   /* :261-265 */
     if (rc) return rc;
-    gsdf_launch_frame_log(c->stream, c->st, c->frame_log, c->frame_log_cap);      /* :268-280 */
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipGetLastError());                                                   /* log row: written by k_fuse_resolve */
     return GSDF_OK;
 }
 

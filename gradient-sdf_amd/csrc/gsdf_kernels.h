@@ -49,21 +49,38 @@ struct gsdf_ncache {
 
 struct gsdf_pose_arg { float R[9]; float t[3]; };
 
+/* a contribution to a voxel that another tile owns in this fusion launch (added by k_fuse_resolve) */
+struct __attribute__((aligned(16))) gsdf_deferred {
+    gsdf_payload* p;
+    float w, s, gx, gy, gz;
+    uint32_t pad;
+};
+
 void gsdf_launch_table_clear(hipStream_t s, gsdf_table tab, size_t n_slots);
 void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int win, float* planes11);
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
                          const float* depth, float* nx, float* ny, float* nz,
-                         const gsdf_dev_state* gate /* nullable: skip unless converged */);
+                         const gsdf_dev_state* gate /* nullable: skip unless converged */,
+                         unsigned int* deferred_count /* nullable: cleared for the k_fuse that follows */);
 /* use_dev_pose: take R,t from st->R / st->pose7 and skip the launch unless st->converged */
 void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
                       const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
                       int use_dev_pose, gsdf_table tab, gsdf_dev_state* st,
-                      unsigned long long* blk_counters /* [gsdf_fuse_grid_blocks][4] */);
+                      unsigned long long* blk_counters /* [gsdf_fuse_grid_blocks][4] */,
+                      gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
+                      unsigned int tag /* ownership tag, unique per launch, never 0 */,
+                      float* log_rows /* nullable: frame log, written when use_dev_pose */, long long max_rows);
 int  gsdf_fuse_grid_blocks(int W, int H);
-void gsdf_launch_track_begin(hipStream_t s, gsdf_dev_state* st, int max_passes, float conv_sq, float damping);
+/* per-launch parameters of one Gauss-Newton pass (RigidOptimizer.h:57-62) */
+struct gsdf_track_params {
+    int pass_index, max_passes;
+    float conv_sq, damping;
+    unsigned int serial;          /* optimize() call number, for the host progress words */
+    unsigned int* progress;       /* pinned host memory: [0] = serial<<8 | passes, [1] = serial when done; nullable */
+};
+void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st);
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
-                            gsdf_dev_state* st, float* partials, int n_blocks);
-void gsdf_launch_frame_log(hipStream_t s, gsdf_dev_state* st, float* log_rows, long long max_rows);
+                            gsdf_dev_state* st, float* partials, int n_blocks, const gsdf_track_params& tp);
 void gsdf_launch_set_pose(hipStream_t s, gsdf_dev_state* st, const float* pose7_dev_or_null,
                           const float pose7_host[7]);
 void gsdf_launch_export(hipStream_t s, gsdf_table tab, size_t n_slots, unsigned long long* keys_out,

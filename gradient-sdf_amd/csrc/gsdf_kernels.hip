@@ -128,8 +128,9 @@ void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int 
 __global__ __launch_bounds__(256) void k_normals(gsdf_frame_geom g, int r, gsdf_ncache nc,
                                                  const float* __restrict__ depth, float* __restrict__ nx,
                                                  float* __restrict__ ny, float* __restrict__ nz,
-                                                 const gsdf_dev_state* gate) {
+                                                 const gsdf_dev_state* gate, unsigned int* deferred_count) {
     if (gate && !gate->converged) return;
+    if (deferred_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *deferred_count = 0u;   /* fresh list for k_fuse */
     __shared__ float prod[3][NRM_TY + 2 * NRM_RMAX][NRM_TX + 2 * NRM_RMAX + 1];
     __shared__ double rows[3][NRM_TY + 2 * NRM_RMAX][NRM_TX];
     const int W = g.W, H = g.H;
@@ -177,31 +178,44 @@ __global__ __launch_bounds__(256) void k_normals(gsdf_frame_geom g, int r, gsdf_
     nx[i] = vx / n; ny[i] = vy / n; nz[i] = vz / n;         /* :201-203 */
 }
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
-                         const float* depth, float* nx, float* ny, float* nz, const gsdf_dev_state* gate) {
+                         const float* depth, float* nx, float* ny, float* nz, const gsdf_dev_state* gate,
+                         unsigned int* deferred_count) {
     dim3 grid((g.W + NRM_TX - 1) / NRM_TX, (g.H + NRM_TY - 1) / NRM_TY);
-    hipLaunchKernelGGL(k_normals, grid, dim3(256), 0, s, g, win / 2, nc, depth, nx, ny, nz, gate);
+    hipLaunchKernelGGL(k_normals, grid, dim3(256), 0, s, g, win / 2, nc, depth, nx, ny, nz, gate, deferred_count);
 }
 
 /* ------------------------------------------------------------------------------------------------
  * MapGradPixelSdf::update -- fusion.
  *
- * One workgroup = one 16x16 pixel tile (4 waves, each an 8x8 sub-tile so that a wave's 64 rays
- * stay spatially compact).  Each lane walks its ray's 2*factor+1 samples.  Neighbouring pixels and
- * consecutive samples hit the same voxels (~5-10 updates per distinct voxel per frame), so updates
- * are first combined in a workgroup-private open-addressed table in LDS and only the distinct
- * voxels of the tile are flushed to the HBM table (1 probe + 5 float atomics each).
+ * Work decomposition: one workgroup = one 16x16 pixel tile (4 waves, each an 8x8 sub-tile so a
+ * wave's 64 rays stay spatially compact) x one half of the ray walk (blockIdx.z: k <= 0 / k > 0).
+ * Each lane walks its ray's samples.  Neighbouring pixels and consecutive samples hit the same
+ * voxels (~5 updates per distinct voxel per frame), so updates are first combined in a
+ * workgroup-private bucketed hash table in LDS; only the distinct voxels of the tile are flushed
+ * to the HBM table.
  *
- * Measured on MI355X (tools/atomics_bench.hip): ds_add_f32 is lane-serial (~190 cycles per
- * wave instruction) while ds_add_u64 costs 8-29 cycles, so the LDS accumulators are 64-bit
- * FIXED POINT (2^-40): every float term converts exactly, the per-tile sums are exact and
- * order-independent, and one rounding to float happens at the flush.  Lanes start their ray walk
- * at skewed sample indices so that neighbouring lanes (same voxel at the same k) do not hit the
- * same LDS address in the same instruction.  Samples that do not fit the LDS table go to HBM
- * directly.
+ * What the MI355X measurements (tools/atomics_bench.hip, profiles/) dictated:
+ *  - ds_add_f32 is lane-serial (~190 cycles per wave instruction), ds_add_u64 costs 8-29: the
+ *    LDS accumulators are 64-bit FIXED POINT (2^-40).  Every float term converts exactly, so the
+ *    per-tile sums are exact and order-independent; one rounding to float happens at the flush.
+ *  - LDS lookups are latency chains (read bucket -> compare -> CAS): three samples per lane are
+ *    in flight at once, a bucket (4 keys) is fetched with two ds_read_b128, and at most one CAS
+ *    is issued per probe.  Lanes start at skewed sample indices so that neighbouring lanes (same
+ *    voxel at the same k) do not serialise on one LDS address.
+ *  - device-scope atomics run at only ~20-50 G/s chip-wide, so the flush takes OWNERSHIP instead
+ *    of adding atomically: one atomicExch of the per-launch tag on the voxel's aux word; the first
+ *    tile to tag a voxel updates its payload with plain loads/stores (nobody else touches it in
+ *    this launch), every later tile appends its contribution to a deferred list that k_fuse_resolve
+ *    adds after the launch.  ~84 % of the (tile, voxel) pairs are owners: 1 atomic instead of 5.
+ * Samples that do not fit the LDS table go to the deferred list as well.
  * ---------------------------------------------------------------------------------------------- */
 #define FUSE_T 16
-#define FUSE_LCAP 1536
+#define FUSE_LCAP 1024
+#define FUSE_NB (FUSE_LCAP / 4)
 #define FUSE_LPROBE 12
+#define FUSE_BATCH 3
+#define FUSE_ZSPLIT 2
+#define FUSE_DEFER_BIT 0x8000000000000000ull
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 struct fuse_args {
@@ -214,6 +228,10 @@ struct fuse_args {
     gsdf_table tab;
     gsdf_dev_state* st;
     unsigned long long* blk_counters;   /* [n_blocks][4]: last n_upd, last n_valid, cum n_upd, cum n_valid */
+    gsdf_deferred* deferred;            /* list of contributions to voxels owned by another tile */
+    unsigned int* deferred_count;
+    unsigned int deferred_cap;
+    unsigned int tag;                   /* ownership tag of this launch = frame serial, never 0 */
     int debug;                          /* experiment switches (gsdf_debug_flags); 0 in production */
 };
 
@@ -221,6 +239,7 @@ struct fuse_lds {
     unsigned long long key[FUSE_LCAP] __attribute__((aligned(16)));
     unsigned long long w[FUSE_LCAP], s[FUSE_LCAP], gx[FUSE_LCAP], gy[FUSE_LCAP], gz[FUSE_LCAP];
     float red[8];
+    unsigned int n_defer, defer_base;
 };
 
 /* float -> signed 2^-40 fixed point, exact for 2^-17 <= |x| < 2^23 (smaller terms keep 2^-40 resolution) */
@@ -237,6 +256,7 @@ __device__ __forceinline__ float fix2f(unsigned long long v) {
     return __ll2float_rn((long long)v) * 9.094947017729282e-13f;   /* 2^-40 */
 }
 
+/* additive update with float atomics: merge / resolve kernels */
 __device__ __forceinline__ void hbm_accumulate(const gsdf_table& T, unsigned long long key, float w, float s,
                                                float gx, float gy, float gz, gsdf_dev_state* st) {
     gsdf_payload* p = gsdf_find_or_insert(T, key);
@@ -248,16 +268,25 @@ __device__ __forceinline__ void hbm_accumulate(const gsdf_table& T, unsigned lon
     unsafeAtomicAdd(&p->gz, gz);
 }
 
+__device__ __forceinline__ void defer_append(const fuse_args& a, gsdf_payload* p, float w, float s, float gx, float gy,
+                                             float gz) {
+    const unsigned int i = atomicAdd(a.deferred_count, 1u);
+    if (i >= a.deferred_cap) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); return; }
+    gsdf_deferred d;
+    d.p = p; d.w = w; d.s = s; d.gx = gx; d.gy = gy; d.gz = gz; d.pad = 0u;
+    a.deferred[i] = d;
+}
+
 int g_fuse_debug = 0;
 __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    fuse_lds& L = *reinterpret_cast<fuse_lds*>(smem_raw);
+    __shared__ fuse_lds L;
     if (a.use_dev_pose && !a.st->converged) return;        /* main_scan_3d.cpp:261: if (conv) update */
     const int tid = threadIdx.x;
     for (int i = tid; i < FUSE_LCAP; i += 256) {
         L.key[i] = GSDF_KEY_EMPTY;
         L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
     }
+    if (tid == 0) { L.n_defer = 0u; L.defer_base = 0u; }
     float R[9], t[3];
     if (a.use_dev_pose) {
 #pragma unroll
@@ -294,94 +323,188 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
             if (nd * nd * a.nc.ninv[idx] < .25) valid = false;             /* :98 */
         }
     }
+    /* this workgroup's share of the ray walk k = -factor..factor (:101); the order is free (sums) */
+    const int k_lo = blockIdx.z == 0 ? -g.factor : 1;
+    const int k_hi = blockIdx.z == 0 ? 0 : g.factor;
+    const int nk = k_hi - k_lo + 1;
     float n_upd = 0.f;
-    if (valid) {
-        const int nk = 2 * g.factor + 1;
+    if (nk > 0) {
         /* skew: lanes of a 3x3 pixel neighbourhood walk different samples in the same instruction */
         int it = (2 * ((lx % 3) + 3 * (ly % 3))) % nk;
-        for (int c = 0; c < nk; ++c) {                                     /* :101 (order is free: sums) */
-            const int kk = it - g.factor;
-            it = it + 1 == nk ? 0 : it + 1;
-            const float s = z + (float)kk * g.vs;
-            const float pxw = s * Rxy.x + t[0], pyw = s * Rxy.y + t[1], pzw = s * Rxy.z + t[2];   /* :103 */
-            const int vx = gsdf_float2vox1(g.inv_vs, pxw);                 /* :104 */
-            const int vy = gsdf_float2vox1(g.inv_vs, pyw);
-            const int vz = gsdf_float2vox1(g.inv_vs, pzw);
-            const float dx = g.vs * (float)vx - t[0], dy = g.vs * (float)vy - t[1], dz = g.vs * (float)vz - t[2];
-            const float pc_z = gsdf_sum3(R[2] * dx, R[5] * dy, R[8] * dz); /* :105  (Rt row 2) */
-            const float sdf = pc_z - z;                                    /* :106 */
-            const float w = gsdf_weight(sdf, g.T, g.inv_T);                /* :107 */
-            if (w > 0.f) {
-                if (!gsdf_key_in_range(vx, vy, vz)) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); continue; }
-                n_upd += 1.f;
-                const unsigned long long key = gsdf_key_pack(vx, vy, vz);
-                const float ws = w * gsdf_truncate(sdf, g.T);              /* :111 as additive sum */
-                const float wgx = w * Rn.x, wgy = w * Rn.y, wgz = w * Rn.z;   /* :112 */
-                /* LDS table = FUSE_LCAP/4 buckets of 4 keys; one probe = two ds_read_b128 of one bucket */
-                uint32_t hh = (a.debug & 256) ? ((uint32_t)(key ^ (key >> 21) ^ (key >> 42)) * 2654435761u) : gsdf_hash(key ^ 0x9E3779B97F4A7C15ull);
-                uint32_t b = (uint32_t)(((unsigned long long)hh * (FUSE_LCAP / 4)) >> 32);
-                const bool cheapfix = (a.debug & 128) != 0;
-                const unsigned long long qw = cheapfix ? (unsigned long long)__float_as_uint(w) : f2fix(w);
-                const unsigned long long qs = cheapfix ? (unsigned long long)__float_as_uint(ws) : f2fix(ws);
-                const unsigned long long qx = cheapfix ? (unsigned long long)__float_as_uint(wgx) : f2fix(wgx);
-                const unsigned long long qy = cheapfix ? (unsigned long long)__float_as_uint(wgy) : f2fix(wgy);
-                const unsigned long long qz = cheapfix ? (unsigned long long)__float_as_uint(wgz) : f2fix(wgz);
-                if (a.debug & 512) {
-                    atomicAdd(&L.w[4 * b], qw); atomicAdd(&L.s[4 * b], qs); atomicAdd(&L.gx[4 * b], qx);
-                    atomicAdd(&L.gy[4 * b], qy); atomicAdd(&L.gz[4 * b], qz);
-                    continue;
+        for (int c0 = 0; c0 < nk; c0 += FUSE_BATCH) {
+            unsigned long long key[FUSE_BATCH], q[FUSE_BATCH][5];
+            float f[FUSE_BATCH][5];
+            bool act[FUSE_BATCH];
+            uint32_t bk[FUSE_BATCH];
+            /* 1. the samples of this batch */
+#pragma unroll
+            for (int j = 0; j < FUSE_BATCH; ++j) {
+                const int kk = k_lo + it;
+                act[j] = valid && (c0 + j < nk);
+                it = it + 1 == nk ? 0 : it + 1;
+                const float s = z + (float)kk * g.vs;
+                const float pxw = s * Rxy.x + t[0], pyw = s * Rxy.y + t[1], pzw = s * Rxy.z + t[2];   /* :103 */
+                const int vx = gsdf_float2vox1(g.inv_vs, pxw);             /* :104 */
+                const int vy = gsdf_float2vox1(g.inv_vs, pyw);
+                const int vz = gsdf_float2vox1(g.inv_vs, pzw);
+                const float dx = g.vs * (float)vx - t[0], dy = g.vs * (float)vy - t[1], dz = g.vs * (float)vz - t[2];
+                const float pc_z = gsdf_sum3(R[2] * dx, R[5] * dy, R[8] * dz);   /* :105  (Rt row 2) */
+                const float sdf = pc_z - z;                                /* :106 */
+                const float w = gsdf_weight(sdf, g.T, g.inv_T);            /* :107 */
+                act[j] = act[j] && w > 0.f;
+                if (act[j] && !gsdf_key_in_range(vx, vy, vz)) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); act[j] = false; }
+                if (act[j]) n_upd += 1.f;
+                key[j] = gsdf_key_pack(vx, vy, vz);
+                f[j][0] = w;
+                f[j][1] = w * gsdf_truncate(sdf, g.T);                     /* :111 as additive sum */
+                f[j][2] = w * Rn.x; f[j][3] = w * Rn.y; f[j][4] = w * Rn.z;   /* :112 */
+#pragma unroll
+                for (int v = 0; v < 5; ++v) q[j][v] = f2fix(f[j][v]);
+                bk[j] = (uint32_t)(((unsigned long long)gsdf_hash(key[j] ^ 0x9E3779B97F4A7C15ull) * FUSE_NB) >> 32);
+            }
+            /* 2.-4. look the voxels up in the LDS table.  All pending samples of the batch advance
+             *    together: bucket (4 keys) = two ds_read_b128, match / first-empty by selects, at most
+             *    one CAS per sample and probe.  Plain LDS reads: a stale EMPTY is resolved by the CAS. */
+            int slot[FUSE_BATCH];
+            bool pend[FUSE_BATCH];
+#pragma unroll
+            for (int j = 0; j < FUSE_BATCH; ++j) { slot[j] = -1; pend[j] = act[j] && !(a.debug & 2); }
+            for (int probe = 0; probe < FUSE_LPROBE; ++probe) {
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < FUSE_BATCH; ++j) any = any || pend[j];
+                if (!any) break;
+                u64x2 k01[FUSE_BATCH], k23[FUSE_BATCH];
+#pragma unroll
+                for (int j = 0; j < FUSE_BATCH; ++j) {
+                    k01[j] = *reinterpret_cast<const u64x2*>(&L.key[4 * bk[j]]);
+                    k23[j] = *reinterpret_cast<const u64x2*>(&L.key[4 * bk[j] + 2]);
                 }
-                bool done = (a.debug & 2) != 0;
-                for (int p = 0; p < FUSE_LPROBE && !done; ++p) {
-                    /* plain (non-volatile) LDS reads -> ds_read_b128; a stale EMPTY is resolved by the CAS,
-                     * and a volatile access here would be lowered to a slow flat_load sc0 sc1 */
-                    const u64x2 k01 = *reinterpret_cast<const u64x2*>(&L.key[4 * b]);
-                    const u64x2 k23 = *reinterpret_cast<const u64x2*>(&L.key[4 * b + 2]);
-                    /* branch-free: index of the matching key, else of the first empty slot */
-                    int hit = k23.y == key ? 3 : -1;
-                    hit = k23.x == key ? 2 : hit;
-                    hit = k01.y == key ? 1 : hit;
-                    hit = k01.x == key ? 0 : hit;
-                    int emp = k23.y == GSDF_KEY_EMPTY ? 3 : -1;
-                    emp = k23.x == GSDF_KEY_EMPTY ? 2 : emp;
-                    emp = k01.y == GSDF_KEY_EMPTY ? 1 : emp;
-                    emp = k01.x == GSDF_KEY_EMPTY ? 0 : emp;
-                    int slot = hit >= 0 ? 4 * b + hit : -1;
-                    if (hit < 0 && emp >= 0) {                      /* at most ONE CAS per probe */
-                        const unsigned long long old = atomicCAS(&L.key[4 * b + emp], GSDF_KEY_EMPTY, key);
-                        if (old == GSDF_KEY_EMPTY || old == key) slot = 4 * b + emp;
-                        /* else: lost the slot to another voxel -> re-read the same bucket */
-                    } else if (hit < 0) {
-                        b = b + 1 == FUSE_LCAP / 4 ? 0 : b + 1;     /* bucket full of other voxels */
-                    }
-                    if (slot >= 0) {
-                        if (!(a.debug & 32))
-                        atomicAdd(&L.w[slot], qw);
-                        atomicAdd(&L.s[slot], qs);
-                        atomicAdd(&L.gx[slot], qx);
-                        atomicAdd(&L.gy[slot], qy);
-                        atomicAdd(&L.gz[slot], qz);
-                        done = true;
-                    }
+                int cas_at[FUSE_BATCH];
+#pragma unroll
+                for (int j = 0; j < FUSE_BATCH; ++j) {
+                    int hit = k23[j].y == key[j] ? 3 : -1;
+                    hit = k23[j].x == key[j] ? 2 : hit; hit = k01[j].y == key[j] ? 1 : hit; hit = k01[j].x == key[j] ? 0 : hit;
+                    int emp = k23[j].y == GSDF_KEY_EMPTY ? 3 : -1;
+                    emp = k23[j].x == GSDF_KEY_EMPTY ? 2 : emp; emp = k01[j].y == GSDF_KEY_EMPTY ? 1 : emp;
+                    emp = k01[j].x == GSDF_KEY_EMPTY ? 0 : emp;
+                    if (pend[j] && hit >= 0) { slot[j] = (int)(4 * bk[j]) + hit; pend[j] = false; }
+                    cas_at[j] = (pend[j] && emp >= 0) ? (int)(4 * bk[j]) + emp : -1;
+                    if (pend[j] && emp < 0) bk[j] = bk[j] + 1 == FUSE_NB ? 0 : bk[j] + 1;   /* bucket full of others */
                 }
-                if (!done) {
-                    if (a.debug & 64) atomicAdd(&a.st->n_hit, 1ull);      /* experiment: count LDS overflows */
-                    if (!(a.debug & 16)) hbm_accumulate(a.tab, key, w, ws, wgx, wgy, wgz, a.st);
+                unsigned long long old[FUSE_BATCH];
+#pragma unroll
+                for (int j = 0; j < FUSE_BATCH; ++j)
+                    old[j] = cas_at[j] >= 0 ? atomicCAS(&L.key[cas_at[j]], GSDF_KEY_EMPTY, key[j]) : 0ull;
+#pragma unroll
+                for (int j = 0; j < FUSE_BATCH; ++j)
+                    if (cas_at[j] >= 0 && (old[j] == GSDF_KEY_EMPTY || old[j] == key[j])) { slot[j] = cas_at[j]; pend[j] = false; }
+                /* a lost CAS (slot taken by another voxel) re-reads the same bucket in the next probe */
+            }
+            /* 5. accumulate (exact 64-bit integer adds) */
+#pragma unroll
+            for (int j = 0; j < FUSE_BATCH; ++j) {
+                if (!act[j] || (a.debug & 2)) continue;
+                if (slot[j] >= 0) {
+                    atomicAdd(&L.w[slot[j]], q[j][0]);
+                    atomicAdd(&L.s[slot[j]], q[j][1]);
+                    atomicAdd(&L.gx[slot[j]], q[j][2]);
+                    atomicAdd(&L.gy[slot[j]], q[j][3]);
+                    atomicAdd(&L.gz[slot[j]], q[j][4]);
+                } else {
+                    /* LDS table full for this voxel: contribute through the deferred list */
+                    gsdf_payload* p = gsdf_find_or_insert(a.tab, key[j]);
+                    if (!p) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
+                    else defer_append(a, p, f[j][0], f[j][1], f[j][2], f[j][3], f[j][4]);
                 }
             }
         }
     }
     __syncthreads();
-    /* flush the tile's distinct voxels to the HBM table */
-    if (!(a.debug & 1))
-    for (int i = tid; i < FUSE_LCAP; i += 256) {
-        const unsigned long long key = L.key[i];
-        if (key != GSDF_KEY_EMPTY) {
-            const float fw = fix2f(L.w[i]), fs = fix2f(L.s[i]), fx = fix2f(L.gx[i]), fy = fix2f(L.gy[i]), fz = fix2f(L.gz[i]);
-            if (a.debug & 4) {
-                if (!gsdf_find_or_insert(a.tab, key)) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
-            } else
-                hbm_accumulate(a.tab, key, fw, fs, fx, fy, fz, a.st);
+    /* flush the tile's distinct voxels: claim ownership with ONE atomic, then plain read-modify-write.
+     * Each lane owns FUSE_LCAP/256 LDS slots and drives them through the stages together, so the
+     * dependent HBM round trips (bucket keys -> exchange -> payload) of its entries overlap. */
+    if (!(a.debug & 1)) {
+        constexpr int NE = FUSE_LCAP / 256;
+        unsigned long long ekey[NE];
+        gsdf_bucket* B[NE];
+        ulonglong2 k01[NE], k23[NE];
+        gsdf_payload* P[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            ekey[e] = L.key[tid + 256 * e];
+            B[e] = a.tab.buckets + (gsdf_hash(ekey[e]) & a.tab.bucket_mask);
+            P[e] = nullptr;
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (ekey[e] != GSDF_KEY_EMPTY) {
+                k01[e] = *reinterpret_cast<const ulonglong2*>(&B[e]->key[0]);
+                k23[e] = *reinterpret_cast<const ulonglong2*>(&B[e]->key[2]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (ekey[e] == GSDF_KEY_EMPTY) continue;
+            /* voxel already in its home bucket: the common case after the first frames */
+            if (k01[e].x == ekey[e]) P[e] = &B[e]->pay[0];
+            else if (k01[e].y == ekey[e]) P[e] = &B[e]->pay[1];
+            else if (k23[e].x == ekey[e]) P[e] = &B[e]->pay[2];
+            else if (k23[e].y == ekey[e]) P[e] = &B[e]->pay[3];
+            else {
+                P[e] = gsdf_find_or_insert(a.tab, ekey[e]);          /* new voxel or overflowed bucket */
+                if (!P[e]) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); ekey[e] = GSDF_KEY_EMPTY; L.key[tid + 256 * e] = GSDF_KEY_EMPTY; }
+            }
+        }
+        unsigned int prev[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) prev[e] = ekey[e] != GSDF_KEY_EMPTY ? atomicExch(&P[e]->aux, a.tag) : a.tag;
+        float2 ws[NE], gxy[NE];
+        float gzv[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (ekey[e] != GSDF_KEY_EMPTY && prev[e] != a.tag) {
+                const float2* q2 = reinterpret_cast<const float2*>(P[e]);
+                ws[e] = q2[0]; gxy[e] = q2[1]; gzv[e] = P[e]->gz;
+            }
+        }
+        unsigned int my_defer = 0u;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (ekey[e] == GSDF_KEY_EMPTY) continue;
+            const int i = tid + 256 * e;
+            if (prev[e] != a.tag) {
+                /* owner for this launch: nobody else reads or writes w..gz until the kernel ends */
+                float2* q2 = reinterpret_cast<float2*>(P[e]);
+                ws[e].x += fix2f(L.w[i]); ws[e].y += fix2f(L.s[i]);
+                gxy[e].x += fix2f(L.gx[i]); gxy[e].y += fix2f(L.gy[i]);
+                gzv[e] += fix2f(L.gz[i]);
+                q2[0] = ws[e]; q2[1] = gxy[e]; P[e]->gz = gzv[e];
+                L.key[i] = GSDF_KEY_EMPTY;
+            } else {
+                /* another tile owns the voxel: keep the entry, remember where it goes */
+                L.key[i] = FUSE_DEFER_BIT | (unsigned long long)(uintptr_t)P[e];   /* device pointers use < 2^57 */
+                ++my_defer;
+            }
+        }
+        if (my_defer) atomicAdd(&L.n_defer, my_defer);
+        __syncthreads();
+        if (L.n_defer) {
+            if (tid == 0) L.defer_base = atomicAdd(a.deferred_count, L.n_defer);   /* one global atomic per workgroup */
+            __syncthreads();
+            if (tid == 0) L.n_defer = 0u;
+            __syncthreads();
+            for (int i = tid; i < FUSE_LCAP; i += 256) {
+                const unsigned long long key = L.key[i];
+                if (key == GSDF_KEY_EMPTY) continue;
+                const unsigned int o = L.defer_base + atomicAdd(&L.n_defer, 1u);
+                if (o >= a.deferred_cap) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); continue; }
+                gsdf_deferred d;
+                d.p = reinterpret_cast<gsdf_payload*>((uintptr_t)(key & ~FUSE_DEFER_BIT));
+                d.w = fix2f(L.w[i]); d.s = fix2f(L.s[i]); d.gx = fix2f(L.gx[i]); d.gy = fix2f(L.gy[i]); d.gz = fix2f(L.gz[i]);
+                d.pad = 0u;
+                a.deferred[o] = d;
+            }
         }
     }
     /* per-workgroup counters (plain stores into this workgroup's own row: no hot atomics) */
@@ -390,30 +513,57 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
     __syncthreads();
     if (tid == 0) {
         const unsigned long long nu = (unsigned long long)(L.red[0] + L.red[1] + L.red[2] + L.red[3]);
-        const unsigned long long nv = (unsigned long long)(L.red[4] + L.red[5] + L.red[6] + L.red[7]);
-        unsigned long long* c = a.blk_counters + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        const unsigned long long nv = blockIdx.z == 0 ? (unsigned long long)(L.red[4] + L.red[5] + L.red[6] + L.red[7]) : 0ull;
+        unsigned long long* c = a.blk_counters + 4 * (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
         c[0] = nu; c[1] = nv; c[2] += nu; c[3] += nv;
-        if (blockIdx.x == 0 && blockIdx.y == 0) a.st->frames += 1;        /* :120 increase_counter() */
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) a.st->frames += 1;   /* :120 increase_counter() */
+    }
+}
+
+/* adds the deferred contributions (voxels shared by several tiles, LDS overflow) after k_fuse.
+ * The list counter is cleared by the k_normals launch that precedes every k_fuse. */
+__global__ __launch_bounds__(256) void k_fuse_resolve(const gsdf_deferred* list, const unsigned int* count, unsigned int cap,
+                                                       gsdf_dev_state* gate, float* log_rows, long long max_rows) {
+    /* per-frame log row: pose7, converged, passes, hits of the last pass (main_scan_3d.cpp:268-280) */
+    if (log_rows && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long r = gate->log_rows;
+        if (r < max_rows) {
+            float* o = log_rows + 10 * r;
+            for (int i = 0; i < 7; ++i) o[i] = gate->pose7[i];
+            o[7] = (float)gate->converged; o[8] = (float)gate->passes; o[9] = gate->last_hits;
+        }
+        gate->log_rows = r + 1;
+    }
+    if (gate && !gate->converged) return;
+    unsigned int n = *count;
+    n = n < cap ? n : cap;
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const gsdf_deferred d = list[i];
+        unsafeAtomicAdd(&d.p->w, d.w);
+        unsafeAtomicAdd(&d.p->s, d.s);
+        unsafeAtomicAdd(&d.p->gx, d.gx);
+        unsafeAtomicAdd(&d.p->gy, d.gy);
+        unsafeAtomicAdd(&d.p->gz, d.gz);
     }
 }
 
 void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
                       const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
-                      int use_dev_pose, gsdf_table tab, gsdf_dev_state* st, unsigned long long* blk_counters) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fuse), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)sizeof(fuse_lds));
-        attr_set = true;
-    }
+                      int use_dev_pose, gsdf_table tab, gsdf_dev_state* st, unsigned long long* blk_counters,
+                      gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
+                      unsigned int tag, float* log_rows, long long max_rows) {
     fuse_args a;
     a.debug = g_fuse_debug;
     a.g = g; a.nc = nc; a.depth = depth; a.nx = nx; a.ny = ny; a.nz = nz; a.pose = pose;
     a.use_dev_pose = use_dev_pose; a.tab = tab; a.st = st; a.blk_counters = blk_counters;
-    dim3 grid((g.W + FUSE_T - 1) / FUSE_T, (g.H + FUSE_T - 1) / FUSE_T);
-    hipLaunchKernelGGL(k_fuse, grid, dim3(256), sizeof(fuse_lds), s, a);
+    a.deferred = deferred; a.deferred_count = deferred_count; a.deferred_cap = deferred_cap; a.tag = tag;
+    dim3 grid((g.W + FUSE_T - 1) / FUSE_T, (g.H + FUSE_T - 1) / FUSE_T, FUSE_ZSPLIT);
+    gsdf_dev_state* gate = use_dev_pose ? st : nullptr;
+    hipLaunchKernelGGL(k_fuse, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate,
+                       use_dev_pose ? log_rows : nullptr, max_rows);
 }
-int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T); }
+int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T) * FUSE_ZSPLIT; }
 
 /* ------------------------------------------------------------------------------------------------
  * RigidPointOptimizer::optimize_sampled -- one Gauss-Newton pass per launch.
@@ -426,30 +576,19 @@ int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * (
  * applies SE3::exp(-xi) to the device-resident pose and raises the done/converged flags, so
  * the host never has to look at an iteration.
  * ---------------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_begin(gsdf_dev_state* st, int max_passes, float conv_sq,
-                                                                  float damping) {
-    if (threadIdx.x == 0) {
-        st->done = max_passes <= 0 ? 1 : 0;
-        st->converged = 0;
-        st->passes = 0;
-        st->max_passes = max_passes;
-        st->ticket = 0u;
-        st->last_hits = 0.f;
-        st->conv_sq = conv_sq;
-        st->damping = damping;
-        gsdf_quat_to_R(st->pose7 + 3, st->R);
-    }
+/* RigidOptimizer with num_iterations_ <= 0: optimize() returns false without touching the pose */
+__global__ void k_track_none(gsdf_dev_state* st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->done = 1; st->converged = 0; st->passes = 0; st->last_hits = 0.f; }
 }
-void gsdf_launch_track_begin(hipStream_t s, gsdf_dev_state* st, int max_passes, float conv_sq, float damping) {
-    hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st, max_passes, conv_sq, damping);
-}
+void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st) { hipLaunchKernelGGL(k_track_none, dim3(1), dim3(64), 0, s, st); }
 
 #define TRK_PPT 4          /* pixels per lane handled as one batch: 4 independent gathers in flight */
 
 __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
                                                                  gsdf_table tab, gsdf_dev_state* st,
-                                                                 float* partials) {
-    if (st->done) return;
+                                                                 float* partials, gsdf_track_params tp) {
+    /* pass 0 starts a new optimize(): whatever `done` holds belongs to the previous frame */
+    if (tp.pass_index > 0 && st->done) return;
     __shared__ float wsum[GSDF_TRACK_BLOCK / 64][32];
     __shared__ float tot[32];
     __shared__ int is_last;
@@ -614,19 +753,20 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
             for (int j = i; j < 6; ++j) { Hm[6 * i + j] = tot[q]; Hm[6 * j + i] = tot[q]; ++q; }
         float xi[6];
         gsdf_llt_solve6(Hm, gvec, xi);                                    /* :86 */
-        const float damping = st->damping;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) xi[i] = damping * xi[i];
+        for (int i = 0; i < 6; ++i) xi[i] = tp.damping * xi[i];
         const float nrm = gsdf_sum3(xi[0] * xi[0], xi[1] * xi[1], xi[2] * xi[2]) +
                           gsdf_sum3(xi[3] * xi[3], xi[4] * xi[4], xi[5] * xi[5]);
-        const int passes = st->passes + 1;
+        const int passes = (tp.pass_index == 0 ? 0 : st->passes) + 1;
         st->passes = passes;
         st->last_hits = tot[28];
         st->n_hit += (unsigned long long)tot[28];
-        if (nrm < st->conv_sq) {                                          /* :88-91 (xi is NOT applied) */
+        int done = 0;
+        if (nrm < tp.conv_sq) {                                           /* :88-91 (xi is NOT applied) */
             st->converged = 1;
-            st->done = 1;
+            done = 1;
         } else {
+            st->converged = 0;
             bool nan = false;
 #pragma unroll
             for (int i = 0; i < 6; ++i) nan = nan || isnan(xi[i]);
@@ -642,30 +782,20 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
                 for (int i = 0; i < 7; ++i) st->pose7[i] = pose[i];
                 gsdf_quat_to_R(pose + 3, st->R);
             }
-            if (passes >= st->max_passes) st->done = 1;                   /* :98 return false */
+            if (passes >= tp.max_passes) done = 1;                        /* :98 return false */
         }
+        st->done = done;
         st->ticket = 0u;
+        /* progress for the host's adaptive pass issue (pinned host memory, system scope) */
+        if (tp.progress) {
+            __hip_atomic_store(&tp.progress[0], (tp.serial << 8) | (unsigned int)passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (done) __hip_atomic_store(&tp.progress[1], tp.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
-                            gsdf_dev_state* st, float* partials, int n_blocks) {
-    hipLaunchKernelGGL(k_track_pass, dim3(n_blocks), dim3(GSDF_TRACK_BLOCK), 0, s, g, depth, tab, st, partials);
-}
-
-/* per-frame log row: pose7, converged, passes, hits of the last pass (main_scan_3d.cpp:268-280) */
-__global__ void k_frame_log(gsdf_dev_state* st, float* rows, long long max_rows) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const long long r = st->log_rows;
-        if (r < max_rows) {
-            float* o = rows + 10 * r;
-            for (int i = 0; i < 7; ++i) o[i] = st->pose7[i];
-            o[7] = (float)st->converged; o[8] = (float)st->passes; o[9] = st->last_hits;
-        }
-        st->log_rows = r + 1;
-    }
-}
-void gsdf_launch_frame_log(hipStream_t s, gsdf_dev_state* st, float* log_rows, long long max_rows) {
-    hipLaunchKernelGGL(k_frame_log, dim3(1), dim3(64), 0, s, st, log_rows, max_rows);
+                            gsdf_dev_state* st, float* partials, int n_blocks, const gsdf_track_params& tp) {
+    hipLaunchKernelGGL(k_track_pass, dim3(n_blocks), dim3(GSDF_TRACK_BLOCK), 0, s, g, depth, tab, st, partials, tp);
 }
 
 struct pose7_arg { float p[7]; };

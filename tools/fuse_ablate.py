@@ -16,8 +16,8 @@ dev = [g.upload(f[0]) for f in frames]
 names = {0: "full", 1: "no flush", 2: "no LDS accumulate (flush empty)", 3: "compute only", 4: "flush: probe only",
          8: "flush: plain RMW", 17: "no flush, no overflow-to-HBM", 65: "no flush, count overflows", 16: "no overflow-to-HBM",
          49: "no flush, no overflow, LDS w-add skipped"}
-names.update({1+128: 'no flush, cheap fix', 1+256: 'no flush, cheap hash', 1+128+256: 'no flush, cheap fix+hash', 1+512: 'no flush, no probe (direct add)', 1+512+128+256: 'no flush, direct add, cheap fix+hash', 2+128+256: 'no LDS, cheap fix+hash'})
-for flags in (1, 1+128, 1+256, 1+128+256, 1+512, 1+512+128+256, 2, 2+128+256):
+names = {0: 'full', 1: 'no flush', 2: 'no LDS lookups/adds (flush empty)', 3: 'compute only'}
+for flags in (0, 1, 2, 3, 0):
     L.gsdf_debug_flags(flags)
     g.reset()
     for rep in range(2):
@@ -29,7 +29,6 @@ for flags in (1, 1+128, 1+256, 1+128+256, 1+512, 1+512+128+256, 2, 2+128+256):
         except Exception as e:
             print("  status:", e)
         pr = g.profile_read()
-        if flags == 65: print("   overflow samples/frame:", g.stats()["n_hit"] / n / (rep + 1), "of n_upd/frame", g.stats()["n_upd"] / n / (rep + 1))
         g.profile(0)
         print("flags=%d %-34s rep%d fusion %.1f us/frame  normals %.1f us" % (flags, names[flags], rep,
               pr["fusion"]["ms"] / n * 1e3, pr["normals"]["ms"] / n * 1e3))
