@@ -199,3 +199,49 @@ def R_to_quat_np(R):
     q[j] = (R[j, i] + R[i, j]) * s
     q[k] = (R[k, i] + R[i, k]) * s
     return q
+
+
+# ---- datasets on disk, in the layouts the reference's loaders read ---------------------------------
+
+def _png_gray16(path, img16):
+    """16-bit grayscale PNG via zlib (no imaging library in this image)."""
+    import struct
+    import zlib
+    h, w = img16.shape
+    raw = b"".join(b"\x00" + img16[y].astype(">u2").tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def write_dataset(seq, out_dir, layout="synth", with_poses=True, pose_file="pose.txt"):
+    """Write `seq` as a dataset directory: intrinsics.txt, depth PNGs (u16), optional TUM pose file.
+    layout "synth": depth/%03d.png 1-based (SynthLoader.h:64-83); "tum": associated.txt + depth/<ts>.png
+    (TumrgbdLoader.h:80-104).  Returns the directory (with trailing slash, as --input expects)."""
+    import os
+    out_dir = os.path.join(out_dir, "")
+    os.makedirs(os.path.join(out_dir, "depth"), exist_ok=True)
+    with open(out_dir + "intrinsics.txt", "w") as f:
+        for r in range(3):
+            f.write(" ".join(repr(float(seq.K[r, c])) for c in range(3)) + "\n")
+    assoc, poses = [], []
+    for i in range(seq.n):
+        ts = "%03d" % (i + 1) if layout == "synth" else "%.6f" % (1305031102.0 + i / 30.0)
+        name = "depth/%s.png" % ts
+        _png_gray16(out_dir + name, seq.depth_u16(i))
+        assoc.append("%s rgb/%s.png %s %s" % (ts, ts, ts, name))
+        R, t = seq.pose(i)
+        q = R_to_quat_np(R)
+        poses.append("%s %.9g %.9g %.9g %.9g %.9g %.9g %.9g" % (ts, t[0], t[1], t[2], q[0], q[1], q[2], q[3]))
+    if layout == "tum":
+        with open(out_dir + "associated.txt", "w") as f:
+            f.write("# rgb_timestamp rgb_file depth_timestamp depth_file\n" + "\n".join(assoc) + "\n")
+    if with_poses:
+        with open(out_dir + pose_file, "w") as f:
+            f.write("\n".join(poses) + "\n")
+    return out_dir

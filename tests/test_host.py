@@ -1,0 +1,109 @@
+"""Host side above the C-ABI (gradient-sdf_amd/host): facade classes + Scan3D CLI.
+not gpu: the CPU-only self test (PNG codec, pose parsing, SE3, generated marching-cubes tables).
+gpu:     Scan3D end to end on a small synthetic dataset against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pose7_from
+
+HOST = os.path.join(ROOT, "gradient-sdf_amd", "host")
+
+
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "gradient-sdf_amd", "csrc"), "-s"])
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+
+
+def test_host_selftest(tmp_path):
+    _build()
+    out = subprocess.run([os.path.join(HOST, "host_selftest"), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "host_selftest: OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_python_png_is_read_by_cpp_loader(pkg, tmp_path):
+    """synth.write_dataset -> png16.cpp reader: checked through host_selftest's own round trip format."""
+    seq = pkg.synth.Sequence("spheres", 64, 48, n_frames=2, seed=3)
+    d = pkg.synth.write_dataset(seq, str(tmp_path / "ds"), layout="synth")
+    assert os.path.exists(d + "depth/001.png") and os.path.exists(d + "pose.txt") and os.path.exists(d + "intrinsics.txt")
+    import zlib
+    raw = open(d + "depth/002.png", "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    i = raw.index(b"IDAT")
+    n = int.from_bytes(raw[i - 4:i], "big")
+    lines = zlib.decompress(raw[i + 4:i + 4 + n])
+    img = np.frombuffer(lines, np.uint8).reshape(48, 1 + 2 * 64)[:, 1:].copy().view(">u2")
+    assert np.array_equal(img.astype(np.uint16), seq.depth_u16(1))
+
+
+@pytest.mark.gpu
+def test_scan3d_gt_pose_fusion_matches_oracle(pkg, O, tmp_path):
+    _build()
+    W, H, n = 320, 240, 4
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=4, step_deg=2.0)
+    ds = pkg.synth.write_dataset(seq, str(tmp_path / "ds"), layout="synth")
+    res = str(tmp_path / "out") + "/"
+    os.makedirs(res)
+    cmd = [os.path.join(HOST, "Scan3D"), "--input", ds, "--results", res, "--scan-type", "grad-sdf", "--data-type", "synth",
+           "--voxel-size", "0.02", "--trunc", "5", "--width", str(W), "--height", str(H), "--hash-capacity", "20", "--save-sdf"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "Integrate depth data into Sdf" in out.stdout and "Current frame counter: %d" % n in out.stdout
+    # oracle on the same files' content, with the CLI's pose path: file -> quaternion -> R -> SE3 -> R
+    vs = np.float32(0.02)
+    o = O.Oracle(vs, np.float32(5) * vs, W, H, seq.K)
+    poses = np.loadtxt(ds + "pose.txt")
+    for i in range(n):
+        d = seq.depth_u16(i).astype(np.float32) * np.float32(0.001)
+        q = poses[i, 4:8].astype(np.float32)
+        R = O.quat_to_R(O.R_to_quat(O.quat_to_R(q)))
+        o.update(d, R, poses[i, 1:4].astype(np.float32))
+    keys, pay = o.export()
+    info = open(res + "gradient_sdf_grid_info.txt").read().split("\n")
+    dim = [int(v) for v in info[1].split(":")[1].split()]
+    mn = [int(v) for v in info[2].split(":")[1].split()]
+    assert mn == keys.min(0).tolist() and dim == (keys.max(0) - keys.min(0) + 1).tolist()
+    lin = (dim[0] * dim[1] * (keys[:, 2] - mn[2]) + dim[0] * (keys[:, 1] - mn[1]) + keys[:, 0] - mn[0])
+    got = np.loadtxt(res + "gradient_sdf_sdf_d.txt")
+    assert np.array_equal(got[:, 0].astype(np.int64), lin)                    # same voxel set, same order
+    assert np.abs(got[:, 1] - pay[:, 0]).max() < 1e-4
+    w = np.loadtxt(res + "gradient_sdf_sdf_weight.txt")[:, 1]
+    assert np.abs(w - pay[:, 4]).max() <= 1e-4 * max(1.0, pay[:, 4].max())
+    pl = open(res + "gradient_sdf_cloud_final.ply").read().split("\n")
+    assert pl[0] == "ply" and int(pl[2].split()[-1]) > 100
+    mesh = open(res + "gradient_sdf_mesh_final.ply").read().split("\n")
+    assert int(mesh[2].split()[-1]) > 300                                      # vertices
+    pf = np.loadtxt(res + "_poses.txt")
+    assert pf.shape == (n, 8) and np.abs(pf[:, 1:4] - poses[:, 1:4]).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_scan3d_tracked_mode_writes_tum_poses(pkg, O, tmp_path):
+    _build()
+    W, H, n = 640, 480, 4
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=0)
+    ds = pkg.synth.write_dataset(seq, str(tmp_path / "ds"), layout="tum", with_poses=False)
+    res = str(tmp_path / "out") + "/"
+    os.makedirs(res)
+    cmd = [os.path.join(HOST, "Scan3D"), "--input", ds, "--results", res, "--scan-type", "grad-sdf", "--data-type", "tum",
+           "--voxel-size", "0.01", "--trunc", "10"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "No GT poses are avaible!" in out.stderr and "Point optimization" in out.stdout
+    pf = np.loadtxt(res + "_poses.txt")
+    assert pf.shape == (n, 8)
+    # oracle loop starting at identity (setup()), TUM depth unit 1/5000
+    vs = np.float32(0.01)
+    o = O.Oracle(vs, np.float32(10) * vs, W, H, seq.K)
+    pose = np.array([0, 0, 0, 0, 0, 0, 1], np.float32)
+    for i in range(n):
+        d = seq.depth_u16(i).astype(np.float32) * np.float32(1.0 / 5000)
+        if i == 0:
+            o.update(d, np.eye(3), np.zeros(3))
+        else:
+            conv, pose, _, _, _ = o.track(d, pose)
+            if conv:
+                o.update(d, O.quat_to_R(pose[3:]), pose[:3])
+        assert np.abs(pf[i, 1:4] - pose[:3]).max() < 2e-4 and np.abs(np.abs(pf[i, 4:8]) - np.abs(pose[3:])).max() < 2e-4
