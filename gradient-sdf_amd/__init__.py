@@ -10,5 +10,5 @@ Layout
 The directory name contains a hyphen (task contract); import it through
 ``__graft_entry__.package()`` which registers it as ``gradient_sdf_amd``.
 """
-from . import binding, synth  # noqa: F401
+from . import binding, parallel, synth  # noqa: F401
 from .binding import GradSdf, GsdfError  # noqa: F401

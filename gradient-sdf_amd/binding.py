@@ -93,6 +93,8 @@ def load():
         "gsdf_count": (C.c_int, [vp, i64p]),
         "gsdf_export": (C.c_int, [vp, i32p, fp, C.c_int64, i64p, C.c_int, C.c_int]),
         "gsdf_merge_raw": (C.c_int, [vp, i32p, fp, C.c_int64]),
+        "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
+        "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
         "gsdf_query": (C.c_int, [vp, fp, C.c_int64, fp, fp, fp]),
         "gsdf_dev_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_int64]),
         "gsdf_dev_free": (C.c_int, [vp, vp]),
@@ -114,7 +116,8 @@ ABI_SYMBOLS = [
     "gsdf_last_error", "gsdf_version", "gsdf_create", "gsdf_destroy", "gsdf_reset", "gsdf_set_zrange",
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
     "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
-    "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_merge_raw", "gsdf_query",
+    "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_merge_raw", "gsdf_export_raw_dev",
+    "gsdf_merge_raw_dev", "gsdf_query",
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_timer_start", "gsdf_timer_stop_ms",
     "gsdf_profile", "gsdf_profile_read",
 ]
@@ -255,6 +258,15 @@ class GradSdf:
         k = np.ascontiguousarray(keys, np.int32).reshape(-1, 3)
         p = _f32(payload_raw).reshape(-1, 5)
         self._chk(self.L.gsdf_merge_raw(self.h, k.ctypes.data_as(C.POINTER(C.c_int32)), _fp(p), k.shape[0]))
+
+    def export_raw_dev(self, keys_ptr, payload_ptr, max_n):
+        """Unsorted (key, raw sums) compaction into device buffers (e.g. torch tensors' data_ptr())."""
+        n = C.c_int64(0)
+        self._chk(self.L.gsdf_export_raw_dev(self.h, C.c_void_p(keys_ptr), C.c_void_p(payload_ptr), int(max_n), C.byref(n)))
+        return n.value
+
+    def merge_raw_dev(self, keys_ptr, payload_ptr, n):
+        self._chk(self.L.gsdf_merge_raw_dev(self.h, C.c_void_p(keys_ptr), C.c_void_p(payload_ptr), int(n)))
 
     def query(self, pts):
         p = _f32(pts).reshape(-1, 3)

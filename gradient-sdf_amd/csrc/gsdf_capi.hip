@@ -569,6 +569,28 @@ int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, i
     return gsdf_sync(c);
 }
 
+int gsdf_export_raw_dev(gsdf_ctx* c, int32_t* keys_dev, float* payload_dev, int64_t max_n, int64_t* n) {
+    if (!c || !keys_dev || !payload_dev || max_n < 0) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+    gsdf_launch_export_raw(c->stream, c->tab, c->n_slots, keys_dev, payload_dev, c->counter, max_n);
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, c->counter, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n) *n = (int64_t)h;
+    if ((int64_t)h > max_n) return fail(GSDF_ERR_INVALID, "export buffer too small (call gsdf_count first)");
+    return GSDF_OK;
+}
+
+int gsdf_merge_raw_dev(gsdf_ctx* c, const int32_t* keys_dev, const float* payload_raw_dev, int64_t n) {
+    if (!c || (n > 0 && (!keys_dev || !payload_raw_dev))) return fail(GSDF_ERR_INVALID, "null argument");
+    if (n <= 0) return GSDF_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_launch_merge_raw(c->stream, c->tab, keys_dev, payload_raw_dev, n, c->st);
+    HIP_TRY(hipGetLastError());
+    return gsdf_sync(c);
+}
+
 int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w) {
     if (!c || (n > 0 && (!pts_host || !dist || !grad || !w))) return fail(GSDF_ERR_INVALID, "null argument");
     if (n <= 0) return GSDF_OK;

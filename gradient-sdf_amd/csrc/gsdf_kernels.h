@@ -85,6 +85,8 @@ void gsdf_launch_set_pose(hipStream_t s, gsdf_dev_state* st, const float* pose7_
                           const float pose7_host[7]);
 void gsdf_launch_export(hipStream_t s, gsdf_table tab, size_t n_slots, unsigned long long* keys_out,
                         float* payload_out, unsigned long long* counter, long long max_n, int raw);
+void gsdf_launch_export_raw(hipStream_t s, gsdf_table tab, size_t n_slots, int32_t* keys_out, float* payload_out,
+                            unsigned long long* counter, long long max_n);
 void gsdf_launch_merge_raw(hipStream_t s, gsdf_table tab, const int32_t* keys, const float* payload,
                            long long n, gsdf_dev_state* st);
 void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, const float* pts, long long n,

@@ -850,6 +850,30 @@ __global__ __launch_bounds__(256) void k_merge_raw(gsdf_table tab, const int32_t
         hbm_accumulate(tab, gsdf_key_pack(x, y, z), p[4], p[0], p[1], p[2], p[3], st);
     }
 }
+/* unsorted compaction of (key as int32 x3, raw sums s,gx,gy,gz,w) into caller-provided device buffers */
+__global__ __launch_bounds__(256) void k_export_raw(gsdf_table tab, size_t n_slots, int32_t* keys_out, float* payload_out,
+                                                    unsigned long long* counter, long long max_n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n_slots; i += stride) {
+        const gsdf_bucket* B = tab.buckets + (i >> 2);
+        const unsigned long long key = B->key[i & 3];
+        if (key == GSDF_KEY_EMPTY) continue;
+        const gsdf_payload sl = B->pay[i & 3];
+        const unsigned long long o = atomicAdd(counter, 1ull);
+        if ((long long)o >= max_n) continue;
+        int x, y, z;
+        gsdf_key_unpack(key, &x, &y, &z);
+        keys_out[3 * o] = x; keys_out[3 * o + 1] = y; keys_out[3 * o + 2] = z;
+        float* p = payload_out + 5 * o;
+        p[0] = sl.s; p[1] = sl.gx; p[2] = sl.gy; p[3] = sl.gz; p[4] = sl.w;
+    }
+}
+void gsdf_launch_export_raw(hipStream_t s, gsdf_table tab, size_t n_slots, int32_t* keys_out, float* payload_out,
+                            unsigned long long* counter, long long max_n) {
+    hipLaunchKernelGGL(k_export_raw, dim3(2048), dim3(256), 0, s, tab, n_slots, keys_out, payload_out, counter, max_n);
+}
+
 void gsdf_launch_merge_raw(hipStream_t s, gsdf_table tab, const int32_t* keys, const float* payload, long long n,
                            gsdf_dev_state* st) {
     if (n <= 0) return;

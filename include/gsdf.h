@@ -117,6 +117,12 @@ int gsdf_export(gsdf_ctx* c, int32_t* keys, float* payload, int64_t max_n, int64
 /* additive merge of raw sums into this table (frame-sharded fusion) */
 int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, int64_t n);
 
+/* device-buffer variants for the multi-GPU exchange (RCCL works on device memory): unsorted
+ * compaction of (key, raw sums) into caller-provided DEVICE buffers / additive merge from them.
+ * These are the pack / unpack steps either side of the all-gather. */
+int gsdf_export_raw_dev(gsdf_ctx* c, int32_t* keys_dev, float* payload_raw_dev, int64_t max_n, int64_t* n);
+int gsdf_merge_raw_dev(gsdf_ctx* c, const int32_t* keys_dev, const float* payload_raw_dev, int64_t n);
+
 /* Sdf::weights(point) and Sdf::tsdf(point, &grad) at n points -- MapGradPixelSdf.h:109-125.
  * w[i]==0 marks a missing voxel (dist/grad are then 0; the reference's .at() would throw). */
 int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w);

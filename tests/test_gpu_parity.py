@@ -184,3 +184,41 @@ def test_table_full_is_reported(pkg, O):
         g.update(d, R, t)
     assert e.value.code == pkg.binding.ERR_TABLE_FULL
     g.close()
+
+
+def test_device_export_merge_is_the_shard_exchange(pkg, O):
+    """gsdf_export_raw_dev -> (all-gather) -> gsdf_merge_raw_dev: the pack/unpack either side of the RCCL
+    exchange, here as two logical shards on one GPU."""
+    seq, g, o = _mk(pkg, O, n=4, cap=19)
+    gb = pkg.GradSdf(np.float32(0.02), np.float32(5) * np.float32(0.02), 160, 120, seq.K, capacity_log2=19)
+    for i in range(seq.n):
+        d, R, t = seq.frame(i)
+        (g if i < 2 else gb).update(d, R, t)
+        o.update(d, R, t)
+    n = gb.count()
+    kbuf = g.upload(np.zeros((n, 3), np.int32))
+    pbuf = g.upload(np.zeros((n, 5), np.float32))
+    got = gb.export_raw_dev(kbuf.value, pbuf.value, n)
+    assert got == n
+    g.merge_raw_dev(kbuf.value, pbuf.value, n)
+    _cmp_tables(g, o)
+    g.close()
+    gb.close()
+
+
+def test_stress_config_c3_small_slice(pkg, O):
+    """BASELINE config C3 geometry (5 mm voxels, trunc 10, K scaled) on a 1280x960 frame, capacity 2^23."""
+    W, H = 1280, 960
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=1, seed=0)
+    vs = np.float32(0.005)
+    T = np.float32(10) * vs
+    assert float(T) == pytest.approx(0.049999997, abs=1e-9)
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=23)
+    o = O.Oracle(vs, T, W, H, seq.K)
+    d, R, t = seq.frame(0)
+    g.update(d, R, t)
+    nu, nv = o.update(d, R, t)
+    st = g.stats()
+    assert st["n_upd"] == nu and st["n_valid"] == nv
+    _cmp_tables(g, o)
+    g.close()
