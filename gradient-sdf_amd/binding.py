@@ -18,7 +18,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libgsdf.so")
+LIB_PATH = os.environ.get("GSDF_LIB", os.path.join(CSRC, "libgsdf.so"))   # GSDF_LIB: kernel-variant experiments (tools/)
 
 GSDF_OK, ERR_TABLE_FULL, ERR_KEY_RANGE, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4, 5
 

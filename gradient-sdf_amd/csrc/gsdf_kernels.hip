@@ -324,8 +324,9 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
         }
     }
     /* this workgroup's share of the ray walk k = -factor..factor (:101); the order is free (sums) */
-    const int k_lo = blockIdx.z == 0 ? -g.factor : 1;
-    const int k_hi = blockIdx.z == 0 ? 0 : g.factor;
+    const int nk_all = 2 * g.factor + 1;
+    const int k_lo = -g.factor + (int)((blockIdx.z * nk_all) / gridDim.z);
+    const int k_hi = -g.factor + (int)(((blockIdx.z + 1) * nk_all) / gridDim.z) - 1;
     const int nk = k_hi - k_lo + 1;
     float n_upd = 0.f;
     if (nk > 0) {
@@ -352,15 +353,20 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
                 const float sdf = pc_z - z;                                /* :106 */
                 const float w = gsdf_weight(sdf, g.T, g.inv_T);            /* :107 */
                 act[j] = act[j] && w > 0.f;
-                if (act[j] && !gsdf_key_in_range(vx, vy, vz)) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); act[j] = false; }
+                /* packable iff every biased coordinate fits 21 bits (same test as gsdf_key_in_range) */
+                const uint32_t ux = (uint32_t)(vx + GSDF_KEY_OFF), uy = (uint32_t)(vy + GSDF_KEY_OFF), uz = (uint32_t)(vz + GSDF_KEY_OFF);
+                if (act[j] && ((ux | uy | uz) >> 21)) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); act[j] = false; }
                 if (act[j]) n_upd += 1.f;
-                key[j] = gsdf_key_pack(vx, vy, vz);
+                key[j] = (unsigned long long)ux | ((unsigned long long)uy << 21) | ((unsigned long long)uz << 42);
                 f[j][0] = w;
                 f[j][1] = w * gsdf_truncate(sdf, g.T);                     /* :111 as additive sum */
                 f[j][2] = w * Rn.x; f[j][3] = w * Rn.y; f[j][4] = w * Rn.z;   /* :112 */
 #pragma unroll
                 for (int v = 0; v < 5; ++v) q[j][v] = f2fix(f[j][v]);
-                bk[j] = (uint32_t)(((unsigned long long)gsdf_hash(key[j] ^ 0x9E3779B97F4A7C15ull) * FUSE_NB) >> 32);
+                /* LDS bucket: cheap 32-bit spatial mix (the HBM table keeps the full 64-bit finaliser) */
+                uint32_t hh = (ux * 0x9E3779B1u) ^ (uy * 0x85EBCA77u) ^ (uz * 0xC2B2AE3Du);
+                hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 13;
+                bk[j] = __umulhi(hh, (uint32_t)FUSE_NB);
             }
             /* 2.-4. look the voxels up in the LDS table.  All pending samples of the batch advance
              *    together: bucket (4 keys) = two ds_read_b128, match / first-empty by selects, at most
