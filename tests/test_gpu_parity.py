@@ -222,3 +222,55 @@ def test_stress_config_c3_small_slice(pkg, O):
     assert st["n_upd"] == nu and st["n_valid"] == nv
     _cmp_tables(g, o)
     g.close()
+
+
+def test_edge_frames_empty_invalid_and_ragged(pkg, O):
+    """Edge cases the path must survive: all-invalid depth, depth outside [zmin,zmax], a frame whose
+    size is not a multiple of the 16x16 / 32x8 tiles, NaN-free output."""
+    W, H = 77, 45
+    K = pkg.synth.intrinsics(W, H)
+    vs = np.float32(0.02)
+    g = pkg.GradSdf(vs, np.float32(0.1), W, H, K, capacity_log2=16)
+    o = O.Oracle(vs, np.float32(0.1), W, H, K)
+    zero = np.zeros((H, W), np.float32)
+    g.update(zero, np.eye(3), np.zeros(3))
+    o.update(zero, np.eye(3), np.zeros(3))
+    assert g.count() == 0 and g.stats()["frames"] == 1
+    far = np.full((H, W), 7.5, np.float32)                  # >= zmax: every pixel skipped
+    g.update(far, np.eye(3), np.zeros(3))
+    assert g.count() == 0
+    conv, pose, passes = g.track(far, np.array([0, 0, 0, 0, 0, 0, 1], np.float32), iters=3)
+    assert not conv and passes == 3
+    rng = np.random.default_rng(1)
+    d = (1.0 + 0.3 * rng.random((H, W))).astype(np.float32)
+    d[rng.random((H, W)) < 0.2] = 0.0                       # ragged holes
+    R = O.quat_to_R(np.array([0.05, -0.1, 0.02, 0.99], np.float32) / np.float32(np.linalg.norm([0.05, -0.1, 0.02, 0.99])))
+    t = np.array([0.3, -0.2, 0.1], np.float32)
+    g.update(d, R, t)
+    o.update(far, np.eye(3), np.zeros(3))
+    o.update(d, R, t)
+    _cmp_tables(g, o)
+    assert g.stats()["frames"] == o.frame_counter() == 3
+    g.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fusion_keys_bit_exact_random_poses(pkg, O, seed):
+    """Random rotations / translations (oblique rays stress the rounding of all three key components)."""
+    rng = np.random.default_rng(seed)
+    W, H = 128, 96
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=1, seed=seed)
+    vs = np.float32(0.015)
+    T = np.float32(7) * vs
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=19)
+    o = O.Oracle(vs, T, W, H, seq.K)
+    d, _, _ = seq.frame(0)
+    for _ in range(3):
+        q = rng.standard_normal(4).astype(np.float32)
+        q /= np.float32(np.linalg.norm(q))
+        R = O.quat_to_R(q)
+        t = rng.uniform(-3, 3, 3).astype(np.float32)
+        g.update(d, R, t)
+        o.update(d, R, t)
+    _cmp_tables(g, o)
+    g.close()
