@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--trunc", type=float, default=10.0)
     ap.add_argument("--hash-capacity-log2", type=int, default=22)
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="dry run of the N>1 code path on a 1-GPU box: every rank uses device 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -49,11 +52,13 @@ def main():
     # torch first: libgsdf binds to the HIP runtime already in the process (gradient-sdf_amd/binding.py)
     import torch
     import torch.distributed as dist
+    if args.single_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -108,7 +113,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
