@@ -181,6 +181,14 @@ def main():
                "sample": "first %d frames of the same stream (1 setup + %d tracked+fused), serial oracle, %s host cores present"
                          % (nc, nc - 1, os.cpu_count())}
 
+    # HBM traffic of one fusion (k_fuse + k_fuse_resolve) from the committed rocprofv3 PMC passes
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            traffic = json.load(f).get("traffic_bytes_per_fusion")
+    except (OSError, ValueError):
+        pass
+
     if rank == 0:
         total_frames = K * world
         out = {
@@ -207,8 +215,8 @@ def main():
                 "fused_only_fps": round(fused_fps * world, 1),
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_fuse", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bound": "hbm", "kernel": "k_fuse (+k_fuse_resolve)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(fuse_ms * 1e3, 2),
                 "launches": prof["fusion"]["launches"],
             },
