@@ -177,9 +177,23 @@ def main():
             if conv:
                 o.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3])
         dt = time.perf_counter() - tc
+        # the reference's OMP-structured variant (critical-section fusion, 4-thread tracker reduction,
+        # MapGradPixelSdfOmp.cpp:82,112 / RigidPointOptimizerOmp.cpp:68-69) on a shorter sample
+        no = min(4, nc)
+        o2 = O.Oracle(vs, T, W, H, seq.K, threads=4)
+        tc = time.perf_counter()
+        o2.update(frames[0][0], quat_to_R(p0[3:]), t0, omp=True)
+        pose = p0.copy()
+        for i in range(1, no):
+            conv, pose, _, _, _ = o2.track(frames[i][0], pose, omp=True)
+            if conv:
+                o2.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3], omp=True)
+        dto = time.perf_counter() - tc
         cpu = {"value": round((nc - 1) / dt, 3) if nc > 1 else 0.0, "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "first %d frames of the same stream (1 setup + %d tracked+fused), serial oracle, %s host cores present"
-                         % (nc, nc - 1, os.cpu_count())}
+                         % (nc, nc - 1, os.cpu_count()),
+               "omp4_value": round((no - 1) / dto, 3) if no > 1 else 0.0,
+               "omp4_note": "reference's OMP structure (fusion inside omp critical, 4-thread tracker), first %d frames" % no}
 
     # HBM traffic of one fusion (k_fuse + k_fuse_resolve) from the committed rocprofv3 PMC passes
     traffic = None

@@ -16,8 +16,10 @@
 
 #if defined(__HIPCC__)
 #define GSDF_HD __host__ __device__ __forceinline__
+#define GSDF_UNROLL _Pragma("unroll")
 #else
 #define GSDF_HD inline
+#define GSDF_UNROLL
 #endif
 
 struct gsdf_v3 { float x, y, z; };
@@ -161,36 +163,36 @@ GSDF_HD void gsdf_se3_exp_mul(const float* xi, float* pose7) {
  * llt_inplace; the triangular solves still run (=> inf/NaN for an all-zero H). */
 GSDF_HD void gsdf_llt_solve6(const float* Hin, const float* g, float* x) {
     float L[36];
-#pragma unroll
+GSDF_UNROLL
     for (int i = 0; i < 36; ++i) L[i] = Hin[i];
-#pragma unroll
+GSDF_UNROLL
     for (int k = 0; k < 6; ++k) {
         float d = L[6 * k + k];
-#pragma unroll
+GSDF_UNROLL
         for (int j = 0; j < k; ++j) d -= L[6 * k + j] * L[6 * k + j];
         if (d <= 0.f) break;
         d = sqrtf(d);
         L[6 * k + k] = d;
-#pragma unroll
+GSDF_UNROLL
         for (int i = k + 1; i < 6; ++i) {
             float s = L[6 * i + k];
-#pragma unroll
+GSDF_UNROLL
             for (int j = 0; j < k; ++j) s -= L[6 * i + j] * L[6 * k + j];
             L[6 * i + k] = s / d;
         }
     }
     float y[6];
-#pragma unroll
+GSDF_UNROLL
     for (int i = 0; i < 6; ++i) {
         float s = g[i];
-#pragma unroll
+GSDF_UNROLL
         for (int j = 0; j < i; ++j) s -= L[6 * i + j] * y[j];
         y[i] = s / L[6 * i + i];
     }
-#pragma unroll
+GSDF_UNROLL
     for (int i = 5; i >= 0; --i) {
         float s = y[i];
-#pragma unroll
+GSDF_UNROLL
         for (int j = i + 1; j < 6; ++j) s -= L[6 * j + i] * x[j];
         x[i] = s / L[6 * i + i];
     }
