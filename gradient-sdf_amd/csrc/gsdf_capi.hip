@@ -183,7 +183,9 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     if (tp.serial == 0) tp.serial = c->track_serial = 1;
     const bool adaptive = c->adaptive && c->progress;
     tp.progress = adaptive ? c->progress_dev : nullptr;
-    for (int k = 0; k < iters; ++k) {
+    /* launches 0..iters-1 gather; launch k>0 first finishes pass k-1 (reduce, solve, update); launch
+     * `iters` is head-only and finishes the last pass */
+    for (int k = 0; k <= iters; ++k) {
         if (adaptive && c->progress[1] == tp.serial) break;  /* device finished this optimize() */
         tp.pass_index = k;
         {
@@ -326,7 +328,7 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipMalloc((void**)&c->normals, 3 * N * sizeof(float)));
     /* tracker grid: a multiple of the 256 CUs when the frame is large enough, 1-4 pixels per lane */
     c->track_blocks = N >= (size_t)1 << 20 ? 1024 : N >= (size_t)1 << 18 ? 512 : (int)std::max<size_t>(1, (N + 511) / 512);
-    HIP_TRY(hipMalloc((void**)&c->partials, (size_t)c->track_blocks * 32 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->partials, (size_t)2 * c->track_blocks * 32 * sizeof(float)));   /* two row sets */
     c->fuse_blocks = gsdf_fuse_grid_blocks(W, H);
     HIP_TRY(hipMalloc((void**)&c->blk_counters, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));

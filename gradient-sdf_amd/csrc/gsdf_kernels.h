@@ -17,6 +17,12 @@
 
 /* Device-resident engine state: the tracker's pose (RigidOptimizer::pose_, RigidOptimizer.h:64),
  * per-optimize flags, sticky launch status and the counters the stats API reports. */
+/* tracker state handed from the head of one pass launch to the next (double-buffered by pass parity) */
+struct gsdf_trk_buf {
+    float pose7[7];
+    int done, converged, passes;
+};
+
 struct gsdf_dev_state {
     float pose7[7];               /* tx ty tz qx qy qz qw */
     float R[9];                   /* rotationMatrix() of pose7, kept in step by whoever writes pose7 */
@@ -33,6 +39,7 @@ struct gsdf_dev_state {
     unsigned long long n_upd, n_valid, n_hit, n_occupied;
     long long frames;             /* Sdf::counter_ */
     long long log_rows;
+    gsdf_trk_buf trk[2];
 };
 
 struct gsdf_frame_geom {

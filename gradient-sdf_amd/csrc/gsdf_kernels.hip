@@ -577,10 +577,11 @@ int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * (
  * Every lane gathers the voxel under its back-projected pixel (one 32-byte slot), forms the
  * residual phi and the 6-vector J and accumulates the 29 normal-equation sums in registers.
  * Sums are reduced with wavefront DPP shuffles, then across the 4 waves through LDS, and each
- * workgroup stores one partial row.  The last workgroup to arrive (agent-scope release /
- * acquire around a ticket counter) adds the rows in a fixed order, solves the 6x6 system,
- * applies SE3::exp(-xi) to the device-resident pose and raises the done/converged flags, so
- * the host never has to look at an iteration.
+ * workgroup stores one partial row.  The NEXT launch starts with a "head" in which every workgroup
+ * adds those rows in the same fixed order, solves the 6x6 system and applies SE3::exp(-xi)
+ * (bit-identical everywhere), so a launch contains no inter-workgroup synchronisation at all: the
+ * kernel boundary is the only barrier, rows and tracker state are double-buffered by pass parity,
+ * and workgroup 0 publishes pose / done / converged for the host and the fusion kernels.
  * ---------------------------------------------------------------------------------------------- */
 /* RigidOptimizer with num_iterations_ <= 0: optimize() returns false without touching the pose */
 __global__ void k_track_none(gsdf_dev_state* st) {
@@ -592,18 +593,123 @@ void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st) { hipLaunchKernel
 
 __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
                                                                  gsdf_table tab, gsdf_dev_state* st,
-                                                                 float* partials, gsdf_track_params tp) {
-    /* pass 0 starts a new optimize(): whatever `done` holds belongs to the previous frame */
-    if (tp.pass_index > 0 && st->done) return;
+                                                                 float* rows, int rows_stride, gsdf_track_params tp) {
     __shared__ float wsum[GSDF_TRACK_BLOCK / 64][32];
     __shared__ float tot[32];
-    __shared__ int is_last;
+    __shared__ float sh_pose[8];
+    __shared__ int sh_done;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float R[9], t[3];
+    const int k = tp.pass_index;
+    float pose[7];
+
+    if (k == 0) {
+        /* a new optimize(): the pose is RigidOptimizer::pose_ (kept in st->pose7 between frames) */
 #pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = st->R[i];                          /* RigidPointOptimizer.cpp:53-54 */
+        for (int i = 0; i < 7; ++i) pose[i] = st->pose7[i];
+        if (blockIdx.x == 0 && tid == 0) {
+            gsdf_trk_buf& o = st->trk[0];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) t[i] = st->pose7[i];
+            for (int i = 0; i < 7; ++i) o.pose7[i] = pose[i];
+            o.done = 0; o.converged = 0; o.passes = 0;
+        }
+    } else {
+        /* ---- head: every workgroup reduces the rows of pass k-1 in the same fixed order, solves the
+         * 6x6 system and applies the update -- bit-identical everywhere, so no workgroup has to wait for
+         * another one inside a launch; workgroup 0 publishes the result for the next launch / the host ---- */
+        const gsdf_trk_buf& in = st->trk[(k - 1) & 1];
+        if (in.done) return;                                              /* this optimize() already ended */
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose[i] = in.pose7[i];
+        const int passes = in.passes + 1;
+        const float* prev = rows + (size_t)((k - 1) & 1) * rows_stride;
+        {
+            float r[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) r[i] = 0.f;
+            for (unsigned int b = tid; b < gridDim.x; b += GSDF_TRACK_BLOCK) {
+                const float4* row = reinterpret_cast<const float4*>(prev + (size_t)b * 32);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 v = row[i];
+                    r[4 * i] += v.x; r[4 * i + 1] += v.y; r[4 * i + 2] += v.z; r[4 * i + 3] += v.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < GSDF_TRACK_NSUM; ++i) {
+                const float v = wave_sum(r[i]);
+                if (lane == 0) wsum[wave][i] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < GSDF_TRACK_NSUM) {
+            float v = wsum[0][tid];
+#pragma unroll
+            for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
+            tot[tid] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float gvec[6], Hm[36];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) gvec[i] = tot[1 + i];
+            int q = 7;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = i; j < 6; ++j) { Hm[6 * i + j] = tot[q]; Hm[6 * j + i] = tot[q]; ++q; }
+            float xi[6];
+            gsdf_llt_solve6(Hm, gvec, xi);                                /* RigidPointOptimizer.cpp:86 */
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xi[i] = tp.damping * xi[i];
+            const float nrm = gsdf_sum3(xi[0] * xi[0], xi[1] * xi[1], xi[2] * xi[2]) +
+                              gsdf_sum3(xi[3] * xi[3], xi[4] * xi[4], xi[5] * xi[5]);
+            int done = 0, converged = 0;
+            if (nrm < tp.conv_sq) {                                       /* :88-91 (xi is NOT applied) */
+                converged = 1;
+                done = 1;
+            } else {
+                bool nan = false;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) nan = nan || isnan(xi[i]);
+                if (!nan) {                                               /* :94-95 */
+                    float mxi[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
+                    gsdf_se3_exp_mul(mxi, pose);
+                }
+                if (passes >= tp.max_passes) done = 1;                    /* :98 return false */
+            }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sh_pose[i] = pose[i];
+            sh_done = done;
+            if (blockIdx.x == 0) {
+                gsdf_trk_buf& o = st->trk[k & 1];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) { o.pose7[i] = pose[i]; st->pose7[i] = pose[i]; }
+                o.done = done; o.converged = converged; o.passes = passes;
+                gsdf_quat_to_R(pose + 3, st->R);
+                st->converged = converged;
+                st->passes = passes;
+                st->last_hits = tot[28];
+                st->n_hit += (unsigned long long)tot[28];
+                /* progress for the host's adaptive pass issue (pinned host memory, system scope) */
+                if (tp.progress) {
+                    __hip_atomic_store(&tp.progress[0], (tp.serial << 8) | (unsigned int)passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (done) __hip_atomic_store(&tp.progress[1], tp.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+        __syncthreads();
+        if (sh_done) return;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose[i] = sh_pose[i];
+    }
+    if (k >= tp.max_passes) return;                                       /* head-only launch */
+
+    /* ---- gather + normal-equation sums of pass k with the current pose ---- */
+    float R[9];
+    gsdf_quat_to_R(pose + 3, R);                                          /* RigidPointOptimizer.cpp:53-54 */
+    const float t[3] = { pose[0], pose[1], pose[2] };
     const float fx_inv = 1.f / g.fx, fy_inv = 1.f / g.fy;                 /* :46-47 */
 
     float acc[GSDF_TRACK_NSUM];
@@ -695,6 +801,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
             acc[28] += 1.f;                                               /* :81 */
         }
     }
+    __syncthreads();                                                      /* wsum is reused */
 #pragma unroll
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) {
         const float v = wave_sum(acc[i]);
@@ -708,100 +815,14 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
             for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
         }
-        partials[(size_t)blockIdx.x * 32 + tid] = v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned int tk = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (tk == gridDim.x - 1) ? 1 : 0;
-        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (!is_last) return;
-
-    /* ---- last workgroup: fixed-order sum of the per-workgroup rows, solve, pose update ---- */
-    {
-        float r[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) r[i] = 0.f;
-        for (unsigned int b = tid; b < gridDim.x; b += GSDF_TRACK_BLOCK) {
-            const float4* row = reinterpret_cast<const float4*>(partials + (size_t)b * 32);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 v = row[i];
-                r[4 * i] += v.x; r[4 * i + 1] += v.y; r[4 * i + 2] += v.z; r[4 * i + 3] += v.w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < GSDF_TRACK_NSUM; ++i) {
-            const float v = wave_sum(r[i]);
-            if (lane == 0) wsum[wave][i] = v;
-        }
-    }
-    __syncthreads();
-    if (tid < GSDF_TRACK_NSUM) {
-        float v = wsum[0][tid];
-#pragma unroll
-        for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
-        tot[tid] = v;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float gvec[6], Hm[36];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) gvec[i] = tot[1 + i];
-        int q = 7;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = i; j < 6; ++j) { Hm[6 * i + j] = tot[q]; Hm[6 * j + i] = tot[q]; ++q; }
-        float xi[6];
-        gsdf_llt_solve6(Hm, gvec, xi);                                    /* :86 */
-#pragma unroll
-        for (int i = 0; i < 6; ++i) xi[i] = tp.damping * xi[i];
-        const float nrm = gsdf_sum3(xi[0] * xi[0], xi[1] * xi[1], xi[2] * xi[2]) +
-                          gsdf_sum3(xi[3] * xi[3], xi[4] * xi[4], xi[5] * xi[5]);
-        const int passes = (tp.pass_index == 0 ? 0 : st->passes) + 1;
-        st->passes = passes;
-        st->last_hits = tot[28];
-        st->n_hit += (unsigned long long)tot[28];
-        int done = 0;
-        if (nrm < tp.conv_sq) {                                           /* :88-91 (xi is NOT applied) */
-            st->converged = 1;
-            done = 1;
-        } else {
-            st->converged = 0;
-            bool nan = false;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) nan = nan || isnan(xi[i]);
-            if (!nan) {                                                   /* :94-95 */
-                float mxi[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
-                float pose[7];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) pose[i] = st->pose7[i];
-                gsdf_se3_exp_mul(mxi, pose);
-#pragma unroll
-                for (int i = 0; i < 7; ++i) st->pose7[i] = pose[i];
-                gsdf_quat_to_R(pose + 3, st->R);
-            }
-            if (passes >= tp.max_passes) done = 1;                        /* :98 return false */
-        }
-        st->done = done;
-        st->ticket = 0u;
-        /* progress for the host's adaptive pass issue (pinned host memory, system scope) */
-        if (tp.progress) {
-            __hip_atomic_store(&tp.progress[0], (tp.serial << 8) | (unsigned int)passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (done) __hip_atomic_store(&tp.progress[1], tp.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        rows[(size_t)(k & 1) * rows_stride + (size_t)blockIdx.x * 32 + tid] = v;   /* read by the next launch's head */
     }
 }
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
                             gsdf_dev_state* st, float* partials, int n_blocks, const gsdf_track_params& tp) {
-    hipLaunchKernelGGL(k_track_pass, dim3(n_blocks), dim3(GSDF_TRACK_BLOCK), 0, s, g, depth, tab, st, partials, tp);
+    /* partials holds two row sets (pass parity): a launch reads the previous set while writing its own */
+    hipLaunchKernelGGL(k_track_pass, dim3(n_blocks), dim3(GSDF_TRACK_BLOCK), 0, s, g, depth, tab, st, partials,
+                       n_blocks * 32, tp);
 }
 
 struct pose7_arg { float p[7]; };
