@@ -616,30 +616,30 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
         /* ---- head: every workgroup reduces the rows of pass k-1 in the same fixed order, solves the
          * 6x6 system and applies the update -- bit-identical everywhere, so no workgroup has to wait for
          * another one inside a launch; workgroup 0 publishes the result for the next launch / the host ---- */
+        /* the row reads do not depend on the state words: issue them first so that both memory round
+         * trips overlap (a launch that finds `done` set wasted 16 loads per lane, and is rare) */
+        const float* prev = rows + (size_t)((k - 1) & 1) * rows_stride;
+        const int r8 = lane >> 3, c4 = lane & 7;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        /* coalesced: 8 lanes read one 128-byte row (16 B each), a wave reads 8 rows per instruction;
+         * lane (r8, c4) accumulates columns 4*c4..4*c4+3 over its rows in increasing order */
+        for (unsigned int b = (unsigned int)(wave * 8 + r8); b < gridDim.x; b += 8 * (GSDF_TRACK_BLOCK / 64)) {
+            const float4 v = *reinterpret_cast<const float4*>(prev + (size_t)b * 32 + 4 * c4);
+            a4.x += v.x; a4.y += v.y; a4.z += v.z; a4.w += v.w;
+        }
         const gsdf_trk_buf& in = st->trk[(k - 1) & 1];
-        if (in.done) return;                                              /* this optimize() already ended */
+        const int in_done = in.done;
 #pragma unroll
         for (int i = 0; i < 7; ++i) pose[i] = in.pose7[i];
         const int passes = in.passes + 1;
-        const float* prev = rows + (size_t)((k - 1) & 1) * rows_stride;
-        {
-            float r[32];
+        if (in_done) return;                                              /* this optimize() already ended */
+        /* the 8 row groups of a wave are combined with xor shuffles, the 4 waves through LDS */
 #pragma unroll
-            for (int i = 0; i < 32; ++i) r[i] = 0.f;
-            for (unsigned int b = tid; b < gridDim.x; b += GSDF_TRACK_BLOCK) {
-                const float4* row = reinterpret_cast<const float4*>(prev + (size_t)b * 32);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float4 v = row[i];
-                    r[4 * i] += v.x; r[4 * i + 1] += v.y; r[4 * i + 2] += v.z; r[4 * i + 3] += v.w;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < GSDF_TRACK_NSUM; ++i) {
-                const float v = wave_sum(r[i]);
-                if (lane == 0) wsum[wave][i] = v;
-            }
+        for (int m = 8; m < 64; m <<= 1) {
+            a4.x += __shfl_xor(a4.x, m); a4.y += __shfl_xor(a4.y, m);
+            a4.z += __shfl_xor(a4.z, m); a4.w += __shfl_xor(a4.w, m);
         }
+        if (r8 == 0) { wsum[wave][4 * c4] = a4.x; wsum[wave][4 * c4 + 1] = a4.y; wsum[wave][4 * c4 + 2] = a4.z; wsum[wave][4 * c4 + 3] = a4.w; }
         __syncthreads();
         if (tid < GSDF_TRACK_NSUM) {
             float v = wsum[0][tid];
