@@ -179,3 +179,67 @@ def test_query_is_first_order_taylor(O, pkg):
     assert np.abs(d2 - (d - g @ off)).max() < 1e-6
     dm, gm, wm = o.query(np.array([[50.0, 50.0, 50.0]], np.float32))
     assert wm[0] == 0 and dm[0] == 0
+
+
+def test_se3_exp_matches_matrix_exponential(O):
+    """The restated Sophus SE3::exp / group product against scipy's expm of the 4x4 twist matrix
+    (independent float64 check of the third-party arithmetic the oracle has to restate)."""
+    from scipy.linalg import expm
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(5)
+    for scale in (1e-6, 1e-3, 0.05, 0.7, 2.5):
+        xi = (scale * rng.standard_normal(6)).astype(np.float32)
+        q0 = rng.standard_normal(4)
+        q0 /= np.linalg.norm(q0)
+        t0 = rng.uniform(-2, 2, 3)
+        pose = np.concatenate([t0, q0]).astype(np.float32)
+        got = O.se3_exp_mul(xi, pose)
+        M = np.zeros((4, 4))
+        w = xi[3:].astype(np.float64)
+        M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+        M[:3, 3] = xi[:3]
+        T0 = np.eye(4)
+        T0[:3, :3] = Rotation.from_quat(pose[3:].astype(np.float64)).as_matrix()
+        T0[:3, 3] = pose[:3]
+        T = expm(M) @ T0
+        Rg = O.quat_to_R(got[3:]).astype(np.float64)
+        assert np.abs(Rg - T[:3, :3]).max() < 5e-6
+        assert np.abs(got[:3] - T[:3, 3]).max() < 5e-6 * max(1.0, np.abs(T[:3, 3]).max())
+        assert abs(np.linalg.norm(got[3:]) - 1) < 1e-6
+
+
+def test_quaternion_conversions_match_scipy(O):
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(6)
+    for _ in range(50):
+        q = rng.standard_normal(4)
+        q /= np.linalg.norm(q)
+        R = O.quat_to_R(q.astype(np.float32))
+        assert np.abs(R - Rotation.from_quat(q).as_matrix()).max() < 1e-6
+        q2 = O.R_to_quat(R)
+        assert min(np.abs(q2 - q).max(), np.abs(q2 + q).max()) < 1e-6      # q and -q are the same rotation
+
+
+def test_tracker_step_solves_the_normal_equations(O, pkg):
+    """trace rows expose E, g, H, xi of every pass: xi must be damping * H^-1 g (Eigen LLT restated) and
+    H symmetric positive definite."""
+    W, H = 320, 240
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=2, seed=0, noise=False)
+    o = O.Oracle(VS, T10, W, H, seq.K)
+    d, R, t = seq.frame(0)
+    o.update(d, R, t)
+    d1, R1, t1 = seq.frame(1)
+    conv, p, used, trace, hits = o.track(d1, pose7_from(O, R, t), iters=3)
+    for row in trace:
+        g = row[1:7].astype(np.float64)
+        Hm = np.zeros((6, 6))
+        q = 7
+        for i in range(6):
+            for j in range(i, 6):
+                Hm[i, j] = Hm[j, i] = row[q]
+                q += 1
+        assert np.all(np.linalg.eigvalsh(Hm) > 0)
+        xi = np.linalg.solve(Hm, g)
+        assert np.abs(row[29:35] - xi).max() <= 2e-3 * max(1e-6, np.abs(xi).max())
+        assert row[35] == pytest.approx(float((row[29:35].astype(np.float64) ** 2).sum()), rel=1e-5)
+        assert row[28] == hits[0] or row[28] > 0
