@@ -92,6 +92,8 @@ def load():
         "gsdf_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
         "gsdf_count": (C.c_int, [vp, i64p]),
         "gsdf_export": (C.c_int, [vp, i32p, fp, C.c_int64, i64p, C.c_int, C.c_int]),
+        "gsdf_enable_vis": (C.c_int, [vp, C.c_int]),
+        "gsdf_export_vis": (C.c_int, [vp, i32p, C.POINTER(C.c_uint32), C.c_int, C.c_int64, i64p]),
         "gsdf_merge_raw": (C.c_int, [vp, i32p, fp, C.c_int64]),
         "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
@@ -116,7 +118,8 @@ ABI_SYMBOLS = [
     "gsdf_last_error", "gsdf_version", "gsdf_create", "gsdf_destroy", "gsdf_reset", "gsdf_set_zrange",
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
     "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
-    "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_merge_raw", "gsdf_export_raw_dev",
+    "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
+    "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_query",
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_timer_start", "gsdf_timer_stop_ms",
     "gsdf_profile", "gsdf_profile_read",
@@ -253,6 +256,20 @@ class GradSdf:
             self._chk(self.L.gsdf_export(self.h, keys.ctypes.data_as(C.POINTER(C.c_int32)), _fp(pay), n,
                                          C.byref(got), int(sorted), int(raw)))
         return keys, pay
+
+    def enable_vis(self, max_frames):
+        self._vis_words = (int(max_frames) + 31) // 32
+        self._chk(self.L.gsdf_enable_vis(self.h, int(max_frames)))
+
+    def export_vis(self):
+        n = self.count()
+        keys = np.empty((n, 3), np.int32)
+        words = np.zeros((n, self._vis_words), np.uint32)
+        got = C.c_int64(0)
+        if n:
+            self._chk(self.L.gsdf_export_vis(self.h, keys.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             words.ctypes.data_as(C.POINTER(C.c_uint32)), self._vis_words, n, C.byref(got)))
+        return keys, words
 
     def merge_raw(self, keys, payload_raw):
         k = np.ascontiguousarray(keys, np.int32).reshape(-1, 3)

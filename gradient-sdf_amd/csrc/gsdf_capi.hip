@@ -61,6 +61,8 @@ struct gsdf_ctx {
     unsigned int* deferred_count = nullptr;
     unsigned int deferred_cap = 0;
     unsigned int fuse_tag = 0;                     /* ownership tag of the last fusion launch */
+    uint32_t* vis = nullptr;                       /* optional vis_ bit-vectors, n_slots x vis_words */
+    int vis_words = 0;
     unsigned int track_serial = 0;                 /* optimize() call counter */
     volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */
     unsigned int* progress_dev = nullptr;
@@ -148,7 +150,7 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
     {
         prof_scope ps(c, 0);
         gsdf_launch_normals(c->stream, g, c->win, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N,
-                            use_dev_pose ? c->st : nullptr, c->deferred_count);
+                            use_dev_pose ? c->st : nullptr, c->deferred_count, c->st);
     }
     {
         prof_scope ps(c, 1);
@@ -156,7 +158,7 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
         if (c->fuse_tag == 0) c->fuse_tag = 1;
         gsdf_launch_fuse(c->stream, g, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N, pose,
                          use_dev_pose, c->tab, c->st, c->blk_counters, c->deferred, c->deferred_count,
-                         c->deferred_cap, c->fuse_tag, c->frame_log, c->frame_log_cap);
+                         c->deferred_cap, c->fuse_tag, c->frame_log, c->frame_log_cap, c->vis, c->vis_words);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
@@ -281,7 +283,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     void* ptrs[] = { c->tab.buckets, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
-                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count };
+                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->vis };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->progress) (void)hipHostFree((void*)c->progress);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -294,6 +296,7 @@ int gsdf_reset(gsdf_ctx* c) {
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     gsdf_launch_table_clear(c->stream, c->tab, c->n_slots);
+    if (c->vis) HIP_TRY(hipMemsetAsync(c->vis, 0, c->n_slots * (size_t)c->vis_words * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->st, 0, sizeof(gsdf_dev_state), c->stream));
     const float ident[7] = { 0, 0, 0, 0, 0, 0, 1 };          /* pose_ = SE3() -- RigidOptimizer.h:64 */
     gsdf_launch_set_pose(c->stream, c->st, nullptr, ident);
@@ -361,7 +364,7 @@ int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float*
     const size_t N = (size_t)c->W * c->H;
     HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), c->depth_stage, c->normals, c->normals + N,
-                        c->normals + 2 * N, nullptr, nullptr);
+                        c->normals + 2 * N, nullptr, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(nx, c->normals, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(ny, c->normals + N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -502,7 +505,7 @@ int gsdf_count(gsdf_ctx* c, int64_t* n) {
     if (!c || !n) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
-    gsdf_launch_export(c->stream, c->tab, c->n_slots, nullptr, nullptr, c->counter, 0, 0);
+    gsdf_launch_export(c->stream, c->tab, c->n_slots, nullptr, nullptr, c->counter, 0, 0, nullptr, 0, nullptr);
     unsigned long long h = 0;
     HIP_TRY(hipMemcpyAsync(&h, c->counter, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -510,29 +513,66 @@ int gsdf_count(gsdf_ctx* c, int64_t* n) {
     return GSDF_OK;
 }
 
+static int export_impl(gsdf_ctx* c, int32_t* keys, float* payload, uint32_t* vis_words_out, int64_t max_n, int64_t* n_out,
+                       int sorted, int raw_sums);
+
 int gsdf_export(gsdf_ctx* c, int32_t* keys, float* payload, int64_t max_n, int64_t* n_out, int sorted, int raw_sums) {
+    return export_impl(c, keys, payload, nullptr, max_n, n_out, sorted, raw_sums);
+}
+
+int gsdf_enable_vis(gsdf_ctx* c, int max_frames) {
+    if (!c || max_frames <= 0) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->vis) { (void)hipFree(c->vis); c->vis = nullptr; }
+    c->vis_words = (max_frames + 31) / 32;
+    const size_t bytes = c->n_slots * (size_t)c->vis_words * sizeof(uint32_t);
+    HIP_TRY(hipMalloc((void**)&c->vis, bytes));
+    HIP_TRY(hipMemsetAsync(c->vis, 0, bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+
+int gsdf_export_vis(gsdf_ctx* c, int32_t* keys, uint32_t* words, int words_per_voxel, int64_t max_n, int64_t* n_out) {
+    if (!c || !words) return fail(GSDF_ERR_INVALID, "null argument");
+    if (!c->vis) return fail(GSDF_ERR_INVALID, "gsdf_enable_vis was not called");
+    if (words_per_voxel != c->vis_words) return fail(GSDF_ERR_INVALID, "words_per_voxel differs from gsdf_enable_vis");
+    return export_impl(c, keys, nullptr, words, max_n, n_out, 1, 0);
+}
+
+static int export_impl(gsdf_ctx* c, int32_t* keys, float* payload, uint32_t* vis_words_out, int64_t max_n, int64_t* n_out,
+                       int sorted, int raw_sums) {
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     int64_t n = 0;
     int rc = gsdf_count(c, &n);
     if (rc) return rc;
     if (n_out) *n_out = n;
-    if (n == 0 || max_n <= 0 || (!keys && !payload)) return GSDF_OK;
+    if (n == 0 || max_n <= 0 || (!keys && !payload && !vis_words_out)) return GSDF_OK;
     if (max_n < n) return fail(GSDF_ERR_INVALID, "export buffer too small (call gsdf_count first)");
     unsigned long long* dkeys = nullptr;
     float* dpay = nullptr;
     HIP_TRY(hipMalloc((void**)&dkeys, (size_t)n * sizeof(unsigned long long)));
     hipError_t e = hipMalloc((void**)&dpay, (size_t)n * 5 * sizeof(float));
     if (e != hipSuccess) { (void)hipFree(dkeys); return fail(GSDF_ERR_HIP, hipGetErrorString(e)); }
+    uint32_t* dvis = nullptr;
+    const int vw = vis_words_out ? c->vis_words : 0;
+    if (vw) {
+        e = hipMalloc((void**)&dvis, (size_t)n * vw * sizeof(uint32_t));
+        if (e != hipSuccess) { (void)hipFree(dkeys); (void)hipFree(dpay); return fail(GSDF_ERR_HIP, hipGetErrorString(e)); }
+    }
     (void)hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream);
-    gsdf_launch_export(c->stream, c->tab, c->n_slots, dkeys, dpay, c->counter, n, raw_sums);
+    gsdf_launch_export(c->stream, c->tab, c->n_slots, dkeys, dpay, c->counter, n, raw_sums, c->vis, vw, dvis);
     std::vector<unsigned long long> hk((size_t)n);
     std::vector<float> hp((size_t)n * 5);
+    std::vector<uint32_t> hv((size_t)n * vw);
     e = hipMemcpyAsync(hk.data(), dkeys, hk.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hp.data(), dpay, hp.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && vw) e = hipMemcpyAsync(hv.data(), dvis, hv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(dkeys);
     (void)hipFree(dpay);
+    if (dvis) (void)hipFree(dvis);
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
     std::vector<size_t> order((size_t)n);
     std::iota(order.begin(), order.end(), (size_t)0);
@@ -546,6 +586,7 @@ int gsdf_export(gsdf_ctx* c, int32_t* keys, float* payload, int64_t max_n, int64
             keys[3 * i] = x; keys[3 * i + 1] = y; keys[3 * i + 2] = z;
         }
         if (payload) std::memcpy(payload + 5 * i, hp.data() + 5 * j, 5 * sizeof(float));
+        if (vis_words_out) std::memcpy(vis_words_out + (size_t)vw * i, hv.data() + (size_t)vw * j, vw * sizeof(uint32_t));
     }
     return GSDF_OK;
 }

@@ -39,6 +39,7 @@ struct gsdf_dev_state {
     unsigned long long n_upd, n_valid, n_hit, n_occupied;
     long long frames;             /* Sdf::counter_ */
     long long log_rows;
+    long long frame_cur;          /* counter_ snapshot for the running update (k_normals -> k_fuse) */
     gsdf_trk_buf trk[2];
 };
 
@@ -68,7 +69,8 @@ void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int 
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
                          const float* depth, float* nx, float* ny, float* nz,
                          const gsdf_dev_state* gate /* nullable: skip unless converged */,
-                         unsigned int* deferred_count /* nullable: cleared for the k_fuse that follows */);
+                         unsigned int* deferred_count /* nullable: cleared for the k_fuse that follows */,
+                         gsdf_dev_state* st_rw /* nullable: snapshot of the frame counter for k_fuse */);
 /* use_dev_pose: take R,t from st->R / st->pose7 and skip the launch unless st->converged */
 void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
                       const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
@@ -76,7 +78,8 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       unsigned long long* blk_counters /* [gsdf_fuse_grid_blocks][4] */,
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
                       unsigned int tag /* ownership tag, unique per launch, never 0 */,
-                      float* log_rows /* nullable: frame log, written when use_dev_pose */, long long max_rows);
+                      float* log_rows /* nullable: frame log, written when use_dev_pose */, long long max_rows,
+                      uint32_t* vis /* nullable: per-voxel frame bit-vectors */, int vis_words);
 int  gsdf_fuse_grid_blocks(int W, int H);
 /* per-launch parameters of one Gauss-Newton pass (RigidOptimizer.h:57-62) */
 struct gsdf_track_params {
@@ -91,7 +94,8 @@ void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float
 void gsdf_launch_set_pose(hipStream_t s, gsdf_dev_state* st, const float* pose7_dev_or_null,
                           const float pose7_host[7]);
 void gsdf_launch_export(hipStream_t s, gsdf_table tab, size_t n_slots, unsigned long long* keys_out,
-                        float* payload_out, unsigned long long* counter, long long max_n, int raw);
+                        float* payload_out, unsigned long long* counter, long long max_n, int raw,
+                        const uint32_t* vis, int vis_words, uint32_t* vis_out);
 void gsdf_launch_export_raw(hipStream_t s, gsdf_table tab, size_t n_slots, int32_t* keys_out, float* payload_out,
                             unsigned long long* counter, long long max_n);
 void gsdf_launch_merge_raw(hipStream_t s, gsdf_table tab, const int32_t* keys, const float* payload,

@@ -128,9 +128,13 @@ void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int 
 __global__ __launch_bounds__(256) void k_normals(gsdf_frame_geom g, int r, gsdf_ncache nc,
                                                  const float* __restrict__ depth, float* __restrict__ nx,
                                                  float* __restrict__ ny, float* __restrict__ nz,
-                                                 const gsdf_dev_state* gate, unsigned int* deferred_count) {
+                                                 const gsdf_dev_state* gate, unsigned int* deferred_count,
+                                                 gsdf_dev_state* st_rw) {
     if (gate && !gate->converged) return;
-    if (deferred_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *deferred_count = 0u;   /* fresh list for k_fuse */
+    if (deferred_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        *deferred_count = 0u;                                  /* fresh list for k_fuse */
+        if (st_rw) st_rw->frame_cur = st_rw->frames;           /* counter_ seen by every workgroup of k_fuse */
+    }
     __shared__ float prod[3][NRM_TY + 2 * NRM_RMAX][NRM_TX + 2 * NRM_RMAX + 1];
     __shared__ double rows[3][NRM_TY + 2 * NRM_RMAX][NRM_TX];
     const int W = g.W, H = g.H;
@@ -179,9 +183,9 @@ __global__ __launch_bounds__(256) void k_normals(gsdf_frame_geom g, int r, gsdf_
 }
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
                          const float* depth, float* nx, float* ny, float* nz, const gsdf_dev_state* gate,
-                         unsigned int* deferred_count) {
+                         unsigned int* deferred_count, gsdf_dev_state* st_rw) {
     dim3 grid((g.W + NRM_TX - 1) / NRM_TX, (g.H + NRM_TY - 1) / NRM_TY);
-    hipLaunchKernelGGL(k_normals, grid, dim3(256), 0, s, g, win / 2, nc, depth, nx, ny, nz, gate, deferred_count);
+    hipLaunchKernelGGL(k_normals, grid, dim3(256), 0, s, g, win / 2, nc, depth, nx, ny, nz, gate, deferred_count, st_rw);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -232,6 +236,8 @@ struct fuse_args {
     unsigned int* deferred_count;
     unsigned int deferred_cap;
     unsigned int tag;                   /* ownership tag of this launch = frame serial, never 0 */
+    uint32_t* vis;                      /* optional per-voxel frame bit-vectors (vis_, MapGradPixelSdf.h:70); nullable */
+    int vis_words;
     int debug;                          /* experiment switches (gsdf_debug_flags); 0 in production */
 };
 
@@ -277,6 +283,14 @@ __device__ __forceinline__ void defer_append(const fuse_args& a, gsdf_payload* p
     a.deferred[i] = d;
 }
 
+/* vis_[vi]: resize(counter_), push_back(true) -- MapGradPixelSdf.cpp:113-115: set bit `frame` of the voxel */
+__device__ __forceinline__ void vis_mark(const fuse_args& a, const gsdf_payload* p, long long frame) {
+    if (!a.vis || frame >= 32ll * a.vis_words) return;
+    const size_t off = (size_t)((const char*)p - (const char*)a.tab.buckets);
+    const size_t slot = (off >> 7) * GSDF_BUCKET + ((off & 127) - 32) / sizeof(gsdf_payload);
+    atomicOr(&a.vis[slot * a.vis_words + (frame >> 5)], 1u << (frame & 31));
+}
+
 int g_fuse_debug = 0;
 __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
     __shared__ fuse_lds L;
@@ -302,6 +316,7 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
     __syncthreads();
 
     const gsdf_frame_geom& g = a.g;
+    const long long frame_cur = a.vis ? a.st->frame_cur : 0;   /* Sdf::counter_ of this update (snapshot by k_normals) */
     const int wave = tid >> 6, lane = tid & 63;
     const int lx = lane & 7, ly = lane >> 3;
     const int px = blockIdx.x * FUSE_T + (wave & 1) * 8 + lx;
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
                     /* LDS table full for this voxel: contribute through the deferred list */
                     gsdf_payload* p = gsdf_find_or_insert(a.tab, key[j]);
                     if (!p) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
-                    else defer_append(a, p, f[j][0], f[j][1], f[j][2], f[j][3], f[j][4]);
+                    else { defer_append(a, p, f[j][0], f[j][1], f[j][2], f[j][3], f[j][4]); vis_mark(a, p, frame_cur); }
                 }
             }
         }
@@ -486,6 +501,7 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
                 gxy[e].x += fix2f(L.gx[i]); gxy[e].y += fix2f(L.gy[i]);
                 gzv[e] += fix2f(L.gz[i]);
                 q2[0] = ws[e]; q2[1] = gxy[e]; P[e]->gz = gzv[e];
+                vis_mark(a, P[e], frame_cur);                 /* exactly one owner per touched voxel and launch */
                 L.key[i] = GSDF_KEY_EMPTY;
             } else {
                 /* another tile owns the voxel: keep the entry, remember where it goes */
@@ -557,8 +573,9 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
                       int use_dev_pose, gsdf_table tab, gsdf_dev_state* st, unsigned long long* blk_counters,
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
-                      unsigned int tag, float* log_rows, long long max_rows) {
+                      unsigned int tag, float* log_rows, long long max_rows, uint32_t* vis, int vis_words) {
     fuse_args a;
+    a.vis = vis; a.vis_words = vis_words;
     a.debug = g_fuse_debug;
     a.g = g; a.nc = nc; a.depth = depth; a.nx = nx; a.ny = ny; a.nz = nz; a.pose = pose;
     a.use_dev_pose = use_dev_pose; a.tab = tab; a.st = st; a.blk_counters = blk_counters;
@@ -843,7 +860,7 @@ void gsdf_launch_set_pose(hipStream_t s, gsdf_dev_state* st, const float*, const
  * ---------------------------------------------------------------------------------------------- */
 __global__ __launch_bounds__(256) void k_export(gsdf_table tab, size_t n_slots, unsigned long long* keys_out,
                                                 float* payload_out, unsigned long long* counter, long long max_n,
-                                                int raw) {
+                                                int raw, const uint32_t* vis, int vis_words, uint32_t* vis_out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n_slots; i += stride) {
@@ -859,11 +876,15 @@ __global__ __launch_bounds__(256) void k_export(gsdf_table tab, size_t n_slots, 
             if (raw) { p[0] = sl.s; p[1] = sl.gx; p[2] = sl.gy; p[3] = sl.gz; p[4] = sl.w; }
             else     { p[0] = sl.s / sl.w; p[1] = sl.gx; p[2] = sl.gy; p[3] = sl.gz; p[4] = sl.w; }
         }
+        if (vis_out && vis)
+            for (int w = 0; w < vis_words; ++w) vis_out[o * vis_words + w] = vis[i * vis_words + w];
     }
 }
 void gsdf_launch_export(hipStream_t s, gsdf_table tab, size_t n_slots, unsigned long long* keys_out,
-                        float* payload_out, unsigned long long* counter, long long max_n, int raw) {
-    hipLaunchKernelGGL(k_export, dim3(2048), dim3(256), 0, s, tab, n_slots, keys_out, payload_out, counter, max_n, raw);
+                        float* payload_out, unsigned long long* counter, long long max_n, int raw,
+                        const uint32_t* vis, int vis_words, uint32_t* vis_out) {
+    hipLaunchKernelGGL(k_export, dim3(2048), dim3(256), 0, s, tab, n_slots, keys_out, payload_out, counter, max_n, raw,
+                       vis, vis_words, vis_out);
 }
 
 __global__ __launch_bounds__(256) void k_merge_raw(gsdf_table tab, const int32_t* keys, const float* payload,

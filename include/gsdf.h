@@ -114,6 +114,15 @@ int gsdf_count(gsdf_ctx* c, int64_t* n);
  * (sum w*d, sum w*Rn, sum w) instead of (dist, grad, weight) -- the merge wire format. */
 int gsdf_export(gsdf_ctx* c, int32_t* keys, float* payload, int64_t max_n, int64_t* n,
                 int sorted, int raw_sums);
+/* vis_ -- MapGradPixelSdf.h:70, MapGradPixelSdf.cpp:113-115: per voxel, bit f set <=> the voxel was updated by
+ * integrated frame f (f = Sdf::counter_ at the time).  The reference always maintains it (PhotoBA reads it
+ * through get_vis(), MapGradPixelSdf.h:140-142); here it is opt-in because it costs one more atomic per
+ * touched voxel: call gsdf_enable_vis once (before fusing) with the number of frames to keep.
+ * gsdf_export_vis returns ceil(max_frames/32) uint32 words per voxel, rows in the (z,y,x) order of
+ * gsdf_export(sorted=1); keys may be NULL. */
+int gsdf_enable_vis(gsdf_ctx* c, int max_frames);
+int gsdf_export_vis(gsdf_ctx* c, int32_t* keys, uint32_t* words, int words_per_voxel, int64_t max_n, int64_t* n);
+
 /* additive merge of raw sums into this table (frame-sharded fusion) */
 int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, int64_t n);
 

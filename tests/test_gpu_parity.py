@@ -274,3 +274,20 @@ def test_fusion_keys_bit_exact_random_poses(pkg, O, seed):
         o.update(d, R, t)
     _cmp_tables(g, o)
     g.close()
+
+
+def test_vis_bitvectors_match_oracle(pkg, O):
+    """vis_ (MapGradPixelSdf.cpp:113-115): bit f of a voxel <=> it was updated by integrated frame f."""
+    seq, g, o = _mk(pkg, O, n=5, cap=19, step_deg=4.0)
+    g.enable_vis(40)
+    for i in range(seq.n):
+        d, R, t = seq.frame(i)
+        g.update(d, R, t)
+        o.update(d, R, t)
+    kg, vg = g.export_vis()
+    ko, _ = o.export()
+    vo = o.export_vis(2)
+    assert np.array_equal(kg, ko)
+    assert np.array_equal(vg, vo)
+    assert (vg[:, 0] > 0).all() and vg[:, 1].max() == 0 and int(vg[:, 0].max()) < (1 << seq.n)
+    g.close()
