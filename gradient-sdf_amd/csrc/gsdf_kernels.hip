@@ -37,6 +37,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+/* wave-64 sums of N values at once: every DPP stage is applied to all N values before the next stage, so
+ * the N dependency chains interleave instead of stalling on each other; lane 63 ends up with the totals */
+template <int N>
+__device__ __forceinline__ void wave_sum_to_lane63(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x111, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x112, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x114, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x118, 0xf>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x142, 0xa>(v[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x143, 0xc>(v[i]);
+}
+
 __device__ __forceinline__ int reflect101(int i, int n) {      /* cv::BORDER_REFLECT_101 */
     if (n == 1) return 0;
     while (i < 0 || i >= n) {
@@ -819,10 +837,10 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
         }
     }
     __syncthreads();                                                      /* wsum is reused */
+    wave_sum_to_lane63(acc);
+    if (lane == 63) {
 #pragma unroll
-    for (int i = 0; i < GSDF_TRACK_NSUM; ++i) {
-        const float v = wave_sum(acc[i]);
-        if (lane == 0) wsum[wave][i] = v;
+        for (int i = 0; i < GSDF_TRACK_NSUM; ++i) wsum[wave][i] = acc[i];
     }
     __syncthreads();
     if (tid < 32) {
