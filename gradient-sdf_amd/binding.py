@@ -94,6 +94,12 @@ def load():
         "gsdf_export": (C.c_int, [vp, i32p, fp, C.c_int64, i64p, C.c_int, C.c_int]),
         "gsdf_enable_vis": (C.c_int, [vp, C.c_int]),
         "gsdf_export_vis": (C.c_int, [vp, i32p, C.POINTER(C.c_uint32), C.c_int, C.c_int64, i64p]),
+        "gsdf_ba_setup": (C.c_int, [vp, C.c_int, fp, fp, C.POINTER(C.c_int), C.c_float]),
+        "gsdf_ba_energy": (C.c_int, [vp, fp]),
+        "gsdf_ba_solve_pose": (C.c_int, [vp, C.c_float]),
+        "gsdf_ba_solve_dist": (C.c_int, [vp, C.c_float]),
+        "gsdf_ba_optimize": (C.c_int, [vp, C.c_int, fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "gsdf_ba_get_poses": (C.c_int, [vp, fp]),
         "gsdf_merge_raw": (C.c_int, [vp, i32p, fp, C.c_int64]),
         "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
@@ -119,6 +125,7 @@ ABI_SYMBOLS = [
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
     "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
+    "gsdf_ba_setup", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_query",
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_timer_start", "gsdf_timer_stop_ms",
@@ -270,6 +277,37 @@ class GradSdf:
             self._chk(self.L.gsdf_export_vis(self.h, keys.ctypes.data_as(C.POINTER(C.c_int32)),
                                              words.ctypes.data_as(C.POINTER(C.c_uint32)), self._vis_words, n, C.byref(got)))
         return keys, words
+
+    # -- PhotoBA (PhotometricOptimizer) ----------------------------------------------------------
+    def ba_setup(self, images_bgr, poses16, frame_idx, reg_weight=10.0):
+        img = _f32(images_bgr)
+        self._ba_n = img.shape[0]
+        P = _f32(poses16).reshape(self._ba_n, 16)
+        idx = np.ascontiguousarray(frame_idx, dtype=np.int32)
+        self._chk(self.L.gsdf_ba_setup(self.h, self._ba_n, _fp(img), _fp(P), idx.ctypes.data_as(C.POINTER(C.c_int)),
+                                       np.float32(reg_weight)))
+
+    def ba_energy(self):
+        e = C.c_float(0)
+        self._chk(self.L.gsdf_ba_energy(self.h, C.byref(e)))
+        return e.value
+
+    def ba_solve_pose(self, damping=1.0):
+        self._chk(self.L.gsdf_ba_solve_pose(self.h, np.float32(damping)))
+
+    def ba_solve_dist(self, damping=1.0):
+        self._chk(self.L.gsdf_ba_solve_dist(self.h, np.float32(damping)))
+
+    def ba_optimize(self, max_it=25):
+        e = np.zeros(2 * max_it + 1, np.float32)
+        ne, conv = C.c_int(0), C.c_int(0)
+        self._chk(self.L.gsdf_ba_optimize(self.h, int(max_it), _fp(e), C.byref(ne), C.byref(conv)))
+        return bool(conv.value), e[:ne.value]
+
+    def ba_poses(self):
+        P = np.zeros((self._ba_n, 16), np.float32)
+        self._chk(self.L.gsdf_ba_get_poses(self.h, _fp(P)))
+        return P.reshape(self._ba_n, 4, 4)
 
     def merge_raw(self, keys, payload_raw):
         k = np.ascontiguousarray(keys, np.int32).reshape(-1, 3)

@@ -63,6 +63,16 @@ struct gsdf_ctx {
     unsigned int fuse_tag = 0;                     /* ownership tag of the last fusion launch */
     uint32_t* vis = nullptr;                       /* optional vis_ bit-vectors, n_slots x vis_words */
     int vis_words = 0;
+    /* PhotoBA (PhotometricOptimizer) */
+    int ba_n = 0;
+    float ba_reg = 10.f;
+    float* ba_images = nullptr;
+    float* ba_Rt = nullptr;                        /* device: n x 9 rotations then n x 3 translations */
+    int* ba_frame_idx = nullptr;
+    double* ba_block_E = nullptr;
+    float* ba_block_part = nullptr;
+    float* ba_Hb = nullptr;
+    std::vector<float> ba_R, ba_t;                 /* host copies of the keyframe poses being optimised */
     unsigned int track_serial = 0;                 /* optimize() call counter */
     volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */
     unsigned int* progress_dev = nullptr;
@@ -283,7 +293,8 @@ void gsdf_destroy(gsdf_ctx* c) {
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     void* ptrs[] = { c->tab.buckets, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
-                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->vis };
+                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->vis, c->ba_images, c->ba_Rt,
+                     c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->progress) (void)hipHostFree((void*)c->progress);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -632,6 +643,151 @@ int gsdf_merge_raw_dev(gsdf_ctx* c, const int32_t* keys_dev, const float* payloa
     gsdf_launch_merge_raw(c->stream, c->tab, keys_dev, payload_raw_dev, n, c->st);
     HIP_TRY(hipGetLastError());
     return gsdf_sync(c);
+}
+
+/* ---- PhotoBA: PhotometricOptimizer (ps_optimizer/PhotometricOptimizer.cpp) ------------------------------- */
+static gsdf_ba_dev ba_dev(gsdf_ctx* c) {
+    gsdf_ba_dev d;
+    d.tab = c->tab; d.n_slots = c->n_slots; d.vis = c->vis; d.vis_words = c->vis_words;
+    d.n = c->ba_n; d.W = c->W; d.H = c->H;
+    d.images = c->ba_images; d.R = c->ba_Rt; d.t = c->ba_Rt + 9 * (size_t)c->ba_n; d.frame_idx = c->ba_frame_idx;
+    d.fx = c->K[0]; d.fy = c->K[4]; d.cx = c->K[2]; d.cy = c->K[5]; d.vs = c->voxel_size; d.reg_weight = c->ba_reg;
+    return d;
+}
+static int ba_upload_poses(gsdf_ctx* c) {
+    HIP_TRY(hipMemcpyAsync(c->ba_Rt, c->ba_R.data(), c->ba_R.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ba_Rt + 9 * (size_t)c->ba_n, c->ba_t.data(), c->ba_t.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+static int ba_require(gsdf_ctx* c) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    if (!c->ba_n) return fail(GSDF_ERR_INVALID, "gsdf_ba_setup was not called");
+    return GSDF_OK;
+}
+
+int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float* poses16_host, const int* frame_idx,
+                  float reg_weight) {
+    int rc = require_frame(c);
+    if (rc) return rc;
+    if (!c->vis) return fail(GSDF_ERR_INVALID, "PhotoBA needs the vis_ bit-vectors: call gsdf_enable_vis before fusing");
+    if (n <= 0 || n > 64 || !images_bgr_host || !poses16_host || !frame_idx) return fail(GSDF_ERR_INVALID, "bad argument (1..64 keyframes)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    void* old[] = { c->ba_images, c->ba_Rt, c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
+    for (void* p : old) if (p) (void)hipFree(p);
+    c->ba_images = nullptr; c->ba_Rt = nullptr; c->ba_frame_idx = nullptr; c->ba_block_E = nullptr; c->ba_block_part = nullptr; c->ba_Hb = nullptr;
+    c->ba_n = n; c->ba_reg = reg_weight;
+    const size_t img_bytes = (size_t)n * c->W * c->H * 3 * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&c->ba_images, img_bytes));
+    HIP_TRY(hipMalloc((void**)&c->ba_Rt, (size_t)n * 12 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->ba_frame_idx, (size_t)n * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&c->ba_block_E, (size_t)gsdf_ba_blocks() * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&c->ba_block_part, (size_t)gsdf_ba_blocks() * n * 27 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->ba_Hb, (size_t)n * 27 * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(c->ba_images, images_bgr_host, img_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ba_frame_idx, frame_idx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->ba_R.resize(9 * (size_t)n); c->ba_t.resize(3 * (size_t)n);
+    for (int i = 0; i < n; ++i)
+        for (int r = 0; r < 3; ++r) {
+            for (int k = 0; k < 3; ++k) c->ba_R[9 * i + 3 * r + k] = poses16_host[16 * i + 4 * r + k];
+            c->ba_t[3 * i + r] = poses16_host[16 * i + 4 * r + 3];
+        }
+    return ba_upload_poses(c);
+}
+
+int gsdf_ba_energy(gsdf_ctx* c, float* E) {
+    int rc = ba_require(c);
+    if (rc) return rc;
+    if (!E) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_launch_ba_energy(c->stream, ba_dev(c), c->ba_block_E);
+    std::vector<double> h((size_t)gsdf_ba_blocks());
+    HIP_TRY(hipMemcpyAsync(h.data(), c->ba_block_E, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double s = 0.0;
+    for (double v : h) s += v;
+    *E = (float)s;
+    return GSDF_OK;
+}
+
+int gsdf_ba_solve_dist(gsdf_ctx* c, float damping) {
+    int rc = ba_require(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_launch_ba_dist(c->stream, ba_dev(c), damping);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+
+int gsdf_ba_solve_pose(gsdf_ctx* c, float damping) {
+    (void)damping;                                            /* unused by the reference as well (:499) */
+    int rc = ba_require(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = c->ba_n;
+    gsdf_launch_ba_pose(c->stream, ba_dev(c), c->ba_block_part, c->ba_Hb);
+    std::vector<float> hb((size_t)n * 27);
+    HIP_TRY(hipMemcpyAsync(hb.data(), c->ba_Hb, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) {                             /* per-keyframe 6x6 LDLT + pose update (:577-589) */
+        const float* v = &hb[27 * (size_t)i];
+        float H[36], dp[6];
+        int q = 6;
+        for (int a1 = 0; a1 < 6; ++a1) for (int a2 = a1; a2 < 6; ++a2) { H[6 * a1 + a2] = v[q]; H[6 * a2 + a1] = v[q]; ++q; }
+        gsdf_ldlt_solve6(H, v, dp);
+        bool nan = false;
+        for (int k = 0; k < 6; ++k) nan = nan || std::isnan(dp[k]);
+        if (nan) continue;
+        for (int k = 0; k < 3; ++k) c->ba_t[3 * i + k] -= dp[k];
+        float pose[7] = { 0, 0, 0, 0, 0, 0, 1 };
+        const float xi[6] = { 0, 0, 0, -dp[3], -dp[4], -dp[5] };
+        gsdf_se3_exp_mul(xi, pose);                           /* SO3::exp(-omega) */
+        float Ex[9], Rn[9];
+        gsdf_quat_to_R(pose + 3, Ex);
+        const float* Ri = &c->ba_R[9 * (size_t)i];
+        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 3; ++k) Rn[3 * r + k] = gsdf_sum3(Ri[3 * r] * Ex[k], Ri[3 * r + 1] * Ex[3 + k], Ri[3 * r + 2] * Ex[6 + k]);
+        std::memcpy(&c->ba_R[9 * (size_t)i], Rn, sizeof(Rn));
+    }
+    return ba_upload_poses(c);
+}
+
+int gsdf_ba_optimize(gsdf_ctx* c, int max_it, float* energies, int* n_energies, int* converged) {
+    int rc = ba_require(c);
+    if (rc) return rc;
+    if (!energies || !n_energies || !converged || max_it < 0) return fail(GSDF_ERR_INVALID, "bad argument");
+    int ne = 0;
+    float E = 0.f, E_pose = 0.f;
+    *converged = 0;
+    if ((rc = gsdf_ba_energy(c, &E))) return rc;
+    energies[ne++] = E;
+    for (int iter = 0; iter < max_it; ++iter) {               /* :621-657 */
+        if ((rc = gsdf_ba_solve_pose(c, 1.0f))) return rc;
+        if ((rc = gsdf_ba_energy(c, &E_pose))) return rc;
+        energies[ne++] = E_pose;
+        if ((rc = gsdf_ba_solve_dist(c, 1.0f))) return rc;
+        if ((rc = gsdf_ba_energy(c, &E))) return rc;
+        energies[ne++] = E;
+        const float rel = std::fabs(E_pose - E) / E_pose;
+        if (rel < 0.0005f) { *converged = 1; break; }
+        if (E_pose < E) break;                                /* diverged */
+    }
+    *n_energies = ne;
+    return GSDF_OK;
+}
+
+int gsdf_ba_get_poses(gsdf_ctx* c, float* poses16_host) {
+    int rc = ba_require(c);
+    if (rc) return rc;
+    if (!poses16_host) return fail(GSDF_ERR_INVALID, "null argument");
+    for (int i = 0; i < c->ba_n; ++i) {
+        float* P = poses16_host + 16 * (size_t)i;
+        for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) P[4 * r + k] = c->ba_R[9 * (size_t)i + 3 * r + k]; P[4 * r + 3] = c->ba_t[3 * (size_t)i + r]; }
+        P[12] = P[13] = P[14] = 0.f; P[15] = 1.f;
+    }
+    return GSDF_OK;
 }
 
 int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w) {

@@ -103,4 +103,22 @@ void gsdf_launch_merge_raw(hipStream_t s, gsdf_table tab, const int32_t* keys, c
 void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, const float* pts, long long n,
                        float* dist, float* grad, float* w);
 
+/* PhotoBA (gsdf_ba.hip): device-side problem description, same layout as the kernels' ba_args */
+struct gsdf_ba_dev {
+    gsdf_table tab;
+    size_t n_slots;
+    const uint32_t* vis;
+    int vis_words;
+    int n, W, H;
+    const float* images;
+    const float* R;
+    const float* t;
+    const int* frame_idx;
+    float fx, fy, cx, cy, vs, reg_weight;
+};
+void gsdf_launch_ba_energy(hipStream_t s, const gsdf_ba_dev& d, double* block_E);
+void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping);
+void gsdf_launch_ba_pose(hipStream_t s, const gsdf_ba_dev& d, float* block_part, float* out);
+int  gsdf_ba_blocks(void);
+
 #endif /* GSDF_KERNELS_H_ */

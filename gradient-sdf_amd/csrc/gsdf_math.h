@@ -198,4 +198,32 @@ GSDF_UNROLL
     }
 }
 
+/* x = H^-1 b by LDL^T with symmetric diagonal pivoting (Eigen LDLT, PhotometricOptimizer.cpp:579) */
+GSDF_HD void gsdf_ldlt_solve6(const float* Hin, const float* bin, float* x) {
+    float A[36], bb[6];
+    int perm[6];
+    for (int i = 0; i < 36; ++i) A[i] = Hin[i];
+    for (int i = 0; i < 6; ++i) perm[i] = i;
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        float best = fabsf(A[7 * k]);
+        for (int i = k + 1; i < 6; ++i) if (fabsf(A[7 * i]) > best) { best = fabsf(A[7 * i]); piv = i; }
+        if (piv != k) {
+            for (int j = 0; j < 6; ++j) { const float tmp = A[6 * k + j]; A[6 * k + j] = A[6 * piv + j]; A[6 * piv + j] = tmp; }
+            for (int j = 0; j < 6; ++j) { const float tmp = A[6 * j + k]; A[6 * j + k] = A[6 * j + piv]; A[6 * j + piv] = tmp; }
+            const int tp = perm[k]; perm[k] = perm[piv]; perm[piv] = tp;
+        }
+        const float d = A[7 * k];
+        if (d == 0.f) continue;
+        for (int i = k + 1; i < 6; ++i) A[6 * i + k] /= d;
+        for (int i = k + 1; i < 6; ++i)
+            for (int j = k + 1; j <= i; ++j) { A[6 * i + j] -= A[6 * i + k] * d * A[6 * j + k]; A[6 * j + i] = A[6 * i + j]; }
+    }
+    for (int i = 0; i < 6; ++i) bb[i] = bin[perm[i]];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < i; ++j) bb[i] -= A[6 * i + j] * bb[j];
+    for (int i = 0; i < 6; ++i) bb[i] = A[7 * i] != 0.f ? bb[i] / A[7 * i] : 0.f;
+    for (int i = 5; i >= 0; --i) for (int j = i + 1; j < 6; ++j) bb[i] -= A[6 * j + i] * bb[j];
+    for (int i = 0; i < 6; ++i) x[perm[i]] = bb[i];
+}
+
 #endif /* GSDF_MATH_H_ */

@@ -245,3 +245,38 @@ def write_dataset(seq, out_dir, layout="synth", with_poses=True, pose_file="pose
         with open(out_dir + pose_file, "w") as f:
             f.write("\n".join(poses) + "\n")
     return out_dir
+
+
+# ---- colour keyframes for the photometric bundle adjustment (PhotoBA, config C5) ---------------------------
+
+def albedo(p):
+    """Smooth procedural RGB texture of a world point (so that every view of a surface point agrees)."""
+    p = np.asarray(p, np.float64)
+    r = 0.5 + 0.25 * np.sin(9.0 * p[..., 0] + 1.0) + 0.25 * np.sin(7.0 * p[..., 1] * p[..., 2] + 0.3)
+    g = 0.5 + 0.25 * np.sin(8.0 * p[..., 1] - 0.5) + 0.25 * np.cos(6.0 * p[..., 0] + 5.0 * p[..., 2])
+    b = 0.5 + 0.25 * np.sin(10.0 * p[..., 2] + 2.0) + 0.25 * np.sin(5.0 * (p[..., 0] - p[..., 1]))
+    return np.stack([r, g, b], -1)
+
+
+def render_color_bgr(seq, i, R=None, t=None):
+    """float32 BGR image in [0,1] (cv::imread order, ImageLoader.h:198-216) of frame i of `seq`, textured
+    with albedo() at the analytic hit point; pixels without a hit are black."""
+    Rs, ts = seq.pose(i)
+    R = Rs if R is None else R
+    t = ts if t is None else t
+    R64, t64 = np.asarray(R, np.float64), np.asarray(t, np.float64)
+    z = render_depth(seq.K, seq.W, seq.H, R64, t64, seq.spheres, seq.box)
+    K = np.asarray(seq.K, np.float64)
+    u, v = np.meshgrid(np.arange(seq.W, dtype=np.float64), np.arange(seq.H, dtype=np.float64))
+    d = np.stack([(u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], np.ones_like(u)], -1)
+    pw = t64 + z[..., None] * (d @ R64.T)
+    rgb = albedo(pw)
+    rgb[z <= 0] = 0.0
+    return np.ascontiguousarray(rgb[..., ::-1], dtype=np.float32)
+
+
+def pose16(R, t):
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T

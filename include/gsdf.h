@@ -123,6 +123,21 @@ int gsdf_export(gsdf_ctx* c, int32_t* keys, float* payload, int64_t max_n, int64
 int gsdf_enable_vis(gsdf_ctx* c, int max_frames);
 int gsdf_export_vis(gsdf_ctx* c, int32_t* keys, uint32_t* words, int words_per_voxel, int64_t max_n, int64_t* n);
 
+/* PhotoBA -- class PhotometricOptimizer (ps_optimizer/PhotometricOptimizer.h:68-186, .cpp), coarse photometric
+ * bundle adjustment of keyframe poses and voxel distances on the fused map.  Needs gsdf_enable_vis.
+ * images: float32 BGR in [0,1], n x H x W x 3 (setImages, cv::Mat CV_32FC3); poses16: n row-major 4x4
+ * camera->world (setPoses); frame_idx: integrated-frame index of each keyframe (setKeyframes), n <= 64.
+ * gsdf_ba_energy = getEnergy (:273-321), gsdf_ba_solve_pose = solvePose (:499-590), gsdf_ba_solve_dist =
+ * solveDist (:326-388), gsdf_ba_optimize = optimize (:611-662): energies receives E0 and E after every pose
+ * and distance step (<= 2*max_it+1 values), *converged = relative change < 5e-4. */
+int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float* poses16_host, const int* frame_idx,
+                  float reg_weight);
+int gsdf_ba_energy(gsdf_ctx* c, float* E);
+int gsdf_ba_solve_pose(gsdf_ctx* c, float damping);
+int gsdf_ba_solve_dist(gsdf_ctx* c, float damping);
+int gsdf_ba_optimize(gsdf_ctx* c, int max_it, float* energies, int* n_energies, int* converged);
+int gsdf_ba_get_poses(gsdf_ctx* c, float* poses16_host);
+
 /* additive merge of raw sums into this table (frame-sharded fusion) */
 int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, int64_t n);
 

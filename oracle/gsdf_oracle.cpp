@@ -26,6 +26,7 @@
 #include <unordered_map>
 #include <algorithm>
 #include <limits>
+#include <array>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -620,6 +621,306 @@ int gsdfo_track(gsdfo* o, const float* depth, const float K[9], float pose7[7],
     }
     if (iters_used) *iters_used = used;
     return 0;                                                         /* :98 */
+}
+
+} // extern "C"
+
+/* ==================================================================================================
+ * PhotoBA oracle: PhotometricOptimizer restated (ps_optimizer/PhotometricOptimizer.cpp), L2 loss path
+ * (the default CAUCHY setting never enters the TRUNC_L2 branches, :358,:541).
+ * ================================================================================================== */
+namespace {
+
+struct Img { int W, H; const float* p; };                    /* BGR float, row-major */
+static inline const float* px(const Img& im, int row, int col) { return im.p + ((size_t)row * im.W + col) * 3; }
+
+/* interpolateImage(m, n, img) -- :57-77: m = row coordinate, n = column coordinate; weights in double,
+ * each weighted pixel rounded to float (cv::Vec3f * double), summed in float; BGR -> RGB */
+static V3 interpolate_image(float m, float n, const Img& im) {
+    const int x = (int)std::floor(m), y = (int)std::floor(n);
+    float t[3];
+    auto wpx = [](double w, const float* q, int c) { return (float)(w * (double)q[c]); };
+    if ((x + 1) < im.H && (y + 1) < im.W) {
+        const double w1 = (y + 1.0 - n) * (m - x), w2 = (y + 1.0 - n) * (x + 1.0 - m), w3 = (n - y) * (m - x), w4 = (n - y) * (x + 1.0 - m);
+        for (int c = 0; c < 3; ++c)
+            t[c] = ((wpx(w1, px(im, x + 1, y), c) + wpx(w2, px(im, x, y), c)) + wpx(w3, px(im, x + 1, y + 1), c)) + wpx(w4, px(im, x, y + 1), c);
+    } else if ((y + 1) < im.W && x >= im.H) {                 /* unreachable for in-bounds m (kept for fidelity) */
+        for (int c = 0; c < 3; ++c) t[c] = wpx(y + 1.0 - n, px(im, std::min(x, im.H - 1), y), c) + wpx(n - y, px(im, std::min(x, im.H - 1), y + 1), c);
+    } else if (y >= im.W && (x + 1) < im.H) {
+        for (int c = 0; c < 3; ++c) t[c] = wpx(m - x, px(im, x + 1, std::min(y, im.W - 1)), c) + wpx(x + 1.0 - m, px(im, x, std::min(y, im.W - 1)), c);
+    } else {
+        for (int c = 0; c < 3; ++c) t[c] = px(im, std::min(x, im.H - 1), std::min(y, im.W - 1))[c];
+    }
+    return V3{ t[2], t[1], t[0] };
+}
+
+/* computeImageGradient(m, n, img, direction) -- :80-140 (finite differences, bilinear in the other axis) */
+static V3 image_gradient(float m, float n, const Img& im, int direction) {
+    const int x = (int)std::floor(m), y = (int)std::floor(n);
+    const float w01 = m - x, w11 = n - y;
+    const float w00 = (float)(1.0 - w01), w10 = (float)(1.0 - w11);
+    float v0[3] = { 0, 0, 0 }, v1[3] = { 0, 0, 0 };
+    auto diff = [&](float* o, int r1, int c1, int r0, int c0) { for (int c = 0; c < 3; ++c) o[c] = px(im, r1, c1)[c] - px(im, r0, c0)[c]; };
+    auto comb = [&](float a, float b) { return V3{ a * v0[2] + b * v1[2], a * v0[1] + b * v1[1], a * v0[0] + b * v1[0] }; };
+    if (direction == 0) {
+        if ((x + 1) < im.H && (y + 1) < im.W) { diff(v0, x, y + 1, x, y); diff(v1, x + 1, y + 1, x + 1, y); return comb(w00, w01); }
+        else if ((x + 1) >= im.H) {
+            if ((y + 1) < im.W) diff(v0, x, y + 1, x, y); else diff(v0, x, y, x, y - 1);      /* reference reads past the row end here */
+            return V3{ v0[2], v0[1], v0[0] };
+        } else { diff(v0, x, y, x, y - 1); diff(v1, x + 1, y, x + 1, y - 1); return comb(w00, w01); }
+    } else {
+        if ((x + 1) < im.H && (y + 1) < im.W) { diff(v0, x + 1, y, x, y); diff(v1, x + 1, y + 1, x, y + 1); return comb(w10, w11); }
+        else if ((x + 1) >= im.H && (y + 1) < im.W) { diff(v0, x, y, x - 1, y); diff(v1, x, y + 1, x - 1, y + 1); return comb(w10, w11); }
+        else {
+            if ((x + 1) < im.H) diff(v0, x + 1, y, x, y); else diff(v0, x, y, x - 1, y);      /* reference reads past the last row here */
+            return V3{ v0[2], v0[1], v0[0] };
+        }
+    }
+}
+
+} // namespace
+
+struct gsdfo_ba {
+    gsdfo* o;
+    float fx, fy, cx, cy;
+    int n, W, H;
+    std::vector<float> images;
+    std::vector<float> R;          /* n x 9 row-major */
+    std::vector<float> t;          /* n x 3 */
+    std::vector<int> frame_idx;
+    float reg_weight;
+    std::vector<Key> order;        /* voxel visiting order (z,y,x) */
+
+    Img img(int i) const { return Img{ W, H, images.data() + (size_t)i * W * H * 3 }; }
+    bool visible(const Key& k, int i) const {
+        auto it = o->vis_.find(k);
+        if (it == o->vis_.end()) return false;
+        const std::vector<bool>& v = it->second;
+        return !((int)v.size() <= frame_idx[i] || !v[frame_idx[i]]);      /* :289 */
+    }
+    /* the common projection of getIntensity / computeJc / computeJdOneFrame (:165-177) */
+    bool project(const Key& idx, const SdfVoxel& vox, int i, V3* point, float* m, float* n) const {
+        const float* Ri = &R[9 * i];
+        const V3 gn = normalized3(V3{ vox.grad[0], vox.grad[1], vox.grad[2] });
+        const V3 c = o->vox2float(idx);
+        const V3 d = { c.x - vox.dist * gn.x - t[3 * i], c.y - vox.dist * gn.y - t[3 * i + 1], c.z - vox.dist * gn.z - t[3 * i + 2] };
+        /* Rt * d */
+        const V3 p = { sum3(Ri[0] * d.x, Ri[3] * d.y, Ri[6] * d.z), sum3(Ri[1] * d.x, Ri[4] * d.y, Ri[7] * d.z),
+                       sum3(Ri[2] * d.x, Ri[5] * d.y, Ri[8] * d.z) };
+        const float z_inv = (float)(1. / p.z);
+        *m = fx * p.x * z_inv + cx;
+        *n = fy * p.y * z_inv + cy;
+        *point = p;
+        return !(*m < 0 || *m >= W || *n < 0 || *n >= H);
+    }
+    bool intensity(const Key& idx, const SdfVoxel& vox, int i, V3* A) const {       /* getIntensity :238-260 */
+        V3 p; float m, n;
+        if (!project(idx, vox, i, &p, &m, &n)) return false;
+        *A = interpolate_image(n, m, img(i));
+        return true;
+    }
+    /* image_grad (3x2) * pi_grad (2x3) as a 3x3 row-major matrix (:188-199, :221-231) */
+    bool image_pi_grad(const Key& idx, const SdfVoxel& vox, int i, V3* point, float G[9]) const {
+        V3 p; float m, n;
+        if (!project(idx, vox, i, &p, &m, &n)) return false;
+        const float z_inv = (float)(1. / p.z), z_inv_sq = z_inv * z_inv;
+        const V3 g0 = image_gradient(n, m, img(i), 0), g1 = image_gradient(n, m, img(i), 1);
+        const float pg[6] = { fx * z_inv, 0.f, -fx * p.x * z_inv_sq, 0.f, fy * z_inv, -fy * p.y * z_inv_sq };
+        const float ig[6] = { g0.x, g1.x, g0.y, g1.y, g0.z, g1.z };          /* 3x2 row-major */
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) G[3 * r + c] = ig[2 * r] * pg[c] + ig[2 * r + 1] * pg[3 + c];
+        *point = p;
+        return true;
+    }
+};
+
+extern "C" {
+
+gsdfo_ba* gsdfo_ba_create(gsdfo* o, const float K[9], int n, int W, int H, const float* images_bgr, const float* poses16,
+                          const int* frame_idx, float reg_weight) {
+    gsdfo_ba* b = new gsdfo_ba();
+    b->o = o; b->fx = K[0]; b->fy = K[4]; b->cx = K[2]; b->cy = K[5];
+    b->n = n; b->W = W; b->H = H; b->reg_weight = reg_weight;
+    b->images.assign(images_bgr, images_bgr + (size_t)n * W * H * 3);
+    b->R.resize(9 * n); b->t.resize(3 * n);
+    for (int i = 0; i < n; ++i)
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) b->R[9 * i + 3 * r + c] = poses16[16 * i + 4 * r + c]; b->t[3 * i + r] = poses16[16 * i + 4 * r + 3]; }
+    b->frame_idx.assign(frame_idx, frame_idx + n);
+    b->order = sorted_keys(o);
+    return b;
+}
+void gsdfo_ba_destroy(gsdfo_ba* b) { delete b; }
+
+/* getEnergy -- :273-321 */
+float gsdfo_ba_energy(gsdfo_ba* b) {
+    float E = 0.f;
+    std::vector<V3> A;
+    for (const Key& idx : b->order) {
+        const SdfVoxel& vox = b->o->tsdf_.at(idx);
+        if (std::fabs(vox.dist) > b->o->voxel_size_) continue;
+        A.clear();
+        V3 mean = { 0, 0, 0 };
+        for (int i = 0; i < b->n; ++i) {
+            if (!b->visible(idx, i)) continue;
+            V3 a;
+            if (!b->intensity(idx, vox, i, &a)) continue;
+            mean = V3{ mean.x + a.x, mean.y + a.y, mean.z + a.z };
+            A.push_back(a);
+        }
+        const float inv = (float)(1. / (float)A.size());
+        mean = V3{ inv * mean.x, inv * mean.y, inv * mean.z };
+        for (const V3& a : A) {
+            const V3 r = { a.x - mean.x, a.y - mean.y, a.z - mean.z };
+            E += dot3(r, r);
+        }
+    }
+    return E;
+}
+
+/* solveDist -- :326-388 */
+void gsdfo_ba_solve_dist(gsdfo_ba* b, float damping) {
+    for (const Key& idx : b->order) {
+        SdfVoxel& vox = b->o->tsdf_.at(idx);
+        size_t Nj = 0;
+        V3 sA = { 0, 0, 0 }, sD = { 0, 0, 0 }, sAD = { 0, 0, 0 }, sDD = { 0, 0, 0 };
+        for (int i = 0; i < b->n; ++i) {
+            if (!b->visible(idx, i)) continue;
+            V3 a;
+            if (!b->intensity(idx, vox, i, &a)) continue;
+            ++Nj;
+            /* computeJdOneFrame :160-203: Jd = image_grad * pi_grad * (-Rt * grad) */
+            V3 p; float G[9];
+            b->image_pi_grad(idx, vox, i, &p, G);
+            const float* Ri = &b->R[9 * i];
+            const V3 Rtn = { -sum3(Ri[0] * vox.grad[0], Ri[3] * vox.grad[1], Ri[6] * vox.grad[2]),
+                             -sum3(Ri[1] * vox.grad[0], Ri[4] * vox.grad[1], Ri[7] * vox.grad[2]),
+                             -sum3(Ri[2] * vox.grad[0], Ri[5] * vox.grad[1], Ri[8] * vox.grad[2]) };
+            const V3 Jd = matvec(G, Rtn);
+            sA = V3{ sA.x + a.x, sA.y + a.y, sA.z + a.z };
+            sD = V3{ sD.x + Jd.x, sD.y + Jd.y, sD.z + Jd.z };
+            sAD = V3{ sAD.x + a.x * Jd.x, sAD.y + a.y * Jd.y, sAD.z + a.z * Jd.z };
+            sDD = V3{ sDD.x + Jd.x * Jd.x, sDD.y + Jd.y * Jd.y, sDD.z + Jd.z * Jd.z };
+        }
+        if (Nj == 0) continue;
+        const float inv_Nj = (float)(1. / (float)Nj);
+        float H_dd = sum3(sDD.x, sDD.y, sDD.z) - inv_Nj * sum3(sD.x * sD.x, sD.y * sD.y, sD.z * sD.z);
+        const float b_d = sum3(sAD.x, sAD.y, sAD.z) - inv_Nj * sum3(sA.x * sD.x, sA.y * sD.y, sA.z * sD.z);
+        H_dd += b->reg_weight * vox.weight;
+        if (H_dd != 0) vox.dist -= damping * b_d / H_dd;                  /* updateDist :265-268 */
+    }
+}
+
+/* 6x6 solve by LDL^T with symmetric (diagonal) pivoting, Eigen's LDLT algorithm restated */
+static void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
+    float A[36]; int perm[6]; float bb[6];
+    std::memcpy(A, Hin, sizeof(A));
+    for (int i = 0; i < 6; ++i) perm[i] = i;
+    for (int k = 0; k < 6; ++k) {
+        int piv = k; float best = std::fabs(A[7 * k]);
+        for (int i = k + 1; i < 6; ++i) if (std::fabs(A[7 * i]) > best) { best = std::fabs(A[7 * i]); piv = i; }
+        if (piv != k) {
+            for (int j = 0; j < 6; ++j) std::swap(A[6 * k + j], A[6 * piv + j]);
+            for (int j = 0; j < 6; ++j) std::swap(A[6 * j + k], A[6 * j + piv]);
+            std::swap(perm[k], perm[piv]);
+        }
+        const float d = A[7 * k];
+        if (d == 0.f) continue;
+        for (int i = k + 1; i < 6; ++i) A[6 * i + k] /= d;
+        for (int i = k + 1; i < 6; ++i)
+            for (int j = k + 1; j <= i; ++j) { A[6 * i + j] -= A[6 * i + k] * d * A[6 * j + k]; A[6 * j + i] = A[6 * i + j]; }
+    }
+    for (int i = 0; i < 6; ++i) bb[i] = bin[perm[i]];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < i; ++j) bb[i] -= A[6 * i + j] * bb[j];      /* L y = P b */
+    for (int i = 0; i < 6; ++i) bb[i] = A[7 * i] != 0.f ? bb[i] / A[7 * i] : 0.f;                /* D z = y (Eigen: 0 for tiny pivots) */
+    for (int i = 5; i >= 0; --i) for (int j = i + 1; j < 6; ++j) bb[i] -= A[6 * j + i] * bb[j];  /* L^T w = z */
+    for (int i = 0; i < 6; ++i) x[perm[i]] = bb[i];
+}
+
+/* solvePose -- :499-590 */
+void gsdfo_ba_solve_pose(gsdfo_ba* b, float) {
+    const int n = b->n;
+    std::vector<float> Hs(36 * (size_t)n, 0.f), bs(6 * (size_t)n, 0.f);
+    std::vector<int> vi; std::vector<V3> vA; std::vector<std::array<float, 18>> vJ;
+    for (const Key& idx : b->order) {
+        const SdfVoxel& vox = b->o->tsdf_.at(idx);
+        if (std::fabs(vox.dist) > b->o->voxel_size_) continue;
+        vi.clear(); vA.clear(); vJ.clear();
+        V3 mean = { 0, 0, 0 };
+        for (int i = 0; i < n; ++i) {
+            if (!b->visible(idx, i)) continue;
+            V3 a, p; float G[9];
+            if (!b->intensity(idx, vox, i, &a) || !b->image_pi_grad(idx, vox, i, &p, G)) continue;
+            /* computeJc :206-233: Jc = [ -G * Rt , G * skew(point) ]  (3x6) */
+            const float* Ri = &b->R[9 * i];
+            std::array<float, 18> J;
+            const float S[9] = { 0.f, -p.z, p.y, p.z, 0.f, -p.x, -p.y, p.x, 0.f };
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    J[6 * r + c] = -sum3(G[3 * r] * Ri[3 * c], G[3 * r + 1] * Ri[3 * c + 1], G[3 * r + 2] * Ri[3 * c + 2]);   /* (G Rt)(r,c) = sum_k G(r,k) R(c,k) */
+                    J[6 * r + 3 + c] = sum3(G[3 * r] * S[c], G[3 * r + 1] * S[3 + c], G[3 * r + 2] * S[6 + c]);
+                }
+            vi.push_back(i); vA.push_back(a); vJ.push_back(J);
+            mean = V3{ mean.x + a.x, mean.y + a.y, mean.z + a.z };
+        }
+        const size_t Nj = vi.size();
+        if (Nj == 0) continue;
+        const float inv_Nj = (float)(1. / (float)Nj);
+        mean = V3{ inv_Nj * mean.x, inv_Nj * mean.y, inv_Nj * mean.z };
+        for (size_t k = 0; k < Nj; ++k) {
+            const int i1 = vi[k];
+            const V3 r = { vA[k].x - mean.x, vA[k].y - mean.y, vA[k].z - mean.z };
+            const std::array<float, 18>& J = vJ[k];
+            for (int c = 0; c < 6; ++c) bs[6 * i1 + c] += sum3(r.x * J[c], r.y * J[6 + c], r.z * J[12 + c]);
+            for (int a1 = 0; a1 < 6; ++a1)
+                for (int a2 = 0; a2 < 6; ++a2)
+                    Hs[36 * i1 + 6 * a1 + a2] += (1 - inv_Nj) * sum3(J[a1] * J[a2], J[6 + a1] * J[6 + a2], J[12 + a1] * J[12 + a2]);
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        float dp[6];
+        ldlt_solve6(&Hs[36 * i], &bs[6 * i], dp);
+        bool nan = false;
+        for (int k = 0; k < 6; ++k) nan = nan || std::isnan(dp[k]);
+        if (nan) continue;
+        for (int k = 0; k < 3; ++k) b->t[3 * i + k] -= dp[k];                              /* :587 */
+        /* R = R * SO3::exp(-omega).matrix()  (:588) */
+        float pose[7] = { 0, 0, 0, 0, 0, 0, 1 };
+        const float xi[6] = { 0, 0, 0, -dp[3], -dp[4], -dp[5] };
+        gsdfo_se3_exp_mul(xi, pose);
+        float E[9], Rn[9];
+        gsdfo_quat_to_R(pose + 3, E);
+        const float* Ri = &b->R[9 * i];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) Rn[3 * r + c] = sum3(Ri[3 * r] * E[c], Ri[3 * r + 1] * E[3 + c], Ri[3 * r + 2] * E[6 + c]);
+        std::memcpy(&b->R[9 * i], Rn, sizeof(Rn));
+    }
+}
+
+/* optimize -- :611-662 */
+int gsdfo_ba_optimize(gsdfo_ba* b, int max_it, float* energies, int* n_energies) {
+    int ne = 0;
+    float E = gsdfo_ba_energy(b);
+    energies[ne++] = E;
+    for (int iter = 0; iter < max_it; ++iter) {
+        gsdfo_ba_solve_pose(b, 1.0f);
+        const float E_pose = gsdfo_ba_energy(b);
+        energies[ne++] = E_pose;
+        gsdfo_ba_solve_dist(b, 1.0f);
+        E = gsdfo_ba_energy(b);
+        energies[ne++] = E;
+        const float rel = std::fabs(E_pose - E) / E_pose;
+        if (rel < 0.0005f) { *n_energies = ne; return 1; }
+        if (E_pose < E) { *n_energies = ne; return 0; }
+    }
+    *n_energies = ne;
+    return 0;
+}
+
+void gsdfo_ba_get_poses(const gsdfo_ba* b, float* P) {
+    for (int i = 0; i < b->n; ++i) {
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) P[16 * i + 4 * r + c] = b->R[9 * i + 3 * r + c]; P[16 * i + 4 * r + 3] = b->t[3 * i + r]; }
+        P[16 * i + 12] = P[16 * i + 13] = P[16 * i + 14] = 0.f; P[16 * i + 15] = 1.f;
+    }
 }
 
 } // extern "C"

@@ -82,3 +82,26 @@ void   gsdfo_se3_exp_mul(const float xi[6], float pose7[7]);     /* pose = SE3::
 }
 #endif
 #endif /* GSDF_ORACLE_H_ */
+
+/* ---- PhotoBA: PhotometricOptimizer (ps_optimizer/PhotometricOptimizer.cpp) on the oracle's map ----------
+ * images: float32 BGR in [0,1], n x H x W x 3 (cv::Mat CV_32FC3, ImageLoader.h:198-216);
+ * poses16: n row-major 4x4 camera->world (key_poses, main_photo_ba.cpp:251);
+ * frame_idx: integrated-frame index of each keyframe = bit tested in vis_ (PhotometricOptimizer.cpp:289).
+ * Voxels are visited in (z,y,x) order (the reference's phmap order is unknowable). */
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct gsdfo_ba gsdfo_ba;
+gsdfo_ba* gsdfo_ba_create(gsdfo* o, const float K[9], int n, int W, int H, const float* images_bgr,
+                          const float* poses16, const int* frame_idx, float reg_weight);
+void   gsdfo_ba_destroy(gsdfo_ba* b);
+float  gsdfo_ba_energy(gsdfo_ba* b);                       /* getEnergy        :273-321 */
+void   gsdfo_ba_solve_pose(gsdfo_ba* b, float damping);    /* solvePose        :499-590 */
+void   gsdfo_ba_solve_dist(gsdfo_ba* b, float damping);    /* solveDist        :326-388 */
+/* optimize() :611-662.  energies receives E0, then E after every pose / dist step (<= 2*max_it+1 values).
+ * Returns 1 = converged (rel. change < 5e-4), 0 = diverged or max_it reached. */
+int    gsdfo_ba_optimize(gsdfo_ba* b, int max_it, float* energies, int* n_energies);
+void   gsdfo_ba_get_poses(const gsdfo_ba* b, float* poses16);
+#ifdef __cplusplus
+}
+#endif

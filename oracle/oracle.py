@@ -169,3 +169,53 @@ def se3_exp_mul(xi, pose7):
     p = _f32(pose7).reshape(7).copy()
     lib().gsdfo_se3_exp_mul(_fp(xi), _fp(p))
     return p
+
+
+class PhotoBA:
+    """PhotometricOptimizer on an Oracle's map (ps_optimizer/PhotometricOptimizer.cpp restated)."""
+
+    def __init__(self, oracle, images_bgr, poses16, frame_idx, reg_weight=10.0):
+        self.L = lib()
+        fp = C.POINTER(C.c_float)
+        self.L.gsdfo_ba_create.restype = C.c_void_p
+        self.L.gsdfo_ba_create.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_int, fp, fp, C.POINTER(C.c_int), C.c_float]
+        self.L.gsdfo_ba_destroy.argtypes = [C.c_void_p]
+        self.L.gsdfo_ba_energy.restype = C.c_float
+        self.L.gsdfo_ba_energy.argtypes = [C.c_void_p]
+        self.L.gsdfo_ba_solve_pose.argtypes = [C.c_void_p, C.c_float]
+        self.L.gsdfo_ba_solve_dist.argtypes = [C.c_void_p, C.c_float]
+        self.L.gsdfo_ba_optimize.restype = C.c_int
+        self.L.gsdfo_ba_optimize.argtypes = [C.c_void_p, C.c_int, fp, C.POINTER(C.c_int)]
+        self.L.gsdfo_ba_get_poses.argtypes = [C.c_void_p, fp]
+        self.oracle = oracle
+        img = _f32(images_bgr)
+        self.n = img.shape[0]
+        P = _f32(poses16).reshape(self.n, 16)
+        idx = np.ascontiguousarray(frame_idx, dtype=np.int32)
+        self.h = self.L.gsdfo_ba_create(oracle.h, _fp(oracle.K), self.n, oracle.W, oracle.H, _fp(img), _fp(P),
+                                        idx.ctypes.data_as(C.POINTER(C.c_int)), np.float32(reg_weight))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.gsdfo_ba_destroy(self.h)
+            self.h = None
+
+    def energy(self):
+        return float(self.L.gsdfo_ba_energy(self.h))
+
+    def solve_pose(self, damping=1.0):
+        self.L.gsdfo_ba_solve_pose(self.h, np.float32(damping))
+
+    def solve_dist(self, damping=1.0):
+        self.L.gsdfo_ba_solve_dist(self.h, np.float32(damping))
+
+    def optimize(self, max_it=25):
+        e = np.zeros(2 * max_it + 1, np.float32)
+        ne = C.c_int(0)
+        conv = self.L.gsdfo_ba_optimize(self.h, int(max_it), _fp(e), C.byref(ne))
+        return bool(conv), e[:ne.value]
+
+    def poses(self):
+        P = np.zeros((self.n, 16), np.float32)
+        self.L.gsdfo_ba_get_poses(self.h, _fp(P))
+        return P.reshape(self.n, 4, 4)
