@@ -722,6 +722,10 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
                 for (int i = 0; i < 7; ++i) { o.pose7[i] = pose[i]; st->pose7[i] = pose[i]; }
                 o.done = done; o.converged = converged; o.passes = passes;
+                /* make `done` sticky in the other parity as well: launches that the host queued beyond the
+                 * end of this optimize() must not take the older buffer for live state and redo the step
+                 * (workgroups of THIS launch that still read it return early, which is what they do anyway) */
+                if (done) st->trk[(k - 1) & 1].done = 1;
                 gsdf_quat_to_R(pose + 3, st->R);
                 st->converged = converged;
                 st->passes = passes;
