@@ -40,6 +40,8 @@ public:
     void set_zmax(float z_max) override { zmax_ = z_max; gsdf_set_zrange(ctx_, zmin_, zmax_); }
 
     SdfLrMap get_tsdf() const;                                         /* MapGradPixelSdf.h:133-138 (by value) */
+    /* vis_ (MapGradPixelSdf.h:70,140-142): opt-in here, call before the first update() */
+    void enable_vis(int max_frames) { check(gsdf_enable_vis(ctx_, max_frames), "gsdf_enable_vis"); }
     /* sorted (z,y,x) arrays: keys int32[n][3], payload float[n][5] = dist,gx,gy,gz,weight */
     void export_arrays(std::vector<int32_t>& keys, std::vector<float>& payload) const;
     int64_t size() const;
