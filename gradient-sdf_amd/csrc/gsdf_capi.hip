@@ -60,7 +60,8 @@ struct gsdf_ctx {
     gsdf_deferred* deferred = nullptr;
     unsigned int* deferred_count = nullptr;
     unsigned int deferred_cap = 0;
-    unsigned int fuse_tag = 0;                     /* ownership tag of the last fusion launch */
+    unsigned int fuse_tag = 0;                     /* serial of the last fusion launch */
+    unsigned int* tile_flags = nullptr;            /* per-tile hand-off flags of k_fuse */
     uint32_t* vis = nullptr;                       /* optional vis_ bit-vectors, n_slots x vis_words */
     int vis_words = 0;
     /* PhotoBA (PhotometricOptimizer) */
@@ -165,10 +166,13 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
     {
         prof_scope ps(c, 1);
         c->fuse_tag += 1;
-        if (c->fuse_tag == 0) c->fuse_tag = 1;
+        if (c->fuse_tag == 0) {                                /* wrapped: no stale flag may equal a new tag */
+            c->fuse_tag = 1;
+            HIP_TRY(hipMemsetAsync(c->tile_flags, 0, (size_t)c->fuse_blocks * sizeof(unsigned int), c->stream));
+        }
         gsdf_launch_fuse(c->stream, g, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N, pose,
                          use_dev_pose, c->tab, c->st, c->blk_counters, c->deferred, c->deferred_count,
-                         c->deferred_cap, c->fuse_tag, c->frame_log, c->frame_log_cap, c->vis, c->vis_words);
+                         c->deferred_cap, c->fuse_tag, c->tile_flags, c->frame_log, c->frame_log_cap, c->vis, c->vis_words);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
@@ -293,7 +297,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     void* ptrs[] = { c->tab.buckets, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
-                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->vis, c->ba_images, c->ba_Rt,
+                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->tile_flags, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->progress) (void)hipHostFree((void*)c->progress);
@@ -330,8 +334,9 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     void* old[] = { c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log, c->deferred,
-                    c->deferred_count };
+                    c->deferred_count, c->tile_flags };
     for (void* p : old) if (p) (void)hipFree(p);
+    c->tile_flags = nullptr;
     c->planes = c->depth_stage = c->normals = c->partials = nullptr;
     c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr;
     c->W = W; c->H = H; c->win = win;
@@ -346,6 +351,8 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     c->fuse_blocks = gsdf_fuse_grid_blocks(W, H);
     HIP_TRY(hipMalloc((void**)&c->blk_counters, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMalloc((void**)&c->tile_flags, (size_t)c->fuse_blocks * sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(c->tile_flags, 0, (size_t)c->fuse_blocks * sizeof(unsigned int), c->stream));
     /* deferred list: contributions to voxels owned by another tile; bounded by the samples of a frame */
     c->deferred_cap = (unsigned int)std::min<size_t>((size_t)1 << 24, std::max<size_t>((size_t)1 << 18, N * 8));
     HIP_TRY(hipMalloc((void**)&c->deferred, (size_t)c->deferred_cap * sizeof(gsdf_deferred)));

@@ -30,7 +30,7 @@ struct gsdf_dev_state {
     int converged;
     int passes;
     int max_passes;
-    unsigned int ticket;          /* block arrival counter of the running pass */
+    unsigned int fuse_timeouts;   /* fusion tiles whose bounded wait for a neighbour expired (they deferred instead) */
     float last_hits;
     float conv_sq;
     float damping;
@@ -77,7 +77,8 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       int use_dev_pose, gsdf_table tab, gsdf_dev_state* st,
                       unsigned long long* blk_counters /* [gsdf_fuse_grid_blocks][4] */,
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
-                      unsigned int tag /* ownership tag, unique per launch, never 0 */,
+                      unsigned int tag /* serial of the fusion launch, never 0 */,
+                      unsigned int* tile_flags /* [gsdf_fuse_grid_blocks] hand-off flags, zeroed once */,
                       float* log_rows /* nullable: frame log, written when use_dev_pose */, long long max_rows,
                       uint32_t* vis /* nullable: per-voxel frame bit-vectors */, int vis_words);
 int  gsdf_fuse_grid_blocks(int W, int H);

@@ -232,7 +232,8 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
  * Samples that do not fit the LDS table go to the deferred list as well.
  * ---------------------------------------------------------------------------------------------- */
 #define FUSE_T 16
-#define FUSE_LCAP 1024
+#define FUSE_THREADS 512                 /* 4 waves (8x8 pixels each) x 2 halves of the ray walk */
+#define FUSE_LCAP 1536
 #define FUSE_NB (FUSE_LCAP / 4)
 #define FUSE_LPROBE 12
 #define FUSE_BATCH 3
@@ -253,7 +254,10 @@ struct fuse_args {
     gsdf_deferred* deferred;            /* list of contributions to voxels owned by another tile */
     unsigned int* deferred_count;
     unsigned int deferred_cap;
-    unsigned int tag;                   /* ownership tag of this launch = frame serial, never 0 */
+    unsigned int tag;                   /* serial of this fusion launch, never 0: value of a published tile flag */
+    unsigned int* tile_flags;           /* [nty][ntx]: tag of the last launch in which the tile finished its flush */
+    int ntx, nty;                       /* tiles per image row / column */
+    int first[4];                       /* first workgroup of each colour (workgroups are numbered colour-major) */
     uint32_t* vis;                      /* optional per-voxel frame bit-vectors (vis_, MapGradPixelSdf.h:70); nullable */
     int vis_words;
     int debug;                          /* experiment switches (gsdf_debug_flags); 0 in production */
@@ -262,19 +266,18 @@ struct fuse_args {
 struct fuse_lds {
     unsigned long long key[FUSE_LCAP] __attribute__((aligned(16)));
     unsigned long long w[FUSE_LCAP], s[FUSE_LCAP], gx[FUSE_LCAP], gy[FUSE_LCAP], gz[FUSE_LCAP];
-    float red[8];
+    float red[16];
     unsigned int n_defer, defer_base;
+    unsigned int zmin_bits;             /* smallest valid depth of the tile (float bits) */
+    unsigned int ordered;               /* flush with plain read-modify-write (1) or through the deferred list (0) */
 };
 
-/* float -> signed 2^-40 fixed point, exact for 2^-17 <= |x| < 2^23 (smaller terms keep 2^-40 resolution) */
+/* float -> signed 2^-40 fixed point for |x| < 2048: x + 1.5*2^12 in double has its last mantissa bit at
+ * 2^-40, so the bit pattern minus that of 1.5*2^12 IS the fixed-point value (exact for |x| >= 2^-17,
+ * nearest 2^-40 below that).  Two double-rate VALU ops + a 64-bit subtract. */
 __device__ __forceinline__ unsigned long long f2fix(float x) {
-    const int b = __float_as_int(x);
-    const int e = (b >> 23) & 0xFF;
-    const long long m = (long long)((b & 0x7FFFFF) | (e ? 0x800000 : 0));
-    const int sh = e - 110;                       /* value = m * 2^(e-150); fixed = value * 2^40 */
-    long long v = sh >= 0 ? (m << (sh > 38 ? 38 : sh)) : (m >> (-sh > 63 ? 63 : -sh));
-    if (b < 0) v = -v;
-    return (unsigned long long)v;
+    const double d = (double)x + 6144.0;
+    return (unsigned long long)(__double_as_longlong(d) - 0x40B8000000000000ll);
 }
 __device__ __forceinline__ float fix2f(unsigned long long v) {
     return __ll2float_rn((long long)v) * 9.094947017729282e-13f;   /* 2^-40 */
@@ -310,15 +313,15 @@ __device__ __forceinline__ void vis_mark(const fuse_args& a, const gsdf_payload*
 }
 
 int g_fuse_debug = 0;
-__global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
+__global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
     __shared__ fuse_lds L;
     if (a.use_dev_pose && !a.st->converged) return;        /* main_scan_3d.cpp:261: if (conv) update */
     const int tid = threadIdx.x;
-    for (int i = tid; i < FUSE_LCAP; i += 256) {
+    for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
         L.key[i] = GSDF_KEY_EMPTY;
         L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
     }
-    if (tid == 0) { L.n_defer = 0u; L.defer_base = 0u; }
+    if (tid == 0) { L.n_defer = 0u; L.defer_base = 0u; L.zmin_bits = 0x7F800000u; }
     float R[9], t[3];
     if (a.use_dev_pose) {
 #pragma unroll
@@ -336,9 +339,15 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
     const gsdf_frame_geom& g = a.g;
     const long long frame_cur = a.vis ? a.st->frame_cur : 0;   /* Sdf::counter_ of this update (snapshot by k_normals) */
     const int wave = tid >> 6, lane = tid & 63;
+    const int zhalf = wave >> 2;
     const int lx = lane & 7, ly = lane >> 3;
-    const int px = blockIdx.x * FUSE_T + (wave & 1) * 8 + lx;
-    const int py = blockIdx.y * FUSE_T + (wave >> 1) * 8 + ly;
+    const int bid = (int)blockIdx.x;
+    const int col = (bid >= a.first[1]) + (bid >= a.first[2]) + (bid >= a.first[3]);
+    const int ntx_c = (a.ntx - (col & 1) + 1) >> 1;
+    const int tile_x = 2 * ((bid - a.first[col]) % ntx_c) + (col & 1);
+    const int tile_y = 2 * ((bid - a.first[col]) / ntx_c) + (col >> 1);
+    const int px = tile_x * FUSE_T + (wave & 1) * 8 + lx;
+    const int py = tile_y * FUSE_T + ((wave >> 1) & 1) * 8 + ly;
     bool valid = px < g.W && py < g.H;
     float z = 0.f;
     gsdf_v3 Rxy = { 0.f, 0.f, 0.f }, Rn = { 0.f, 0.f, 0.f };
@@ -356,26 +365,33 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
             if (nd * nd * a.nc.ninv[idx] < .25) valid = false;             /* :98 */
         }
     }
-    /* this workgroup's share of the ray walk k = -factor..factor (:101); the order is free (sums) */
+    /* smallest valid depth of the tile: decides below whether the flush needs the ownership atomics */
+    if (zhalf == 0) {
+        unsigned int zb = valid ? __float_as_uint(z) : 0x7F800000u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned int other = __shfl_xor(zb, o); zb = other < zb ? other : zb; }
+        if (lane == 0) atomicMin(&L.zmin_bits, zb);
+    }
+    /* this half-workgroup's share of the ray walk k = -factor..factor (:101); the order is free (sums) */
     const int nk_all = 2 * g.factor + 1;
-    const int k_lo = -g.factor + (int)((blockIdx.z * nk_all) / gridDim.z);
-    const int k_hi = -g.factor + (int)(((blockIdx.z + 1) * nk_all) / gridDim.z) - 1;
-    const int nk = k_hi - k_lo + 1;
+    const int k_lo = -g.factor + (int)((zhalf * nk_all) / FUSE_ZSPLIT);
+    const int k_hi = -g.factor + (int)(((zhalf + 1) * nk_all) / FUSE_ZSPLIT) - 1;
+    const int nk = __builtin_amdgcn_readfirstlane(k_hi - k_lo + 1);       /* the same for the whole wave */
     float n_upd = 0.f;
+    unsigned int dbg_go = 0u;
     if (nk > 0) {
-        /* skew: lanes of a 3x3 pixel neighbourhood walk different samples in the same instruction */
-        int it = (2 * ((lx % 3) + 3 * (ly % 3))) % nk;
         for (int c0 = 0; c0 < nk; c0 += FUSE_BATCH) {
             unsigned long long key[FUSE_BATCH], q[FUSE_BATCH][5];
             float f[FUSE_BATCH][5];
             bool act[FUSE_BATCH];
             uint32_t bk[FUSE_BATCH];
-            /* 1. the samples of this batch */
+            /* 1. the samples of this batch (the last batch of a walk may be short: wave-uniform skip) */
 #pragma unroll
             for (int j = 0; j < FUSE_BATCH; ++j) {
-                const int kk = k_lo + it;
-                act[j] = valid && (c0 + j < nk);
-                it = it + 1 == nk ? 0 : it + 1;
+                act[j] = false; key[j] = 0ull; bk[j] = 0u;
+                if (c0 + j >= nk) continue;
+                const int kk = k_lo + c0 + j;                          /* wave-uniform */
+                act[j] = valid;
                 const float s = z + (float)kk * g.vs;
                 const float pxw = s * Rxy.x + t[0], pyw = s * Rxy.y + t[1], pzw = s * Rxy.z + t[2];   /* :103 */
                 const int vx = gsdf_float2vox1(g.inv_vs, pxw);             /* :104 */
@@ -396,37 +412,54 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
                 f[j][2] = w * Rn.x; f[j][3] = w * Rn.y; f[j][4] = w * Rn.z;   /* :112 */
 #pragma unroll
                 for (int v = 0; v < 5; ++v) q[j][v] = f2fix(f[j][v]);
-                /* LDS bucket: cheap 32-bit spatial mix (the HBM table keeps the full 64-bit finaliser) */
-                uint32_t hh = (ux * 0x9E3779B1u) ^ (uy * 0x85EBCA77u) ^ (uz * 0xC2B2AE3Du);
-                hh ^= hh >> 15; hh *= 0x2C1B3C6Du; hh ^= hh >> 13;
-                bk[j] = __umulhi(hh, (uint32_t)FUSE_NB);
+                /* LDS bucket: a LATTICE hash, not a random one.  A tile's voxels are a compact oblique prism;
+                 * x + 65 y + 138 z (mod 384) sends any two voxels closer than ~7.9 cells to different buckets
+                 * (best 3-D lattice for this modulus, found by search), so buckets fill evenly (~2.3 of 4
+                 * slots), almost never overflow, and the distinct voxels of one wave instruction never
+                 * compete for a bucket.  (The HBM table keeps the full 64-bit finaliser.) */
+                static_assert(FUSE_NB == 384, "lattice constants are for 384 buckets");
+                bk[j] = ((ux & 1023u) + 65u * (uy & 1023u) + 138u * (uz & 1023u)) % (uint32_t)FUSE_NB;
             }
             /* 2.-4. look the voxels up in the LDS table.  All pending samples of the batch advance
              *    together: bucket (4 keys) = two ds_read_b128, match / first-empty by selects, at most
              *    one CAS per sample and probe.  Plain LDS reads: a stale EMPTY is resolved by the CAS. */
+            const int nb = nk - c0 < FUSE_BATCH ? nk - c0 : FUSE_BATCH;   /* wave-uniform */
             int slot[FUSE_BATCH];
             bool pend[FUSE_BATCH];
 #pragma unroll
             for (int j = 0; j < FUSE_BATCH; ++j) { slot[j] = -1; pend[j] = act[j] && !(a.debug & 2); }
+            if (a.debug & 32) {                   /* experiment: no lookup, slot straight from the hash */
+#pragma unroll
+                for (int j = 0; j < FUSE_BATCH; ++j) { if (act[j]) slot[j] = (int)(4 * bk[j] + (key[j] & 3)); pend[j] = false; }
+            }
             for (int probe = 0; probe < FUSE_LPROBE; ++probe) {
+                /* only samples that still have a pending lane somewhere in the wave cost instructions */
+                bool go[FUSE_BATCH];
                 bool any = false;
 #pragma unroll
-                for (int j = 0; j < FUSE_BATCH; ++j) any = any || pend[j];
+                for (int j = 0; j < FUSE_BATCH; ++j) { go[j] = j < nb && __any(pend[j]); any = any || go[j]; if (go[j]) ++dbg_go; }
                 if (!any) break;
                 u64x2 k01[FUSE_BATCH], k23[FUSE_BATCH];
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j) {
+                    if (!go[j]) continue;
                     k01[j] = *reinterpret_cast<const u64x2*>(&L.key[4 * bk[j]]);
                     k23[j] = *reinterpret_cast<const u64x2*>(&L.key[4 * bk[j] + 2]);
                 }
                 int cas_at[FUSE_BATCH];
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j) {
+                    cas_at[j] = -1;
+                    if (!go[j]) continue;
                     int hit = k23[j].y == key[j] ? 3 : -1;
                     hit = k23[j].x == key[j] ? 2 : hit; hit = k01[j].y == key[j] ? 1 : hit; hit = k01[j].x == key[j] ? 0 : hit;
-                    int emp = k23[j].y == GSDF_KEY_EMPTY ? 3 : -1;
-                    emp = k23[j].x == GSDF_KEY_EMPTY ? 2 : emp; emp = k01[j].y == GSDF_KEY_EMPTY ? 1 : emp;
-                    emp = k01[j].x == GSDF_KEY_EMPTY ? 0 : emp;
+                    /* first empty slot in a key-dependent rotation: different voxels that meet in one bucket
+                     * in the same instruction go for different slots, so fewer of them lose the CAS */
+                    const uint32_t m = (k01[j].x == GSDF_KEY_EMPTY ? 1u : 0u) | (k01[j].y == GSDF_KEY_EMPTY ? 2u : 0u) |
+                                       (k23[j].x == GSDF_KEY_EMPTY ? 4u : 0u) | (k23[j].y == GSDF_KEY_EMPTY ? 8u : 0u);
+                    const uint32_t r = (uint32_t)(key[j] ^ (key[j] >> 21) ^ (key[j] >> 42)) & 3u;
+                    const uint32_t mr = ((m | (m << 4)) >> r) & 15u;
+                    const int emp = mr ? (int)((__ffs(mr) - 1 + r) & 3u) : -1;
                     if (pend[j] && hit >= 0) { slot[j] = (int)(4 * bk[j]) + hit; pend[j] = false; }
                     cas_at[j] = (pend[j] && emp >= 0) ? (int)(4 * bk[j]) + emp : -1;
                     if (pend[j] && emp < 0) bk[j] = bk[j] + 1 == FUSE_NB ? 0 : bk[j] + 1;   /* bucket full of others */
@@ -434,16 +467,17 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
                 unsigned long long old[FUSE_BATCH];
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j)
-                    old[j] = cas_at[j] >= 0 ? atomicCAS(&L.key[cas_at[j]], GSDF_KEY_EMPTY, key[j]) : 0ull;
+                    old[j] = (go[j] && cas_at[j] >= 0) ? atomicCAS(&L.key[cas_at[j]], GSDF_KEY_EMPTY, key[j]) : 0ull;
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j)
-                    if (cas_at[j] >= 0 && (old[j] == GSDF_KEY_EMPTY || old[j] == key[j])) { slot[j] = cas_at[j]; pend[j] = false; }
+                    if (go[j] && cas_at[j] >= 0 && (old[j] == GSDF_KEY_EMPTY || old[j] == key[j])) { slot[j] = cas_at[j]; pend[j] = false; }
                 /* a lost CAS (slot taken by another voxel) re-reads the same bucket in the next probe */
             }
             /* 5. accumulate (exact 64-bit integer adds) */
 #pragma unroll
             for (int j = 0; j < FUSE_BATCH; ++j) {
-                if (!act[j] || (a.debug & 2)) continue;
+                if (j >= nb || !act[j] || (a.debug & 2)) continue;
+                if (a.debug & 16) continue;
                 if (slot[j] >= 0) {
                     atomicAdd(&L.w[slot[j]], q[j][0]);
                     atomicAdd(&L.s[slot[j]], q[j][1]);
@@ -459,19 +493,52 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
             }
         }
     }
+    if ((a.debug & 128) && lane == 0) atomicAdd(&a.st->n_hit, (unsigned long long)dbg_go);
     __syncthreads();
-    /* flush the tile's distinct voxels: claim ownership with ONE atomic, then plain read-modify-write.
-     * Each lane owns FUSE_LCAP/256 LDS slots and drives them through the stages together, so the
-     * dependent HBM round trips (bucket keys -> exchange -> payload) of its entries overlap. */
+    /* Flush the tile's distinct voxels: read-modify-write of the HBM payload with NO atomics.
+     *
+     * Mutual exclusion between tiles comes from two facts:
+     *  (1) far tiles cannot meet.  Two samples s1 d1, s2 d2 (d = (x0, y0, 1)) that round to one voxel are
+     *      < D = sqrt(3) vs apart, hence |s1 - s2| < D and |x1 - x2| < D (1 + |x1|) / s2.  If every sample
+     *      of this tile is deep enough that this bound stays below FUSE_T + 1 pixels, only the 8 adjacent
+     *      tiles can touch this tile's voxels ("ordered" tile).  A tile that is too near for that sends
+     *      all its contributions through the deferred list (float atomics in k_fuse_resolve, after the launch).
+     *  (2) adjacent tiles take turns.  Tiles are coloured by the parity of (tile_x, tile_y); an ordered tile
+     *      waits until its adjacent tiles of LOWER colour have published their flag for this launch.
+     *      Workgroups are numbered colour-major, so whatever a tile waits for was dispatched before it.
+     *      (Dispatch order is only a performance assumption: the wait is bounded, and a tile whose wait
+     *      times out defers its contributions instead.)
+     * Hand-off between workgroups (other CUs, other XCDs: neither L1 nor the per-XCD L2s are coherent for
+     * plain accesses): payloads are read and written with agent-scope (sc1) 8-byte accesses, every
+     * storing wave drains its stores, then one lane publishes the tile's flag with an agent-scope store.
+     * Bucket keys are insert-only, so plain (possibly stale) key loads can only show EMPTY and the CAS
+     * settles it.  Each lane owns FUSE_LCAP/FUSE_THREADS LDS slots and drives them through the stages
+     * together, so the dependent HBM round trips (bucket keys -> payload) of its entries overlap. */
+    const int colour = (tile_x & 1) + 2 * (tile_y & 1);
+    unsigned int* my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
+    if (tid == 0) {
+        const float D = 1.7421f * g.vs;
+        const float s_min = __uint_as_float(L.zmin_bits) - (float)g.factor * g.vs - 2.f * D;
+        const float x_lo = (float)(tile_x * FUSE_T) - g.cx, x_hi = x_lo + (float)(FUSE_T - 1);
+        const float y_lo = (float)(tile_y * FUSE_T) - g.cy, y_hi = y_lo + (float)(FUSE_T - 1);
+        const float xm = fmaxf(fabsf(x_lo), fabsf(x_hi)) + 1.f, ym = fmaxf(fabsf(y_lo), fabsf(y_hi)) + 1.f;
+        const float gap = (float)FUSE_T + 0.5f;                       /* true gap is FUSE_T + 1 pixels */
+        bool ordered = s_min > 0.f && D * (g.fx + xm) <= gap * s_min && D * (g.fy + ym) <= gap * s_min;
+        if (a.debug & 4) ordered = false;
+        L.ordered = ordered ? 1u : 0u;
+        /* a tile that writes nothing itself has nothing to hand over: publish at once */
+        if (!ordered) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
     if (!(a.debug & 1)) {
-        constexpr int NE = FUSE_LCAP / 256;
+        constexpr int NE = FUSE_LCAP / FUSE_THREADS;
         unsigned long long ekey[NE];
         gsdf_bucket* B[NE];
         ulonglong2 k01[NE], k23[NE];
         gsdf_payload* P[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            ekey[e] = L.key[tid + 256 * e];
+            ekey[e] = L.key[tid + FUSE_THREADS * e];
             B[e] = a.tab.buckets + (gsdf_hash(ekey[e]) & a.tab.bucket_mask);
             P[e] = nullptr;
         }
@@ -480,6 +547,30 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
             if (ekey[e] != GSDF_KEY_EMPTY) {
                 k01[e] = *reinterpret_cast<const ulonglong2*>(&B[e]->key[0]);
                 k23[e] = *reinterpret_cast<const ulonglong2*>(&B[e]->key[2]);
+            }
+        }
+        /* meanwhile one wave waits for the adjacent tiles of lower colour (lane j watches neighbour j) */
+        if (wave == 0 && L.ordered) {
+            bool need = false;
+            const unsigned int* flag = my_flag;
+            if (lane < 8) {
+                const int j = lane < 4 ? lane : lane + 1;             /* 3x3 neighbourhood without the centre */
+                const int nx = tile_x + (j % 3) - 1, ny = tile_y + (j / 3) - 1;
+                if (nx >= 0 && nx < a.ntx && ny >= 0 && ny < a.nty && (nx & 1) + 2 * (ny & 1) < colour && !(a.debug & 8)) {
+                    need = true;
+                    flag = a.tile_flags + (size_t)ny * a.ntx + nx;
+                }
+            }
+            const unsigned long long t0 = wall_clock64();
+            bool ok = !need;
+            for (;;) {
+                if (!ok) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 200000ull) {                /* 2 ms at 100 MHz: give up, defer instead */
+                    if (lane == 0) { L.ordered = 0u; atomicAdd(&a.st->fuse_timeouts, 1u); }
+                    break;
+                }
             }
         }
 #pragma unroll
@@ -492,71 +583,91 @@ __global__ __launch_bounds__(256) void k_fuse(fuse_args a) {
             else if (k23[e].y == ekey[e]) P[e] = &B[e]->pay[3];
             else {
                 P[e] = gsdf_find_or_insert(a.tab, ekey[e]);          /* new voxel or overflowed bucket */
-                if (!P[e]) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); ekey[e] = GSDF_KEY_EMPTY; L.key[tid + 256 * e] = GSDF_KEY_EMPTY; }
+                if (!P[e]) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); ekey[e] = GSDF_KEY_EMPTY; L.key[tid + FUSE_THREADS * e] = GSDF_KEY_EMPTY; }
             }
         }
-        unsigned int prev[NE];
+        __syncthreads();                                              /* the wait above is over (or timed out) */
+        const bool ordered = L.ordered != 0u;
+        if (ordered) {
+            unsigned long long q0[NE], q1[NE], q2[NE];
 #pragma unroll
-        for (int e = 0; e < NE; ++e) prev[e] = ekey[e] != GSDF_KEY_EMPTY ? atomicExch(&P[e]->aux, a.tag) : a.tag;
-        float2 ws[NE], gxy[NE];
-        float gzv[NE];
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            if (ekey[e] != GSDF_KEY_EMPTY && prev[e] != a.tag) {
-                const float2* q2 = reinterpret_cast<const float2*>(P[e]);
-                ws[e] = q2[0]; gxy[e] = q2[1]; gzv[e] = P[e]->gz;
+            for (int e = 0; e < NE; ++e) {
+                if (ekey[e] == GSDF_KEY_EMPTY) continue;
+                unsigned long long* q = reinterpret_cast<unsigned long long*>(P[e]);
+                q0[e] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q1[e] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                q2[e] = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        }
-        unsigned int my_defer = 0u;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            if (ekey[e] == GSDF_KEY_EMPTY) continue;
-            const int i = tid + 256 * e;
-            if (prev[e] != a.tag) {
-                /* owner for this launch: nobody else reads or writes w..gz until the kernel ends */
-                float2* q2 = reinterpret_cast<float2*>(P[e]);
-                ws[e].x += fix2f(L.w[i]); ws[e].y += fix2f(L.s[i]);
-                gxy[e].x += fix2f(L.gx[i]); gxy[e].y += fix2f(L.gy[i]);
-                gzv[e] += fix2f(L.gz[i]);
-                q2[0] = ws[e]; q2[1] = gxy[e]; P[e]->gz = gzv[e];
-                vis_mark(a, P[e], frame_cur);                 /* exactly one owner per touched voxel and launch */
-                L.key[i] = GSDF_KEY_EMPTY;
-            } else {
-                /* another tile owns the voxel: keep the entry, remember where it goes */
-                L.key[i] = FUSE_DEFER_BIT | (unsigned long long)(uintptr_t)P[e];   /* device pointers use < 2^57 */
+            for (int e = 0; e < NE; ++e) {
+                if (ekey[e] == GSDF_KEY_EMPTY) continue;
+                const int i = tid + FUSE_THREADS * e;
+                const float w = __uint_as_float((uint32_t)q0[e]) + fix2f(L.w[i]);
+                const float sd = __uint_as_float((uint32_t)(q0[e] >> 32)) + fix2f(L.s[i]);
+                const float gx = __uint_as_float((uint32_t)q1[e]) + fix2f(L.gx[i]);
+                const float gy = __uint_as_float((uint32_t)(q1[e] >> 32)) + fix2f(L.gy[i]);
+                const float gz = __uint_as_float((uint32_t)q2[e]) + fix2f(L.gz[i]);
+                unsigned long long* q = reinterpret_cast<unsigned long long*>(P[e]);
+                __hip_atomic_store(q, (unsigned long long)__float_as_uint(w) | ((unsigned long long)__float_as_uint(sd) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(gx) | ((unsigned long long)__float_as_uint(gy) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q + 2, (unsigned long long)__float_as_uint(gz) | ((unsigned long long)a.tag << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vis_mark(a, P[e], frame_cur);
+            }
+            /* hand the voxels on: every storing wave drains its stores, then ONE lane publishes the flag */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            /* near tile (or timed-out wait): everything goes through the deferred list */
+            unsigned int my_defer = 0u;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                if (ekey[e] == GSDF_KEY_EMPTY) continue;
+                L.key[tid + FUSE_THREADS * e] = FUSE_DEFER_BIT | (unsigned long long)(uintptr_t)P[e];   /* device pointers use < 2^57 */
+                vis_mark(a, P[e], frame_cur);
                 ++my_defer;
             }
-        }
-        if (my_defer) atomicAdd(&L.n_defer, my_defer);
-        __syncthreads();
-        if (L.n_defer) {
-            if (tid == 0) L.defer_base = atomicAdd(a.deferred_count, L.n_defer);   /* one global atomic per workgroup */
+            if (my_defer) atomicAdd(&L.n_defer, my_defer);
             __syncthreads();
-            if (tid == 0) L.n_defer = 0u;
-            __syncthreads();
-            for (int i = tid; i < FUSE_LCAP; i += 256) {
-                const unsigned long long key = L.key[i];
-                if (key == GSDF_KEY_EMPTY) continue;
-                const unsigned int o = L.defer_base + atomicAdd(&L.n_defer, 1u);
-                if (o >= a.deferred_cap) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); continue; }
-                gsdf_deferred d;
-                d.p = reinterpret_cast<gsdf_payload*>((uintptr_t)(key & ~FUSE_DEFER_BIT));
-                d.w = fix2f(L.w[i]); d.s = fix2f(L.s[i]); d.gx = fix2f(L.gx[i]); d.gy = fix2f(L.gy[i]); d.gz = fix2f(L.gz[i]);
-                d.pad = 0u;
-                a.deferred[o] = d;
+            if (L.n_defer) {
+                if (tid == 0) L.defer_base = atomicAdd(a.deferred_count, L.n_defer);   /* one global atomic per workgroup */
+                __syncthreads();
+                if (tid == 0) L.n_defer = 0u;
+                __syncthreads();
+                for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
+                    const unsigned long long key = L.key[i];
+                    if (key == GSDF_KEY_EMPTY) continue;
+                    const unsigned int o = L.defer_base + atomicAdd(&L.n_defer, 1u);
+                    if (o >= a.deferred_cap) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); continue; }
+                    gsdf_deferred d;
+                    d.p = reinterpret_cast<gsdf_payload*>((uintptr_t)(key & ~FUSE_DEFER_BIT));
+                    d.w = fix2f(L.w[i]); d.s = fix2f(L.s[i]); d.gx = fix2f(L.gx[i]); d.gy = fix2f(L.gy[i]); d.gz = fix2f(L.gz[i]);
+                    d.pad = 0u;
+                    a.deferred[o] = d;
+                }
             }
+            /* a timed-out tile still has to release the tiles that wait for it (it wrote nothing itself) */
+            if (tid == 0) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    } else if (tid == 0) {
+        __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     /* per-workgroup counters (plain stores into this workgroup's own row: no hot atomics) */
     const float wu = wave_sum(n_upd), wv = wave_sum(valid ? 1.f : 0.f);
-    if (lane == 0) { L.red[wave] = wu; L.red[4 + wave] = wv; }
+    if (lane == 0) { L.red[wave] = wu; L.red[8 + wave] = wv; }
     __syncthreads();
     if (tid == 0) {
-        const unsigned long long nu = (unsigned long long)(L.red[0] + L.red[1] + L.red[2] + L.red[3]);
-        const unsigned long long nv = blockIdx.z == 0 ? (unsigned long long)(L.red[4] + L.red[5] + L.red[6] + L.red[7]) : 0ull;
-        unsigned long long* c = a.blk_counters + 4 * (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        float su = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) su += L.red[i];
+        const unsigned long long nu = (unsigned long long)su;
+        const unsigned long long nv = (unsigned long long)(L.red[8] + L.red[9] + L.red[10] + L.red[11]);
+        unsigned long long* c = a.blk_counters + 4 * ((size_t)tile_y * a.ntx + tile_x);
         c[0] = nu; c[1] = nv; c[2] += nu; c[3] += nv;
-        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) a.st->frames += 1;   /* :120 increase_counter() */
+        if (tile_x == 0 && tile_y == 0) a.st->frames += 1;            /* :120 increase_counter() */
     }
 }
 
@@ -591,20 +702,27 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
                       int use_dev_pose, gsdf_table tab, gsdf_dev_state* st, unsigned long long* blk_counters,
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
-                      unsigned int tag, float* log_rows, long long max_rows, uint32_t* vis, int vis_words) {
+                      unsigned int tag, unsigned int* tile_flags, float* log_rows, long long max_rows, uint32_t* vis,
+                      int vis_words) {
     fuse_args a;
     a.vis = vis; a.vis_words = vis_words;
     a.debug = g_fuse_debug;
     a.g = g; a.nc = nc; a.depth = depth; a.nx = nx; a.ny = ny; a.nz = nz; a.pose = pose;
     a.use_dev_pose = use_dev_pose; a.tab = tab; a.st = st; a.blk_counters = blk_counters;
     a.deferred = deferred; a.deferred_count = deferred_count; a.deferred_cap = deferred_cap; a.tag = tag;
-    dim3 grid((g.W + FUSE_T - 1) / FUSE_T, (g.H + FUSE_T - 1) / FUSE_T, FUSE_ZSPLIT);
+    const int ntx = (g.W + FUSE_T - 1) / FUSE_T, nty = (g.H + FUSE_T - 1) / FUSE_T;
     gsdf_dev_state* gate = use_dev_pose ? st : nullptr;
-    hipLaunchKernelGGL(k_fuse, grid, dim3(256), 0, s, a);
+    a.tile_flags = tile_flags; a.ntx = ntx; a.nty = nty;
+    int n = 0;
+    for (int c = 0; c < 4; ++c) {                 /* colour-major numbering: a tile only waits for lower colours */
+        a.first[c] = n;
+        n += ((ntx - (c & 1) + 1) / 2) * ((nty - (c >> 1) + 1) / 2);
+    }
+    hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate,
                        use_dev_pose ? log_rows : nullptr, max_rows);
 }
-int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T) * FUSE_ZSPLIT; }
+int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T); }
 
 /* ------------------------------------------------------------------------------------------------
  * RigidPointOptimizer::optimize_sampled -- one Gauss-Newton pass per launch.

@@ -56,10 +56,8 @@ GSDF_HD gsdf_v3 gsdf_normalized3(gsdf_v3 n) {
 
 /* Sdf::weight -- sdf_tracker/Sdf.h:76-85 */
 GSDF_HD float gsdf_weight(float sdf, float T, float inv_T) {
-    float w = 0.f;
-    if (sdf <= 0.f) w = 1.f;
-    else if (sdf <= T) w = 1.f - sdf * inv_T;
-    return w;
+    const float ramp = 1.f - sdf * inv_T;
+    return sdf <= 0.f ? 1.f : (sdf <= T ? ramp : 0.f);     /* NaN -> 0, like the if-chain of the reference */
 }
 /* Sdf::truncate -- sdf_tracker/Sdf.h:72-74 */
 GSDF_HD float gsdf_truncate(float sdf, float T) { return fmaxf(-T, fminf(T, sdf)); }

@@ -1,0 +1,21 @@
+import sys, os
+import numpy as np
+sys.path.insert(0, "/root/repo")
+import __graft_entry__ as G
+pkg = G.package()
+n = 12
+seq = pkg.synth.Sequence("tum", 640, 480, n_frames=n, seed=0)
+vs = np.float32(0.01); T = np.float32(10) * vs
+frames = [seq.frame(i) for i in range(n)]
+g = pkg.GradSdf(vs, T, 640, 480, seq.K, capacity_log2=22)
+L = pkg.binding.load()
+L.gsdf_debug_flags(128)
+dev = [g.upload(f[0]) for f in frames]
+for i in range(n):
+    g.update_dev(dev[i], frames[i][1], frames[i][2])
+g.sync()
+st = g.stats()
+print("go per frame", st["n_hit"] / n, "wave-samples per frame", 1200 * 8 * 10.5, "ratio", st["n_hit"] / n / (1200 * 8 * 10.5))
+print("n_upd/frame", st["n_upd"] / n, "voxels", g.count())
+L.gsdf_debug_flags(0)
+g.close()
