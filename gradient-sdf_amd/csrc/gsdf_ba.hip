@@ -79,12 +79,12 @@ struct ba_args {
 struct ba_voxel { float dist, w; gsdf_v3 grad, gn, c; };
 
 __device__ __forceinline__ bool ba_load_voxel(const ba_args& a, size_t slot, ba_voxel* v) {
-    const gsdf_bucket* B = a.tab.buckets + (slot >> 2);
-    const unsigned long long key = B->key[slot & 3];
-    if (key == GSDF_KEY_EMPTY) return false;
-    const gsdf_payload p = B->pay[slot & 3];
+    const unsigned long long bk = a.tab.bkeys[slot / GSDF_BLOCK_VOX];
+    if (bk == GSDF_KEY_EMPTY) return false;
+    const gsdf_payload p = a.tab.vox[slot];
+    if (!(p.w > 0.f)) return false;                    /* the voxel exists iff w > 0 */
     int x, y, z;
-    gsdf_key_unpack(key, &x, &y, &z);
+    gsdf_key_unpack(gsdf_voxel_key(bk, (uint32_t)(slot % GSDF_BLOCK_VOX)), &x, &y, &z);
     v->w = p.w; v->dist = p.s / p.w;
     v->grad = gsdf_v3{ p.gx, p.gy, p.gz };
     v->gn = gsdf_normalized3(v->grad);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_ba_dist(ba_args a, float damping) {
         H_dd += a.reg_weight * v.w;                                            /* :383 */
         if (H_dd != 0.f) {
             /* updateDist: dist -= delta (:265-268); the table stores s = dist * w */
-            gsdf_payload* P = &a.tab.buckets[slot >> 2].pay[slot & 3];
+            gsdf_payload* P = &a.tab.vox[slot];
             P->s = (v.dist - damping * b_d / H_dd) * v.w;
         }
     }

@@ -263,7 +263,8 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
     c->n_slots = (size_t)1 << capacity_log2;
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipMalloc((void**)&c->tab.buckets, (c->n_slots / GSDF_BUCKET) * sizeof(gsdf_bucket))) != hipSuccess ||
+        (e = hipMalloc((void**)&c->tab.vox, c->n_slots * sizeof(gsdf_payload))) != hipSuccess ||
+        (e = hipMalloc((void**)&c->tab.bkeys, (c->n_slots / GSDF_BLOCK_VOX) * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void**)&c->st, sizeof(gsdf_dev_state))) != hipSuccess ||
         (e = hipMalloc((void**)&c->counter, sizeof(unsigned long long))) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
@@ -271,7 +272,7 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         gsdf_destroy(c);
         return fail(GSDF_ERR_HIP, m);
     }
-    c->tab.bucket_mask = (uint32_t)(c->n_slots / GSDF_BUCKET - 1);
+    c->tab.block_mask = (uint32_t)(c->n_slots / GSDF_BLOCK_VOX - 1);
     {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
@@ -296,7 +297,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    void* ptrs[] = { c->tab.buckets, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
+    void* ptrs[] = { c->tab.vox, c->tab.bkeys, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->tile_flags, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
     for (void* p : ptrs) if (p) (void)hipFree(p);

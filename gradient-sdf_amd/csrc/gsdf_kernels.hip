@@ -67,19 +67,16 @@ __device__ __forceinline__ int reflect101(int i, int n) {      /* cv::BORDER_REF
 /* ------------------------------------------------------------------------------------------------
  * table clear: keys = EMPTY, payloads = 0 (so an insert never has to initialise a payload)
  * ---------------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__(256) void k_table_clear(gsdf_bucket* buckets, size_t n_buckets) {
-    /* 8 lanes per 128-byte bucket, one 16-byte store each: fully coalesced */
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_table_clear(gsdf_table tab, size_t n_blocks) {
+    /* voxel records: 2 lanes per 32-byte record, one 16-byte store each; then the block keys */
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t n16 = n_buckets * 8;
-    uint4* p = reinterpret_cast<uint4*>(buckets);
-    for (; i < n16; i += stride) {
-        const uint32_t v = (i & 7) < 2 ? 0xFFFFFFFFu : 0u;
-        p[i] = make_uint4(v, v, v, v);
-    }
+    const size_t n16 = n_blocks * GSDF_BLOCK_VOX * 2;
+    uint4* p = reinterpret_cast<uint4*>(tab.vox);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += stride) tab.bkeys[i] = GSDF_KEY_EMPTY;
 }
 void gsdf_launch_table_clear(hipStream_t s, gsdf_table tab, size_t n_slots) {
-    hipLaunchKernelGGL(k_table_clear, dim3(2048), dim3(256), 0, s, tab.buckets, n_slots / GSDF_BUCKET);
+    hipLaunchKernelGGL(k_table_clear, dim3(2048), dim3(256), 0, s, tab, n_slots / GSDF_BLOCK_VOX);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -307,8 +304,7 @@ __device__ __forceinline__ void defer_append(const fuse_args& a, gsdf_payload* p
 /* vis_[vi]: resize(counter_), push_back(true) -- MapGradPixelSdf.cpp:113-115: set bit `frame` of the voxel */
 __device__ __forceinline__ void vis_mark(const fuse_args& a, const gsdf_payload* p, long long frame) {
     if (!a.vis || frame >= 32ll * a.vis_words) return;
-    const size_t off = (size_t)((const char*)p - (const char*)a.tab.buckets);
-    const size_t slot = (off >> 7) * GSDF_BUCKET + ((off & 127) - 32) / sizeof(gsdf_payload);
+    const size_t slot = (size_t)(p - a.tab.vox);
     atomicOr(&a.vis[slot * a.vis_words + (frame >> 5)], 1u << (frame & 31));
 }
 
@@ -532,23 +528,20 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
     __syncthreads();
     if (!(a.debug & 1)) {
         constexpr int NE = FUSE_LCAP / FUSE_THREADS;
-        unsigned long long ekey[NE];
-        gsdf_bucket* B[NE];
-        ulonglong2 k01[NE], k23[NE];
+        unsigned long long ekey[NE], bkey[NE], k0[NE];
+        uint32_t home[NE];
         gsdf_payload* P[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             ekey[e] = L.key[tid + FUSE_THREADS * e];
-            B[e] = a.tab.buckets + (gsdf_hash(ekey[e]) & a.tab.bucket_mask);
+            bkey[e] = gsdf_block_key(ekey[e]);
+            home[e] = gsdf_hash(bkey[e]) & a.tab.block_mask;
             P[e] = nullptr;
+            k0[e] = GSDF_KEY_EMPTY;
         }
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            if (ekey[e] != GSDF_KEY_EMPTY) {
-                k01[e] = *reinterpret_cast<const ulonglong2*>(&B[e]->key[0]);
-                k23[e] = *reinterpret_cast<const ulonglong2*>(&B[e]->key[2]);
-            }
-        }
+        for (int e = 0; e < NE; ++e)
+            if (ekey[e] != GSDF_KEY_EMPTY) k0[e] = a.tab.bkeys[home[e]];         /* 512 KB of block keys: L2 hits */
         /* meanwhile one wave waits for the adjacent tiles of lower colour (lane j watches neighbour j) */
         if (wave == 0 && L.ordered) {
             bool need = false;
@@ -576,15 +569,10 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             if (ekey[e] == GSDF_KEY_EMPTY) continue;
-            /* voxel already in its home bucket: the common case after the first frames */
-            if (k01[e].x == ekey[e]) P[e] = &B[e]->pay[0];
-            else if (k01[e].y == ekey[e]) P[e] = &B[e]->pay[1];
-            else if (k23[e].x == ekey[e]) P[e] = &B[e]->pay[2];
-            else if (k23[e].y == ekey[e]) P[e] = &B[e]->pay[3];
-            else {
-                P[e] = gsdf_find_or_insert(a.tab, ekey[e]);          /* new voxel or overflowed bucket */
-                if (!P[e]) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); ekey[e] = GSDF_KEY_EMPTY; L.key[tid + FUSE_THREADS * e] = GSDF_KEY_EMPTY; }
-            }
+            /* block already at its home entry: the common case; else probe on / insert the block */
+            const int b = k0[e] == bkey[e] ? (int)home[e] : gsdf_block_find_or_insert(a.tab, bkey[e], home[e], k0[e]);
+            if (b < 0) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); ekey[e] = GSDF_KEY_EMPTY; L.key[tid + FUSE_THREADS * e] = GSDF_KEY_EMPTY; }
+            else P[e] = a.tab.vox + ((size_t)b * GSDF_BLOCK_VOX + gsdf_block_local(ekey[e]));
         }
         __syncthreads();                                              /* the wait above is over (or timed out) */
         const bool ordered = L.ordered != 0u;
@@ -885,12 +873,11 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
             ok[j] = pix < N;
             z[j] = ok[j] ? depth[pix] : 0.f;
         }
-        /* stage B: back-project, voxel key, the 4 keys of the home bucket (one 128-byte line) */
+        /* stage B: back-project, voxel key, block key at the home entry (L2-resident key array) */
         gsdf_v3 p[TRK_PPT];
         int vx[TRK_PPT], vy[TRK_PPT], vz[TRK_PPT];
-        unsigned long long key[TRK_PPT];
-        const gsdf_bucket* B[TRK_PPT];
-        ulonglong2 k01[TRK_PPT], k23[TRK_PPT];
+        unsigned long long key[TRK_PPT], bkey[TRK_PPT], k0[TRK_PPT];
+        uint32_t home[TRK_PPT];
 #pragma unroll
         for (int j = 0; j < TRK_PPT; ++j) {
             const int pix = base + j * nthreads;
@@ -906,27 +893,19 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
             vz[j] = gsdf_float2vox1(g.inv_vs, p[j].z);
             ok[j] = ok[j] && gsdf_key_in_range(vx[j], vy[j], vz[j]);
             key[j] = gsdf_key_pack(vx[j], vy[j], vz[j]);
-            B[j] = tab.buckets + (gsdf_hash(key[j]) & tab.bucket_mask);
-            if (ok[j]) {
-                k01[j] = *reinterpret_cast<const ulonglong2*>(&B[j]->key[0]);
-                k23[j] = *reinterpret_cast<const ulonglong2*>(&B[j]->key[2]);
-            } else {
-                k01[j] = make_ulonglong2(GSDF_KEY_EMPTY, GSDF_KEY_EMPTY);
-                k23[j] = k01[j];
-            }
+            bkey[j] = gsdf_block_key(key[j]);
+            home[j] = gsdf_hash(bkey[j]) & tab.block_mask;
+            k0[j] = ok[j] ? tab.bkeys[home[j]] : GSDF_KEY_EMPTY;
         }
-        /* stage C: payload of the hit (same line as the keys) */
+        /* stage C: the voxel record (neighbouring pixels share lines: 4 x-adjacent voxels per line) */
         const gsdf_payload* P[TRK_PPT];
         float2 pa[TRK_PPT], pb[TRK_PPT], pc2[TRK_PPT];
 #pragma unroll
         for (int j = 0; j < TRK_PPT; ++j) {
             P[j] = nullptr;
             if (ok[j]) {
-                if (k01[j].x == key[j]) P[j] = &B[j]->pay[0];
-                else if (k01[j].y == key[j]) P[j] = &B[j]->pay[1];
-                else if (k23[j].x == key[j]) P[j] = &B[j]->pay[2];
-                else if (k23[j].y == key[j]) P[j] = &B[j]->pay[3];
-                else if (k23[j].y != GSDF_KEY_EMPTY) P[j] = gsdf_find(tab, key[j]);   /* full bucket: probe on (rare) */
+                const int b = k0[j] == bkey[j] ? (int)home[j] : gsdf_block_find(tab, bkey[j], home[j], k0[j]);
+                if (b >= 0) P[j] = tab.vox + ((size_t)b * GSDF_BLOCK_VOX + gsdf_block_local(key[j]));
             }
             if (P[j]) {
                 const float2* q = reinterpret_cast<const float2*>(P[j]);
@@ -1004,10 +983,11 @@ __global__ __launch_bounds__(256) void k_export(gsdf_table tab, size_t n_slots, 
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n_slots; i += stride) {
-        const gsdf_bucket* B = tab.buckets + (i >> 2);
-        const unsigned long long key = B->key[i & 3];
-        if (key == GSDF_KEY_EMPTY) continue;
-        const gsdf_payload sl = B->pay[i & 3];
+        const unsigned long long bk = tab.bkeys[i / GSDF_BLOCK_VOX];      /* one block per wavefront */
+        if (bk == GSDF_KEY_EMPTY) continue;
+        const gsdf_payload sl = tab.vox[i];
+        if (!(sl.w > 0.f)) continue;                                      /* the voxel exists iff w > 0 */
+        const unsigned long long key = gsdf_voxel_key(bk, (uint32_t)(i % GSDF_BLOCK_VOX));
         const unsigned long long o = atomicAdd(counter, 1ull);
         if ((long long)o >= max_n) continue;
         if (keys_out) keys_out[o] = key;
@@ -1044,10 +1024,11 @@ __global__ __launch_bounds__(256) void k_export_raw(gsdf_table tab, size_t n_slo
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n_slots; i += stride) {
-        const gsdf_bucket* B = tab.buckets + (i >> 2);
-        const unsigned long long key = B->key[i & 3];
-        if (key == GSDF_KEY_EMPTY) continue;
-        const gsdf_payload sl = B->pay[i & 3];
+        const unsigned long long bk = tab.bkeys[i / GSDF_BLOCK_VOX];
+        if (bk == GSDF_KEY_EMPTY) continue;
+        const gsdf_payload sl = tab.vox[i];
+        if (!(sl.w > 0.f)) continue;
+        const unsigned long long key = gsdf_voxel_key(bk, (uint32_t)(i % GSDF_BLOCK_VOX));
         const unsigned long long o = atomicAdd(counter, 1ull);
         if ((long long)o >= max_n) continue;
         int x, y, z;
@@ -1081,7 +1062,7 @@ __global__ __launch_bounds__(256) void k_query(gsdf_table tab, float vs, float i
         gsdf_v3 og = { 0.f, 0.f, 0.f };
         if (gsdf_key_in_range(vx, vy, vz)) {
             const gsdf_payload* sl = gsdf_find(tab, gsdf_key_pack(vx, vy, vz));
-            if (sl) {
+            if (sl && sl->w > 0.f) {
                 ow = sl->w;
                 const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ sl->gx, sl->gy, sl->gz });
                 og = gsdf_v3{ 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };

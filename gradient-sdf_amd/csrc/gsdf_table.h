@@ -4,22 +4,31 @@
  * Replaces the reference's two CPU containers
  *   tsdf_ : phmap::parallel_node_hash_map<Vector3i, SdfVoxel>   (MapGradPixelSdf.h:65-68)
  *   vis_  : phmap::parallel_flat_hash_map<Vec3i, vector<bool>>  (MapGradPixelSdf.h:70)
- * with ONE open-addressed table of 128-byte buckets (= one HBM / L2 line) of 4 voxels:
+ * with a hash map of 4x4x4 VOXEL BLOCKS (the surface band is ~21 voxels thick, so blocks that exist
+ * are ~70 % full):
  *
- *   +0   u64 key[4]     x,y,z + 2^20 packed 21 bits each (x low, z high); ~0 = empty
- *   +32  payload[4]     6 x 4 bytes each:
+ *   bkeys[n_blocks]      u64 block key: (x>>2, y>>2, z>>2) + 2^18, 19 bits each (x low); ~0 = empty.
+ *                        Open addressing, double hashing; entry i owns block i.  65536 blocks (the
+ *                        2^22-voxel default) = 512 KB of keys: the probe runs out of the L2.
+ *                        Capacity: 2^c voxel records = 2^(c-6) blocks; a surface map fills its blocks to
+ *                        ~70 %, random-depth clutter to ~30 %; TABLE_FULL is reported when a probe
+ *                        sequence of GSDF_MAX_PROBE entries finds no room (block load > ~0.95).
+ *   vox[n_blocks * 64]   32-byte voxel records, index = block * 64 + (x&3 | (y&3)<<2 | (z&3)<<4):
  *          f32 w          sum of weights                      (SdfVoxel::weight)
  *          f32 s          sum of w * truncated sdf            (SdfVoxel::dist  = s / w)
  *          f32 gx,gy,gz   sum of w * R n                      (SdfVoxel::grad)
- *          u32 aux        index+1 of the last frame that touched the voxel (vis_ stand-in,
- *                         and the per-frame ownership tag of the fusion flush)
+ *          u32 aux        serial of the last fusion launch that wrote the voxel
+ *          u32 pad[2]
+ *                        4 x-adjacent voxels share a 128-byte line, a block is 16 consecutive lines.
  *
- * A probe reads the 4 keys of a bucket with two 16-byte loads of ONE line (coalesced probe);
- * the payload of a hit sits in the same line.  Probing is linear over buckets; a capacity of
- * 2^c "slots" means 2^(c-2) buckets.  The running mean of the reference
- * (MapGradPixelSdf.cpp:111) equals s / w, so storing the additive sums makes fusion
- * order-free (atomics) and shard-mergeable.  Packed keys order like (z, y, x), the order
- * exports are sorted in.
+ * A voxel EXISTS iff its w > 0: the reference creates tsdf_[vi] only for a sample with w > 0
+ * (MapGradPixelSdf.cpp:108-109), weights are positive and only ever added, and records are zeroed by
+ * the table clear.  The running mean of the reference (MapGradPixelSdf.cpp:111) equals s / w, so
+ * storing the additive sums makes fusion order-free and shard-mergeable.
+ *
+ * Why blocks: a camera tile touches ~1000 voxels per frame but only ~50 blocks and ~400 lines, so
+ * the fusion flush and the tracker's gather move 2.6x fewer lines than with per-voxel hashing, the
+ * key probe is an L2 hit, and full-map sweeps (export, PhotoBA) stream dense memory.
  */
 #ifndef GSDF_TABLE_H_
 #define GSDF_TABLE_H_
@@ -30,27 +39,26 @@
 #define GSDF_KEY_EMPTY   0xFFFFFFFFFFFFFFFFull
 #define GSDF_KEY_OFF     (1 << 20)
 #define GSDF_KEY_MASK    0x1FFFFFull
-#define GSDF_BUCKET      4            /* voxels per 128-byte bucket */
-#define GSDF_MAX_PROBE   128          /* buckets probed before reporting TABLE_FULL */
+#define GSDF_BLOCK_VOX   64           /* voxels per 4x4x4 block */
+#define GSDF_MAX_PROBE   1024         /* block keys probed before reporting TABLE_FULL */
 
-struct gsdf_payload {
+struct __attribute__((aligned(32))) gsdf_payload {
     float w, s, gx, gy, gz;
     uint32_t aux;
-};
-struct __attribute__((aligned(128))) gsdf_bucket {
-    unsigned long long key[GSDF_BUCKET];
-    gsdf_payload pay[GSDF_BUCKET];
+    uint32_t pad[2];
 };
 
 struct gsdf_table {
-    gsdf_bucket* buckets;
-    uint32_t bucket_mask;             /* number of buckets - 1 */
+    unsigned long long* bkeys;        /* [block_mask + 1] */
+    gsdf_payload* vox;                /* [(block_mask + 1) * 64] */
+    uint32_t block_mask;              /* number of blocks - 1 (power of two) */
 };
 
 __host__ __device__ __forceinline__ bool gsdf_key_in_range(int x, int y, int z) {
     return x >= -GSDF_KEY_OFF && x < GSDF_KEY_OFF && y >= -GSDF_KEY_OFF && y < GSDF_KEY_OFF &&
            z >= -GSDF_KEY_OFF && z < GSDF_KEY_OFF;
 }
+/* packed VOXEL key: x,y,z + 2^20, 21 bits each (x low, z high); orders like (z, y, x), the export order */
 __host__ __device__ __forceinline__ unsigned long long gsdf_key_pack(int x, int y, int z) {
     return (unsigned long long)(uint32_t)(x + GSDF_KEY_OFF) |
            ((unsigned long long)(uint32_t)(y + GSDF_KEY_OFF) << 21) |
@@ -61,56 +69,81 @@ __host__ __device__ __forceinline__ void gsdf_key_unpack(unsigned long long k, i
     *y = (int)((k >> 21) & GSDF_KEY_MASK) - GSDF_KEY_OFF;
     *z = (int)((k >> 42) & GSDF_KEY_MASK) - GSDF_KEY_OFF;
 }
+/* block key and in-block index of a packed voxel key (the 2^20 bias is a multiple of 4: floor semantics) */
+__host__ __device__ __forceinline__ unsigned long long gsdf_block_key(unsigned long long k) {
+    return ((k >> 2) & 0x7FFFFull) | (((k >> 23) & 0x7FFFFull) << 19) | (((k >> 44) & 0x7FFFFull) << 38);
+}
+__host__ __device__ __forceinline__ uint32_t gsdf_block_local(unsigned long long k) {
+    return (uint32_t)(k & 3ull) | ((uint32_t)((k >> 21) & 3ull) << 2) | ((uint32_t)((k >> 42) & 3ull) << 4);
+}
+/* packed voxel key of voxel `local` of the block with key `bk` */
+__host__ __device__ __forceinline__ unsigned long long gsdf_voxel_key(unsigned long long bk, uint32_t local) {
+    const unsigned long long ux = ((bk & 0x7FFFFull) << 2) | (local & 3u);
+    const unsigned long long uy = (((bk >> 19) & 0x7FFFFull) << 2) | ((local >> 2) & 3u);
+    const unsigned long long uz = (((bk >> 38) & 0x7FFFFull) << 2) | ((local >> 4) & 3u);
+    return ux | (uy << 21) | (uz << 42);
+}
 /* hash choice is free: std::hash<Vec3i> (hash_map.h:44-52) only fixes phmap's iteration order */
-__host__ __device__ __forceinline__ uint32_t gsdf_hash(unsigned long long k) {
+__host__ __device__ __forceinline__ unsigned long long gsdf_hash64(unsigned long long k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
     k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
     k ^= k >> 33;
-    return (uint32_t)k;
+    return k;
+}
+__host__ __device__ __forceinline__ uint32_t gsdf_hash(unsigned long long k) { return (uint32_t)gsdf_hash64(k); }
+/* probe step of a block key: odd, so the sequence h, h + step, h + 2 step, ... visits every entry */
+__host__ __device__ __forceinline__ uint32_t gsdf_probe_step(unsigned long long bk) {
+    return (uint32_t)(gsdf_hash64(bk) >> 32) | 1u;
 }
 
 #if defined(__HIPCC__)
-/* tsdf_[vi] (operator[]: find, insert zero-initialised if absent) -- MapGradPixelSdf.cpp:109.
- * Returns the payload slot or nullptr when the probe budget is exhausted.  Keys never change
- * once written and payloads are zeroed by the table clear, so the 4 keys are read with plain
- * 16-byte loads: a stale read can only show EMPTY, and then the CAS is authoritative. */
-__device__ __forceinline__ gsdf_payload* gsdf_find_or_insert(const gsdf_table& T, unsigned long long key) {
-    uint32_t b = gsdf_hash(key) & T.bucket_mask;
+/* Block lookup with insertion; `first` is the key already loaded from the home entry `h` (callers
+ * load it early to overlap the round trip).  Keys never change once written and records are zeroed by
+ * the table clear, so keys are read with plain loads: a stale read can only show EMPTY, and then the
+ * CAS is authoritative.  Returns the block index or -1 when the probe budget is exhausted. */
+__device__ __forceinline__ int gsdf_block_find_or_insert(const gsdf_table& T, unsigned long long bk, uint32_t h,
+                                                         unsigned long long first) {
+    unsigned long long k = first;
+    const uint32_t step = gsdf_probe_step(bk);
     for (int probe = 0; probe < GSDF_MAX_PROBE; ++probe) {
-        gsdf_bucket* B = T.buckets + b;
-        const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&B->key[0]);
-        const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&B->key[2]);
-        const unsigned long long ks[4] = { k01.x, k01.y, k23.x, k23.y };
-#pragma unroll
-        for (int j = 0; j < GSDF_BUCKET; ++j) {
-            unsigned long long k = ks[j];
-            if (k == GSDF_KEY_EMPTY) {
-                k = atomicCAS(&B->key[j], GSDF_KEY_EMPTY, key);
-                if (k == GSDF_KEY_EMPTY) return &B->pay[j];
-            }
-            if (k == key) return &B->pay[j];
+        if (k == GSDF_KEY_EMPTY) {
+            k = atomicCAS(&T.bkeys[h], GSDF_KEY_EMPTY, bk);
+            if (k == GSDF_KEY_EMPTY) return (int)h;
         }
-        b = (b + 1) & T.bucket_mask;
+        if (k == bk) return (int)h;
+        h = (h + step) & T.block_mask;
+        k = T.bkeys[h];
     }
-    return nullptr;
+    return -1;
+}
+__device__ __forceinline__ int gsdf_block_find(const gsdf_table& T, unsigned long long bk, uint32_t h,
+                                               unsigned long long first) {
+    unsigned long long k = first;
+    const uint32_t step = gsdf_probe_step(bk);
+    for (int probe = 0; probe < GSDF_MAX_PROBE; ++probe) {
+        if (k == bk) return (int)h;
+        if (k == GSDF_KEY_EMPTY) return -1;           /* entries are never freed: an empty one ends the chain */
+        h = (h + step) & T.block_mask;
+        k = T.bkeys[h];
+    }
+    return -1;
 }
 
-/* tsdf_.find(idx) -- MapGradPixelSdf.h:119.  Read-only kernels only. */
+/* tsdf_[vi] (operator[]: find, insert zero-initialised if absent) -- MapGradPixelSdf.cpp:109.
+ * `key` is the packed voxel key.  nullptr when the table is full. */
+__device__ __forceinline__ gsdf_payload* gsdf_find_or_insert(const gsdf_table& T, unsigned long long key) {
+    const unsigned long long bk = gsdf_block_key(key);
+    const uint32_t h = gsdf_hash(bk) & T.block_mask;
+    const int b = gsdf_block_find_or_insert(T, bk, h, T.bkeys[h]);
+    return b < 0 ? nullptr : T.vox + ((size_t)b * GSDF_BLOCK_VOX + gsdf_block_local(key));
+}
+/* tsdf_.find(idx) -- MapGradPixelSdf.h:119.  nullptr when the block does not exist; the caller
+ * tests w > 0 for the voxel itself. */
 __device__ __forceinline__ const gsdf_payload* gsdf_find(const gsdf_table& T, unsigned long long key) {
-    uint32_t b = gsdf_hash(key) & T.bucket_mask;
-    for (int probe = 0; probe < GSDF_MAX_PROBE; ++probe) {
-        const gsdf_bucket* B = T.buckets + b;
-        const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(&B->key[0]);
-        const ulonglong2 k23 = *reinterpret_cast<const ulonglong2*>(&B->key[2]);
-        if (k01.x == key) return &B->pay[0];
-        if (k01.y == key) return &B->pay[1];
-        if (k23.x == key) return &B->pay[2];
-        if (k23.y == key) return &B->pay[3];
-        /* slots fill in order and are never freed: an empty slot ends the probe sequence */
-        if (k23.y == GSDF_KEY_EMPTY) return nullptr;
-        b = (b + 1) & T.bucket_mask;
-    }
-    return nullptr;
+    const unsigned long long bk = gsdf_block_key(key);
+    const uint32_t h = gsdf_hash(bk) & T.block_mask;
+    const int b = gsdf_block_find(T, bk, h, T.bkeys[h]);
+    return b < 0 ? nullptr : T.vox + ((size_t)b * GSDF_BLOCK_VOX + gsdf_block_local(key));
 }
 #endif
 

@@ -230,7 +230,7 @@ def test_edge_frames_empty_invalid_and_ragged(pkg, O):
     W, H = 77, 45
     K = pkg.synth.intrinsics(W, H)
     vs = np.float32(0.02)
-    g = pkg.GradSdf(vs, np.float32(0.1), W, H, K, capacity_log2=16)
+    g = pkg.GradSdf(vs, np.float32(0.1), W, H, K, capacity_log2=18)
     o = O.Oracle(vs, np.float32(0.1), W, H, K)
     zero = np.zeros((H, W), np.float32)
     g.update(zero, np.eye(3), np.zeros(3))
@@ -262,7 +262,7 @@ def test_fusion_keys_bit_exact_random_poses(pkg, O, seed):
     seq = pkg.synth.Sequence("tum", W, H, n_frames=1, seed=seed)
     vs = np.float32(0.015)
     T = np.float32(7) * vs
-    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=19)
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=21)
     o = O.Oracle(vs, T, W, H, seq.K)
     d, _, _ = seq.frame(0)
     for _ in range(3):
