@@ -34,6 +34,7 @@ static int fail(int code, const std::string& msg) {
             return fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
+extern int g_fuse_debug;                          /* experiment switches, see gsdf_debug_flags */
 struct gsdf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -199,6 +200,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     if (tp.serial == 0) tp.serial = c->track_serial = 1;
     const bool adaptive = c->adaptive && c->progress;
     tp.progress = adaptive ? c->progress_dev : nullptr;
+    tp.debug = g_fuse_debug >> 8;
     /* launches 0..iters-1 gather; launch k>0 first finishes pass k-1 (reduce, solve, update); launch
      * `iters` is head-only and finishes the last pass */
     for (int k = 0; k <= iters; ++k) {
@@ -235,7 +237,6 @@ int read_state(gsdf_ctx* c, gsdf_dev_state* out) {
 extern "C" {
 
 const char* gsdf_last_error(void) { return g_err.c_str(); }
-extern int g_fuse_debug;
 /* experiment switch for kernel ablations (tools/); not part of include/gsdf.h */
 void gsdf_debug_flags(int flags) { g_fuse_debug = flags; }
 const char* gsdf_version(void) { return "gsdf-mi355x 0.1 (gfx950)"; }
@@ -354,8 +355,9 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipMalloc((void**)&c->tile_flags, (size_t)c->fuse_blocks * sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(c->tile_flags, 0, (size_t)c->fuse_blocks * sizeof(unsigned int), c->stream));
-    /* deferred list: contributions to voxels owned by another tile; bounded by the samples of a frame */
-    c->deferred_cap = (unsigned int)std::min<size_t>((size_t)1 << 24, std::max<size_t>((size_t)1 << 18, N * 8));
+    /* deferred list: contributions of near tiles and LDS overflow; bounded by the samples of a frame */
+    c->deferred_cap = (unsigned int)std::min<size_t>((size_t)1 << 26, std::max<size_t>((size_t)1 << 18,
+                                                     N * (size_t)(2 * c->factor + 1)));   /* every sample of a frame */
     HIP_TRY(hipMalloc((void**)&c->deferred, (size_t)c->deferred_cap * sizeof(gsdf_deferred)));
     HIP_TRY(hipMalloc((void**)&c->deferred_count, sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(c->deferred_count, 0, sizeof(unsigned int), c->stream));

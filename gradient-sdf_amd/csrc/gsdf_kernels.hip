@@ -265,8 +265,11 @@ struct fuse_lds {
     unsigned long long w[FUSE_LCAP], s[FUSE_LCAP], gx[FUSE_LCAP], gy[FUSE_LCAP], gz[FUSE_LCAP];
     float red[16];
     unsigned int n_defer, defer_base;
-    unsigned int zmin_bits;             /* smallest valid depth of the tile (float bits) */
+    unsigned int st_min[4], st_max[4];  /* per wave: smallest / largest valid depth (float bits) */
+    float st_cnt[4];                    /* per wave: valid pixels */
     unsigned int ordered;               /* flush with plain read-modify-write (1) or through the deferred list (0) */
+    const float* plane[7];              /* depth, x0, y0, 1/n2, nx, ny, nz: read from here by the band reloads, so the
+                                           seven pointers do not stay in scalar registers across the ray walk */
 };
 
 /* float -> signed 2^-40 fixed point for |x| < 2048: x + 1.5*2^12 in double has its last mantissa bit at
@@ -309,15 +312,10 @@ __device__ __forceinline__ void vis_mark(const fuse_args& a, const gsdf_payload*
 }
 
 int g_fuse_debug = 0;
-__global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
+__global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 waves per SIMD = 2 workgroups per CU */
     __shared__ fuse_lds L;
     if (a.use_dev_pose && !a.st->converged) return;        /* main_scan_3d.cpp:261: if (conv) update */
     const int tid = threadIdx.x;
-    for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
-        L.key[i] = GSDF_KEY_EMPTY;
-        L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
-    }
-    if (tid == 0) { L.n_defer = 0u; L.defer_base = 0u; L.zmin_bits = 0x7F800000u; }
     float R[9], t[3];
     if (a.use_dev_pose) {
 #pragma unroll
@@ -330,7 +328,6 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) t[i] = a.pose.t[i];
     }
-    __syncthreads();
 
     const gsdf_frame_geom& g = a.g;
     const long long frame_cur = a.vis ? a.st->frame_cur : 0;   /* Sdf::counter_ of this update (snapshot by k_normals) */
@@ -342,43 +339,107 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
     const int ntx_c = (a.ntx - (col & 1) + 1) >> 1;
     const int tile_x = 2 * ((bid - a.first[col]) % ntx_c) + (col & 1);
     const int tile_y = 2 * ((bid - a.first[col]) / ntx_c) + (col >> 1);
-    const int px = tile_x * FUSE_T + (wave & 1) * 8 + lx;
-    const int py = tile_y * FUSE_T + ((wave >> 1) & 1) * 8 + ly;
-    bool valid = px < g.W && py < g.H;
+    bool valid = false;
     float z = 0.f;
     gsdf_v3 Rxy = { 0.f, 0.f, 0.f }, Rn = { 0.f, 0.f, 0.f };
-    if (valid) {
-        const size_t idx = (size_t)py * g.W + px;
-        z = a.depth[idx];
-        valid = !(z <= g.zmin || z >= g.zmax);                             /* MapGradPixelSdf.cpp:87 */
+    auto load_pixel = [&](int px, int py, const float* dp, const float* x0p, const float* y0p, const float* nip,
+                          const float* nxp, const float* nyp, const float* nzp) {
+        valid = px < g.W && py < g.H;
+        z = 0.f;
         if (valid) {
-            const gsdf_v3 xy = { a.nc.x0[idx], a.nc.y0[idx], 1.f };        /* :90 */
-            const gsdf_v3 n = { a.nx[idx], a.ny[idx], a.nz[idx] };         /* :92 */
-            Rxy = gsdf_matvec(R, xy);                                      /* :91 */
-            Rn = gsdf_matvec(R, n);                                        /* :93 */
-            if ((double)gsdf_dot3(n, n) < .1) valid = false;               /* :95 */
-            const float nd = gsdf_dot3(n, xy);
-            if (nd * nd * a.nc.ninv[idx] < .25) valid = false;             /* :98 */
+            const size_t idx = (size_t)py * g.W + px;
+            z = dp[idx];
+            valid = !(z <= g.zmin || z >= g.zmax);                         /* MapGradPixelSdf.cpp:87 */
+            if (valid) {
+                const gsdf_v3 xy = { x0p[idx], y0p[idx], 1.f };            /* :90 */
+                const gsdf_v3 n = { nxp[idx], nyp[idx], nzp[idx] };        /* :92 */
+                Rxy = gsdf_matvec(R, xy);                                  /* :91 */
+                Rn = gsdf_matvec(R, n);                                    /* :93 */
+                if ((double)gsdf_dot3(n, n) < .1) valid = false;           /* :95 */
+                const float nd = gsdf_dot3(n, xy);
+                if (nd * nd * nip[idx] < .25) valid = false;               /* :98 */
+            }
         }
+    };
+    /* the common case is one band: load its pixels now, the loads overlap the table clear */
+    load_pixel(tile_x * FUSE_T + (wave & 1) * 8 + lx, tile_y * FUSE_T + ((wave >> 1) & 1) * 8 + ly,
+               a.depth, a.nc.x0, a.nc.y0, a.nc.ninv, a.nx, a.ny, a.nz);
+    /* meanwhile: empty table */
+    for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
+        L.key[i] = GSDF_KEY_EMPTY;
+        L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
     }
-    /* smallest valid depth of the tile: decides below whether the flush needs the ownership atomics */
+    if (tid == 0) {
+        L.n_defer = 0u; L.defer_base = 0u;
+        L.plane[0] = a.depth; L.plane[1] = a.nc.x0; L.plane[2] = a.nc.y0; L.plane[3] = a.nc.ninv;
+        L.plane[4] = a.nx; L.plane[5] = a.ny; L.plane[6] = a.nz;
+    }
+    /* depth range of the tile and the number of valid pixels: one entry per wave of the first half */
     if (zhalf == 0) {
-        unsigned int zb = valid ? __float_as_uint(z) : 0x7F800000u;
+        unsigned int zb = valid ? __float_as_uint(z) : 0x7F800000u, zt = valid ? __float_as_uint(z) : 0u;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const unsigned int other = __shfl_xor(zb, o); zb = other < zb ? other : zb; }
-        if (lane == 0) atomicMin(&L.zmin_bits, zb);
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned int o1 = __shfl_xor(zb, o), o2 = __shfl_xor(zt, o);
+            zb = o1 < zb ? o1 : zb; zt = o2 > zt ? o2 : zt;
+        }
+        const float cnt = wave_sum(valid ? 1.f : 0.f);
+        if (lane == 0) { L.st_min[wave] = zb; L.st_max[wave] = zt; L.st_cnt[wave] = cnt; }
     }
-    /* this half-workgroup's share of the ray walk k = -factor..factor (:101); the order is free (sums) */
+    __syncthreads();
     const int nk_all = 2 * g.factor + 1;
-    const int k_lo = -g.factor + (int)((zhalf * nk_all) / FUSE_ZSPLIT);
-    const int k_hi = -g.factor + (int)(((zhalf + 1) * nk_all) / FUSE_ZSPLIT) - 1;
-    const int nk = __builtin_amdgcn_readfirstlane(k_hi - k_lo + 1);       /* the same for the whole wave */
-    float n_upd = 0.f;
+    const int colour = (tile_x & 1) + 2 * (tile_y & 1);
+    unsigned int* my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
+    /* every lane derives the two tile-wide decisions from the four entries (same result everywhere) */
+    int n_pass;
+    {
+        const unsigned int zmin_bits = min(min(L.st_min[0], L.st_min[1]), min(L.st_min[2], L.st_min[3]));
+        const unsigned int zmax_bits = max(max(L.st_max[0], L.st_max[1]), max(L.st_max[2], L.st_max[3]));
+        const float n_valid = (L.st_cnt[0] + L.st_cnt[1]) + (L.st_cnt[2] + L.st_cnt[3]);
+        /* (1) of the flush comment below: may this tile write its voxels itself? */
+        const float D = 1.7421f * g.vs;
+        const float s_min = __uint_as_float(zmin_bits) - (float)g.factor * g.vs - 2.f * D;
+        const float x_lo = (float)(tile_x * FUSE_T) - g.cx, x_hi = x_lo + (float)(FUSE_T - 1);
+        const float y_lo = (float)(tile_y * FUSE_T) - g.cy, y_hi = y_lo + (float)(FUSE_T - 1);
+        const float xm = fmaxf(fabsf(x_lo), fabsf(x_hi)) + 1.f, ym = fmaxf(fabsf(y_lo), fabsf(y_hi)) + 1.f;
+        const float gap = (float)FUSE_T + 0.5f;                       /* true gap is FUSE_T + 1 pixels */
+        bool ordered = s_min > 0.f && D * (g.fx + xm) <= gap * s_min && D * (g.fy + ym) <= gap * s_min;
+        if (a.debug & 4) ordered = false;
+        if (tid == 0) {
+            L.ordered = ordered ? 1u : 0u;                            /* read after the ray walk's barrier */
+            /* a tile that writes nothing itself has nothing to hand over: publish at once */
+            if (!ordered) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        /* distinct voxels the tile will touch ~ samples / (pixels per voxel face): far tiles (or small
+         * voxels) would overflow the LDS table, so they are walked as 2 or 4 row bands */
+        const float zf = __uint_as_float(zmax_bits);
+        const float ppv = fmaxf(1.f, (g.fx * g.vs / zf) * (g.fy * g.vs / zf) * 1.1f);
+        const float est = n_valid * (float)nk_all / ppv;
+        n_pass = est <= 0.8f * FUSE_LCAP ? 1 : (est <= 1.6f * FUSE_LCAP ? 2 : 4);
+        if (a.debug & 256) n_pass = 1;
+        if (a.debug & 512) n_pass = 4;
+        if (!(n_valid > 0.f)) n_pass = 1;
+        n_pass = __builtin_amdgcn_readfirstlane(n_pass);
+    }
+    float n_upd = 0.f, n_val = 0.f;
     unsigned int dbg_go = 0u;
+    for (int pass = 0; pass < n_pass; ++pass) {
+    /* lanes -> (pixel of the band, slice of the ray walk).  One band: as loaded above, 2 slices.  Two bands
+     * of 16x8 pixels: 2 waves (8x8 each) per slice, 4 slices.  Four bands of 16x4: 1 wave per slice, 8 slices. */
+    const int per = FUSE_THREADS / (2 * n_pass);
+    const int q = tid % per, zs = tid / per;
+    const int bx = n_pass == 4 ? (q & 15) : ((q >> 6) & 1) * 8 + (q & 7);
+    const int by = n_pass == 4 ? (q >> 4) : (q >> 7) * 8 + ((q >> 3) & 7);
+    if (n_pass > 1)
+        load_pixel(tile_x * FUSE_T + bx, tile_y * FUSE_T + pass * (FUSE_T / n_pass) + by,
+                   L.plane[0], L.plane[1], L.plane[2], L.plane[3], L.plane[4], L.plane[5], L.plane[6]);
+    if (zs == 0 && valid) n_val += 1.f;
+    /* this slice's share of the ray walk k = -factor..factor (:101); the order is free (sums) */
+    const int k_lo = -g.factor + (zs * nk_all) / (2 * n_pass);
+    const int k_hi = -g.factor + ((zs + 1) * nk_all) / (2 * n_pass) - 1;
+    const int nk = __builtin_amdgcn_readfirstlane(k_hi - k_lo + 1);       /* the same for the whole wave */
     if (nk > 0) {
         for (int c0 = 0; c0 < nk; c0 += FUSE_BATCH) {
             unsigned long long key[FUSE_BATCH], q[FUSE_BATCH][5];
-            float f[FUSE_BATCH][5];
             bool act[FUSE_BATCH];
             uint32_t bk[FUSE_BATCH];
             /* 1. the samples of this batch (the last batch of a walk may be short: wave-uniform skip) */
@@ -403,11 +464,9 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
                 if (act[j] && ((ux | uy | uz) >> 21)) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); act[j] = false; }
                 if (act[j]) n_upd += 1.f;
                 key[j] = (unsigned long long)ux | ((unsigned long long)uy << 21) | ((unsigned long long)uz << 42);
-                f[j][0] = w;
-                f[j][1] = w * gsdf_truncate(sdf, g.T);                     /* :111 as additive sum */
-                f[j][2] = w * Rn.x; f[j][3] = w * Rn.y; f[j][4] = w * Rn.z;   /* :112 */
-#pragma unroll
-                for (int v = 0; v < 5; ++v) q[j][v] = f2fix(f[j][v]);
+                q[j][0] = f2fix(w);
+                q[j][1] = f2fix(w * gsdf_truncate(sdf, g.T));              /* :111 as additive sum */
+                q[j][2] = f2fix(w * Rn.x); q[j][3] = f2fix(w * Rn.y); q[j][4] = f2fix(w * Rn.z);   /* :112 */
                 /* LDS bucket: a LATTICE hash, not a random one.  A tile's voxels are a compact oblique prism;
                  * x + 65 y + 138 z (mod 384) sends any two voxels closer than ~7.9 cells to different buckets
                  * (best 3-D lattice for this modulus, found by search), so buckets fill evenly (~2.3 of 4
@@ -484,7 +543,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
                     /* LDS table full for this voxel: contribute through the deferred list */
                     gsdf_payload* p = gsdf_find_or_insert(a.tab, key[j]);
                     if (!p) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
-                    else { defer_append(a, p, f[j][0], f[j][1], f[j][2], f[j][3], f[j][4]); vis_mark(a, p, frame_cur); }
+                    else { defer_append(a, p, fix2f(q[j][0]), fix2f(q[j][1]), fix2f(q[j][2]), fix2f(q[j][3]), fix2f(q[j][4])); vis_mark(a, p, frame_cur); }
                 }
             }
         }
@@ -510,22 +569,6 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
      * Bucket keys are insert-only, so plain (possibly stale) key loads can only show EMPTY and the CAS
      * settles it.  Each lane owns FUSE_LCAP/FUSE_THREADS LDS slots and drives them through the stages
      * together, so the dependent HBM round trips (bucket keys -> payload) of its entries overlap. */
-    const int colour = (tile_x & 1) + 2 * (tile_y & 1);
-    unsigned int* my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
-    if (tid == 0) {
-        const float D = 1.7421f * g.vs;
-        const float s_min = __uint_as_float(L.zmin_bits) - (float)g.factor * g.vs - 2.f * D;
-        const float x_lo = (float)(tile_x * FUSE_T) - g.cx, x_hi = x_lo + (float)(FUSE_T - 1);
-        const float y_lo = (float)(tile_y * FUSE_T) - g.cy, y_hi = y_lo + (float)(FUSE_T - 1);
-        const float xm = fmaxf(fabsf(x_lo), fabsf(x_hi)) + 1.f, ym = fmaxf(fabsf(y_lo), fabsf(y_hi)) + 1.f;
-        const float gap = (float)FUSE_T + 0.5f;                       /* true gap is FUSE_T + 1 pixels */
-        bool ordered = s_min > 0.f && D * (g.fx + xm) <= gap * s_min && D * (g.fy + ym) <= gap * s_min;
-        if (a.debug & 4) ordered = false;
-        L.ordered = ordered ? 1u : 0u;
-        /* a tile that writes nothing itself has nothing to hand over: publish at once */
-        if (!ordered) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
     if (!(a.debug & 1)) {
         constexpr int NE = FUSE_LCAP / FUSE_THREADS;
         unsigned long long ekey[NE], bkey[NE], k0[NE];
@@ -543,7 +586,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
         for (int e = 0; e < NE; ++e)
             if (ekey[e] != GSDF_KEY_EMPTY) k0[e] = a.tab.bkeys[home[e]];         /* 512 KB of block keys: L2 hits */
         /* meanwhile one wave waits for the adjacent tiles of lower colour (lane j watches neighbour j) */
-        if (wave == 0 && L.ordered) {
+        if (wave == 0 && L.ordered && pass == 0) {
             bool need = false;
             const unsigned int* flag = my_flag;
             if (lane < 8) {
@@ -607,7 +650,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
             /* hand the voxels on: every storing wave drains its stores, then ONE lane publishes the flag */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             /* near tile (or timed-out wait): everything goes through the deferred list */
             unsigned int my_defer = 0u;
@@ -638,13 +681,23 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
                 }
             }
             /* a timed-out tile still has to release the tiles that wait for it (it wrote nothing itself) */
-            if (tid == 0) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else if (tid == 0) {
         __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (pass + 1 < n_pass) {                                          /* next band: start from an empty table */
+        __syncthreads();
+        for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
+            L.key[i] = GSDF_KEY_EMPTY;
+            L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
+        }
+        if (tid == 0) L.n_defer = 0u;
+        __syncthreads();
+    }
+    }   /* pass */
     /* per-workgroup counters (plain stores into this workgroup's own row: no hot atomics) */
-    const float wu = wave_sum(n_upd), wv = wave_sum(valid ? 1.f : 0.f);
+    const float wu = wave_sum(n_upd), wv = wave_sum(n_val);
     if (lane == 0) { L.red[wave] = wu; L.red[8 + wave] = wv; }
     __syncthreads();
     if (tid == 0) {
@@ -652,7 +705,10 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_fuse(fuse_args a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) su += L.red[i];
         const unsigned long long nu = (unsigned long long)su;
-        const unsigned long long nv = (unsigned long long)(L.red[8] + L.red[9] + L.red[10] + L.red[11]);
+        float sv = 0.f;
+#pragma unroll
+        for (int i = 8; i < 16; ++i) sv += L.red[i];
+        const unsigned long long nv = (unsigned long long)sv;
         unsigned long long* c = a.blk_counters + 4 * ((size_t)tile_y * a.ntx + tile_x);
         c[0] = nu; c[1] = nv; c[2] += nu; c[3] += nv;
         if (tile_x == 0 && tile_y == 0) a.st->frames += 1;            /* :120 increase_counter() */
@@ -799,6 +855,8 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
                 for (int j = i; j < 6; ++j) { Hm[6 * i + j] = tot[q]; Hm[6 * j + i] = tot[q]; ++q; }
             float xi[6];
+            if (tp.debug & 1) { for (int i = 0; i < 6; ++i) xi[i] = 1.f; }   /* experiment: no solve */
+            else
             gsdf_llt_solve6(Hm, gvec, xi);                                /* RigidPointOptimizer.cpp:86 */
 #pragma unroll
             for (int i = 0; i < 6; ++i) xi[i] = tp.damping * xi[i];
@@ -812,7 +870,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
                 bool nan = false;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) nan = nan || isnan(xi[i]);
-                if (!nan) {                                               /* :94-95 */
+                if (!nan && !(tp.debug & 1)) {                            /* :94-95 */
                     float mxi[6];
 #pragma unroll
                     for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
@@ -849,7 +907,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
         for (int i = 0; i < 7; ++i) pose[i] = sh_pose[i];
     }
-    if (k >= tp.max_passes) return;                                       /* head-only launch */
+    if (k >= tp.max_passes || (tp.debug & 2)) return;                     /* head-only launch */
 
     /* ---- gather + normal-equation sums of pass k with the current pose ---- */
     float R[9];

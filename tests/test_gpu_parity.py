@@ -66,6 +66,28 @@ def test_fusion_keys_bit_exact(pkg, O, kind, W, H, vs, trunc):
     g.close()
 
 
+@pytest.mark.parametrize("flags,name", [(4, "every tile defers (near-tile path, float atomics in k_fuse_resolve)"),
+                                        (512, "every tile walked as 4 row bands (far-tile path)"),
+                                        (256, "single band only (far tiles overflow the LDS table into the deferred list)"),
+                                        (512 + 4, "4 bands, deferred")])
+def test_fusion_forced_paths_match_oracle(pkg, O, flags, name):
+    """The flush has a fast path (ordered tiles, plain read-modify-write handed from tile to tile) and
+    fallbacks chosen per tile from its depth; force each of them on the same input."""
+    seq, g, o = _mk(pkg, O, kind="tum", W=320, H=240, vs=0.01, trunc=10, cap=21, n=3)
+    L = pkg.binding.load()
+    L.gsdf_debug_flags(flags)
+    try:
+        for i in range(seq.n):
+            d, R, t = seq.frame(i)
+            g.update(d, R, t)
+            o.update(d, R, t)
+        g.sync()
+    finally:
+        L.gsdf_debug_flags(0)
+    assert _cmp_tables(g, o) > 10000
+    g.close()
+
+
 def test_fusion_counters_match_oracle(pkg, O):
     seq, g, o = _mk(pkg, O, n=2)
     tot_u = tot_v = 0

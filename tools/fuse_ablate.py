@@ -17,6 +17,8 @@ names = {0: "full", 1: "no flush", 2: "no LDS accumulate (flush empty)", 3: "com
          8: "flush: plain RMW", 17: "no flush, no overflow-to-HBM", 65: "no flush, count overflows", 16: "no overflow-to-HBM",
          49: "no flush, no overflow, LDS w-add skipped"}
 names = {0: 'full', 1: 'no flush', 2: 'no LDS lookups/adds (flush empty)', 3: 'compute only', 17: 'no flush, lookups only (no adds)', 33: 'no flush, adds only (slot from hash)', 8: 'flush without waiting (WRONG results)', 64: 'full, no skew', 65: 'no flush, no skew', 81: 'no flush, lookups only, no skew'}
+names[256] = 'full, single band forced'; names[512] = 'full, 4 bands forced'
+names[1024] = 'band limit 0.9'; names[2048] = 'band limit 1.1'
 for flags in (0, 1, 17, 33, 3, 0):
     L.gsdf_debug_flags(flags)
     g.reset()
