@@ -239,13 +239,22 @@ extern "C" {
 const char* gsdf_last_error(void) { return g_err.c_str(); }
 /* experiment switch for kernel ablations (tools/); not part of include/gsdf.h */
 void gsdf_debug_flags(int flags) { g_fuse_debug = flags; }
+/* experiment counters of the kernels (tools/ only; not part of the ABI in include/gsdf.h) */
+int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[4]) {
+    if (!c || !out) return GSDF_ERR_INVALID;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
+    gsdf_dev_state h;
+    if (hipMemcpy(&h, c->st, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
+    for (int i = 0; i < 4; ++i) out[i] = h.dbg[i];
+    return GSDF_OK;
+}
 const char* gsdf_version(void) { return "gsdf-mi355x 0.1 (gfx950)"; }
 
 int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device) {
     if (!out) return fail(GSDF_ERR_INVALID, "out == NULL");
     *out = nullptr;
     if (!(voxel_size > 0.f) || !(trunc_dist > 0.f)) return fail(GSDF_ERR_INVALID, "voxel_size and trunc_dist must be > 0");
-    if (capacity_log2 < 10 || capacity_log2 > 32) return fail(GSDF_ERR_INVALID, "capacity_log2 must be in [10, 32]");
+    if (capacity_log2 < 10 || capacity_log2 > 30) return fail(GSDF_ERR_INVALID, "capacity_log2 must be in [10, 30]");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
         (void)hipGetLastError();

@@ -230,12 +230,13 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
  * ---------------------------------------------------------------------------------------------- */
 #define FUSE_T 16
 #define FUSE_THREADS 512                 /* 4 waves (8x8 pixels each) x 2 halves of the ray walk */
-#define FUSE_LCAP 1536
+#define FUSE_LCAP 1792
 #define FUSE_NB (FUSE_LCAP / 4)
+#define FUSE_LKEY_EMPTY 0xFFFFFFFFu      /* LDS keys are 32-bit: voxel coordinates relative to the tile origin, 10 bits each */
+#define FUSE_LKEY_DEFER 0x80000000u      /* flush: the entry goes to the deferred list, low 31 bits = voxel record index */
 #define FUSE_LPROBE 12
 #define FUSE_BATCH 3
 #define FUSE_ZSPLIT 2
-#define FUSE_DEFER_BIT 0x8000000000000000ull
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 struct fuse_args {
@@ -261,7 +262,7 @@ struct fuse_args {
 };
 
 struct fuse_lds {
-    unsigned long long key[FUSE_LCAP] __attribute__((aligned(16)));
+    uint32_t key[FUSE_LCAP] __attribute__((aligned(16)));
     unsigned long long w[FUSE_LCAP], s[FUSE_LCAP], gx[FUSE_LCAP], gy[FUSE_LCAP], gz[FUSE_LCAP];
     float red[16];
     unsigned int n_defer, defer_base;
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                a.depth, a.nc.x0, a.nc.y0, a.nc.ninv, a.nx, a.ny, a.nz);
     /* meanwhile: empty table */
     for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
-        L.key[i] = GSDF_KEY_EMPTY;
+        L.key[i] = FUSE_LKEY_EMPTY;
         L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
     }
     if (tid == 0) {
@@ -420,8 +421,32 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
         if (!(n_valid > 0.f)) n_pass = 1;
         n_pass = __builtin_amdgcn_readfirstlane(n_pass);
     }
+    /* origin of the tile-local voxel coordinates: the world bounding box of the tile's frustum chunk
+     * (4 corner rays x the two ends of the sampled depth range) minus a margin; a sample whose voxel is not
+     * within 1024 cells of it (huge depth range at tiny voxels) takes the deferred route instead */
+    int ox, oy, oz;
+    {
+        const unsigned int zmin_bits = min(min(L.st_min[0], L.st_min[1]), min(L.st_min[2], L.st_min[3]));
+        const unsigned int zmax_bits = max(max(L.st_max[0], L.st_max[1]), max(L.st_max[2], L.st_max[3]));
+        const float s_lo = __uint_as_float(zmin_bits) - ((float)g.factor + 1.f) * g.vs;
+        const float s_hi = __uint_as_float(zmax_bits) + ((float)g.factor + 1.f) * g.vs;
+        float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f };
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float u = (float)(tile_x * FUSE_T + ((c & 1) ? FUSE_T : -1)), v = (float)(tile_y * FUSE_T + ((c & 2) ? FUSE_T : -1));
+            const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ (u - g.cx) / g.fx, (v - g.cy) / g.fy, 1.f });
+            mn[0] = fminf(mn[0], fminf(s_lo * d.x, s_hi * d.x));
+            mn[1] = fminf(mn[1], fminf(s_lo * d.y, s_hi * d.y));
+            mn[2] = fminf(mn[2], fminf(s_lo * d.z, s_hi * d.z));
+        }
+        const bool any_valid = zmax_bits != 0u;
+        ox = any_valid ? (int)floorf((mn[0] + t[0]) * g.inv_vs) - 3 : 0;
+        oy = any_valid ? (int)floorf((mn[1] + t[1]) * g.inv_vs) - 3 : 0;
+        oz = any_valid ? (int)floorf((mn[2] + t[2]) * g.inv_vs) - 3 : 0;
+        ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); oz = __builtin_amdgcn_readfirstlane(oz);
+    }
     float n_upd = 0.f, n_val = 0.f;
-    unsigned int dbg_go = 0u;
+    unsigned int dbg_go = 0u, dbg_full = 0u, dbg_lost = 0u;
     for (int pass = 0; pass < n_pass; ++pass) {
     /* lanes -> (pixel of the band, slice of the ray walk).  One band: as loaded above, 2 slices.  Two bands
      * of 16x8 pixels: 2 waves (8x8 each) per slice, 4 slices.  Four bands of 16x4: 1 wave per slice, 8 slices. */
@@ -439,13 +464,13 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     const int nk = __builtin_amdgcn_readfirstlane(k_hi - k_lo + 1);       /* the same for the whole wave */
     if (nk > 0) {
         for (int c0 = 0; c0 < nk; c0 += FUSE_BATCH) {
-            unsigned long long key[FUSE_BATCH], q[FUSE_BATCH][5];
-            bool act[FUSE_BATCH];
-            uint32_t bk[FUSE_BATCH];
+            unsigned long long gkey[FUSE_BATCH], q[FUSE_BATCH][5];
+            uint32_t key[FUSE_BATCH], bk[FUSE_BATCH];
+            bool act[FUSE_BATCH], local[FUSE_BATCH];
             /* 1. the samples of this batch (the last batch of a walk may be short: wave-uniform skip) */
 #pragma unroll
             for (int j = 0; j < FUSE_BATCH; ++j) {
-                act[j] = false; key[j] = 0ull; bk[j] = 0u;
+                act[j] = false; local[j] = false; key[j] = 0u; gkey[j] = 0ull; bk[j] = 0u;
                 if (c0 + j >= nk) continue;
                 const int kk = k_lo + c0 + j;                          /* wave-uniform */
                 act[j] = valid;
@@ -463,17 +488,21 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                 const uint32_t ux = (uint32_t)(vx + GSDF_KEY_OFF), uy = (uint32_t)(vy + GSDF_KEY_OFF), uz = (uint32_t)(vz + GSDF_KEY_OFF);
                 if (act[j] && ((ux | uy | uz) >> 21)) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); act[j] = false; }
                 if (act[j]) n_upd += 1.f;
-                key[j] = (unsigned long long)ux | ((unsigned long long)uy << 21) | ((unsigned long long)uz << 42);
+                gkey[j] = (unsigned long long)ux | ((unsigned long long)uy << 21) | ((unsigned long long)uz << 42);
+                /* tile-local key: 10 bits per axis relative to the tile origin */
+                const uint32_t lx3 = (uint32_t)(vx - ox), ly3 = (uint32_t)(vy - oy), lz3 = (uint32_t)(vz - oz);
+                local[j] = ((lx3 | ly3 | lz3) >> 10) == 0u;
+                key[j] = lx3 | (ly3 << 10) | (lz3 << 20);
                 q[j][0] = f2fix(w);
                 q[j][1] = f2fix(w * gsdf_truncate(sdf, g.T));              /* :111 as additive sum */
                 q[j][2] = f2fix(w * Rn.x); q[j][3] = f2fix(w * Rn.y); q[j][4] = f2fix(w * Rn.z);   /* :112 */
                 /* LDS bucket: a LATTICE hash, not a random one.  A tile's voxels are a compact oblique prism;
-                 * x + 65 y + 138 z (mod 384) sends any two voxels closer than ~7.9 cells to different buckets
-                 * (best 3-D lattice for this modulus, found by search), so buckets fill evenly (~2.3 of 4
-                 * slots), almost never overflow, and the distinct voxels of one wave instruction never
-                 * compete for a bucket.  (The HBM table keeps the full 64-bit finaliser.) */
-                static_assert(FUSE_NB == 384, "lattice constants are for 384 buckets");
-                bk[j] = ((ux & 1023u) + 65u * (uy & 1023u) + 138u * (uz & 1023u)) % (uint32_t)FUSE_NB;
+                 * x + 186 y + 234 z (mod 448) sends any two voxels closer than ~8.3 cells to different buckets
+                 * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
+                 * overflow, and the distinct voxels of one wave instruction never compete for a bucket.
+                 * (The HBM table keeps the full 64-bit finaliser.) */
+                static_assert(FUSE_NB == 448, "lattice constants are for 448 buckets");
+                bk[j] = (lx3 + 186u * ly3 + 234u * lz3) % (uint32_t)FUSE_NB;
             }
             /* 2.-4. look the voxels up in the LDS table.  All pending samples of the batch advance
              *    together: bucket (4 keys) = two ds_read_b128, match / first-empty by selects, at most
@@ -482,7 +511,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
             int slot[FUSE_BATCH];
             bool pend[FUSE_BATCH];
 #pragma unroll
-            for (int j = 0; j < FUSE_BATCH; ++j) { slot[j] = -1; pend[j] = act[j] && !(a.debug & 2); }
+            for (int j = 0; j < FUSE_BATCH; ++j) { slot[j] = -1; pend[j] = act[j] && local[j] && !(a.debug & 2); }
             if (a.debug & 32) {                   /* experiment: no lookup, slot straight from the hash */
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j) { if (act[j]) slot[j] = (int)(4 * bk[j] + (key[j] & 3)); pend[j] = false; }
@@ -494,38 +523,42 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j) { go[j] = j < nb && __any(pend[j]); any = any || go[j]; if (go[j]) ++dbg_go; }
                 if (!any) break;
-                u64x2 k01[FUSE_BATCH], k23[FUSE_BATCH];
+                uint4 kk4[FUSE_BATCH];
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j) {
                     if (!go[j]) continue;
-                    k01[j] = *reinterpret_cast<const u64x2*>(&L.key[4 * bk[j]]);
-                    k23[j] = *reinterpret_cast<const u64x2*>(&L.key[4 * bk[j] + 2]);
+                    kk4[j] = *reinterpret_cast<const uint4*>(&L.key[4 * bk[j]]);
                 }
                 int cas_at[FUSE_BATCH];
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j) {
                     cas_at[j] = -1;
                     if (!go[j]) continue;
-                    int hit = k23[j].y == key[j] ? 3 : -1;
-                    hit = k23[j].x == key[j] ? 2 : hit; hit = k01[j].y == key[j] ? 1 : hit; hit = k01[j].x == key[j] ? 0 : hit;
+                    int hit = kk4[j].w == key[j] ? 3 : -1;
+                    hit = kk4[j].z == key[j] ? 2 : hit; hit = kk4[j].y == key[j] ? 1 : hit; hit = kk4[j].x == key[j] ? 0 : hit;
                     /* first empty slot in a key-dependent rotation: different voxels that meet in one bucket
                      * in the same instruction go for different slots, so fewer of them lose the CAS */
-                    const uint32_t m = (k01[j].x == GSDF_KEY_EMPTY ? 1u : 0u) | (k01[j].y == GSDF_KEY_EMPTY ? 2u : 0u) |
-                                       (k23[j].x == GSDF_KEY_EMPTY ? 4u : 0u) | (k23[j].y == GSDF_KEY_EMPTY ? 8u : 0u);
-                    const uint32_t r = (uint32_t)(key[j] ^ (key[j] >> 21) ^ (key[j] >> 42)) & 3u;
+                    const uint32_t m = (kk4[j].x == FUSE_LKEY_EMPTY ? 1u : 0u) | (kk4[j].y == FUSE_LKEY_EMPTY ? 2u : 0u) |
+                                       (kk4[j].z == FUSE_LKEY_EMPTY ? 4u : 0u) | (kk4[j].w == FUSE_LKEY_EMPTY ? 8u : 0u);
+                    const uint32_t r = (key[j] ^ (key[j] >> 10) ^ (key[j] >> 20)) & 3u;
                     const uint32_t mr = ((m | (m << 4)) >> r) & 15u;
                     const int emp = mr ? (int)((__ffs(mr) - 1 + r) & 3u) : -1;
                     if (pend[j] && hit >= 0) { slot[j] = (int)(4 * bk[j]) + hit; pend[j] = false; }
                     cas_at[j] = (pend[j] && emp >= 0) ? (int)(4 * bk[j]) + emp : -1;
                     if (pend[j] && emp < 0) bk[j] = bk[j] + 1 == FUSE_NB ? 0 : bk[j] + 1;   /* bucket full of others */
+                    if ((a.debug & 128) && __any(pend[j] && emp < 0)) ++dbg_full;
                 }
-                unsigned long long old[FUSE_BATCH];
+                uint32_t old[FUSE_BATCH];
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j)
-                    old[j] = (go[j] && cas_at[j] >= 0) ? atomicCAS(&L.key[cas_at[j]], GSDF_KEY_EMPTY, key[j]) : 0ull;
+                    old[j] = (go[j] && cas_at[j] >= 0) ? atomicCAS(&L.key[cas_at[j]], FUSE_LKEY_EMPTY, key[j]) : 0u;
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j)
-                    if (go[j] && cas_at[j] >= 0 && (old[j] == GSDF_KEY_EMPTY || old[j] == key[j])) { slot[j] = cas_at[j]; pend[j] = false; }
+                    if (go[j] && cas_at[j] >= 0 && (old[j] == FUSE_LKEY_EMPTY || old[j] == key[j])) { slot[j] = cas_at[j]; pend[j] = false; }
+                if (a.debug & 128) {
+#pragma unroll
+                    for (int j = 0; j < FUSE_BATCH; ++j) if (go[j] && __any(cas_at[j] >= 0 && pend[j])) ++dbg_lost;
+                }
                 /* a lost CAS (slot taken by another voxel) re-reads the same bucket in the next probe */
             }
             /* 5. accumulate (exact 64-bit integer adds) */
@@ -540,15 +573,19 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                     atomicAdd(&L.gy[slot[j]], q[j][3]);
                     atomicAdd(&L.gz[slot[j]], q[j][4]);
                 } else {
-                    /* LDS table full for this voxel: contribute through the deferred list */
-                    gsdf_payload* p = gsdf_find_or_insert(a.tab, key[j]);
+                    /* LDS table full for this voxel (or voxel outside the local key range): deferred list */
+                    gsdf_payload* p = gsdf_find_or_insert(a.tab, gkey[j]);
                     if (!p) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
                     else { defer_append(a, p, fix2f(q[j][0]), fix2f(q[j][1]), fix2f(q[j][2]), fix2f(q[j][3]), fix2f(q[j][4])); vis_mark(a, p, frame_cur); }
                 }
             }
         }
     }
-    if ((a.debug & 128) && lane == 0) atomicAdd(&a.st->n_hit, (unsigned long long)dbg_go);
+    if ((a.debug & 128) && lane == 0) {
+        atomicAdd(&a.st->n_hit, (unsigned long long)dbg_go);
+        atomicAdd(&a.st->dbg[0], (unsigned long long)dbg_full); atomicAdd(&a.st->dbg[1], (unsigned long long)dbg_lost);
+        dbg_go = dbg_full = dbg_lost = 0u;
+    }
     __syncthreads();
     /* Flush the tile's distinct voxels: read-modify-write of the HBM payload with NO atomics.
      *
@@ -570,13 +607,17 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
      * settles it.  Each lane owns FUSE_LCAP/FUSE_THREADS LDS slots and drives them through the stages
      * together, so the dependent HBM round trips (bucket keys -> payload) of its entries overlap. */
     if (!(a.debug & 1)) {
-        constexpr int NE = FUSE_LCAP / FUSE_THREADS;
+        constexpr int NE = (FUSE_LCAP + FUSE_THREADS - 1) / FUSE_THREADS;
         unsigned long long ekey[NE], bkey[NE], k0[NE];
         uint32_t home[NE];
         gsdf_payload* P[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            ekey[e] = L.key[tid + FUSE_THREADS * e];
+            /* back from the tile-local key to the packed voxel key of the HBM map */
+            const int i = tid + FUSE_THREADS * e;
+            const uint32_t lk = i < FUSE_LCAP ? L.key[i] : FUSE_LKEY_EMPTY;
+            ekey[e] = lk == FUSE_LKEY_EMPTY ? GSDF_KEY_EMPTY
+                                            : gsdf_key_pack(ox + (int)(lk & 1023u), oy + (int)((lk >> 10) & 1023u), oz + (int)(lk >> 20));
             bkey[e] = gsdf_block_key(ekey[e]);
             home[e] = gsdf_hash(bkey[e]) & a.tab.block_mask;
             P[e] = nullptr;
@@ -614,7 +655,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
             if (ekey[e] == GSDF_KEY_EMPTY) continue;
             /* block already at its home entry: the common case; else probe on / insert the block */
             const int b = k0[e] == bkey[e] ? (int)home[e] : gsdf_block_find_or_insert(a.tab, bkey[e], home[e], k0[e]);
-            if (b < 0) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); ekey[e] = GSDF_KEY_EMPTY; L.key[tid + FUSE_THREADS * e] = GSDF_KEY_EMPTY; }
+            if (b < 0) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); ekey[e] = GSDF_KEY_EMPTY; L.key[tid + FUSE_THREADS * e] = FUSE_LKEY_EMPTY; }
             else P[e] = a.tab.vox + ((size_t)b * GSDF_BLOCK_VOX + gsdf_block_local(ekey[e]));
         }
         __syncthreads();                                              /* the wait above is over (or timed out) */
@@ -657,7 +698,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 if (ekey[e] == GSDF_KEY_EMPTY) continue;
-                L.key[tid + FUSE_THREADS * e] = FUSE_DEFER_BIT | (unsigned long long)(uintptr_t)P[e];   /* device pointers use < 2^57 */
+                L.key[tid + FUSE_THREADS * e] = FUSE_LKEY_DEFER | (uint32_t)(P[e] - a.tab.vox);   /* < 2^31 records (gsdf_create) */
                 vis_mark(a, P[e], frame_cur);
                 ++my_defer;
             }
@@ -669,12 +710,12 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                 if (tid == 0) L.n_defer = 0u;
                 __syncthreads();
                 for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
-                    const unsigned long long key = L.key[i];
-                    if (key == GSDF_KEY_EMPTY) continue;
+                    const uint32_t key = L.key[i];
+                    if (key == FUSE_LKEY_EMPTY) continue;
                     const unsigned int o = L.defer_base + atomicAdd(&L.n_defer, 1u);
                     if (o >= a.deferred_cap) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); continue; }
                     gsdf_deferred d;
-                    d.p = reinterpret_cast<gsdf_payload*>((uintptr_t)(key & ~FUSE_DEFER_BIT));
+                    d.p = a.tab.vox + (key & ~FUSE_LKEY_DEFER);
                     d.w = fix2f(L.w[i]); d.s = fix2f(L.s[i]); d.gx = fix2f(L.gx[i]); d.gy = fix2f(L.gy[i]); d.gz = fix2f(L.gz[i]);
                     d.pad = 0u;
                     a.deferred[o] = d;
@@ -689,7 +730,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     if (pass + 1 < n_pass) {                                          /* next band: start from an empty table */
         __syncthreads();
         for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
-            L.key[i] = GSDF_KEY_EMPTY;
+            L.key[i] = FUSE_LKEY_EMPTY;
             L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
         }
         if (tid == 0) L.n_defer = 0u;

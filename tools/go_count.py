@@ -16,6 +16,10 @@ for i in range(n):
 g.sync()
 st = g.stats()
 print("go per frame", st["n_hit"] / n, "wave-samples per frame", 1200 * 8 * 10.5, "ratio", st["n_hit"] / n / (1200 * 8 * 10.5))
+import ctypes
+out = (ctypes.c_ulonglong * 4)()
+L.gsdf_debug_read(g.h, out)
+print("wave-level events per frame: bucket full", out[0] / n, "CAS lost", out[1] / n)
 print("n_upd/frame", st["n_upd"] / n, "voxels", g.count())
 L.gsdf_debug_flags(0)
 g.close()
