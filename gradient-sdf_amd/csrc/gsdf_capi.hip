@@ -357,7 +357,8 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipMalloc((void**)&c->depth_stage, N * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->normals, 3 * N * sizeof(float)));
     /* tracker grid: a multiple of the 256 CUs when the frame is large enough, 1-4 pixels per lane */
-    c->track_blocks = N >= (size_t)1 << 20 ? 1024 : N >= (size_t)1 << 18 ? 512 : (int)std::max<size_t>(1, (N + 511) / 512);
+    c->track_blocks = N >= (size_t)1 << 20 ? 2 * GSDF_TRACK_MAXBLK : N >= (size_t)1 << 18 ? GSDF_TRACK_MAXBLK
+                                                : (int)std::max<size_t>(1, (N + 511) / 512);
     HIP_TRY(hipMalloc((void**)&c->partials, (size_t)2 * c->track_blocks * 32 * sizeof(float)));   /* two row sets */
     c->fuse_blocks = gsdf_fuse_grid_blocks(W, H);
     HIP_TRY(hipMalloc((void**)&c->blk_counters, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long)));

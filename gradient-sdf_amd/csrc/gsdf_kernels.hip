@@ -827,7 +827,9 @@ __global__ void k_track_none(gsdf_dev_state* st) {
 }
 void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st) { hipLaunchKernelGGL(k_track_none, dim3(1), dim3(64), 0, s, st); }
 
-#define TRK_PPT 4          /* pixels per lane handled as one batch: 4 independent gathers in flight */
+#ifndef TRK_PPT
+#define TRK_PPT 3          /* pixels per lane handled as one batch: independent gathers in flight */
+#endif
 
 __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
                                                                  gsdf_table tab, gsdf_dev_state* st,
