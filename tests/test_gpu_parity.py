@@ -88,6 +88,35 @@ def test_fusion_forced_paths_match_oracle(pkg, O, flags, name):
     g.close()
 
 
+def test_fusion_handoff_loses_nothing_at_full_size(pkg):
+    """Size-independent property at the bench size (640x480, 1 cm): the tile-to-tile hand-off of the flush
+    (plain read-modify-write, agent-scope accesses, flags) must give the same sums as the path that defers
+    every contribution to float atomics.  A lost or stale hand-off would drop a whole tile's contribution to
+    a voxel (>= 1e-2 relative); float reordering alone stays below 1e-5."""
+    W, H, n = 640, 480, 24
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=3)
+    vs = np.float32(0.01); T = np.float32(10) * vs
+    L = pkg.binding.load()
+    out = []
+    for flags in (0, 4):
+        g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=22)
+        L.gsdf_debug_flags(flags)
+        try:
+            for i in range(n):
+                d, R, t = seq.frame(i)
+                g.update(d, R, t)
+            g.sync()
+        finally:
+            L.gsdf_debug_flags(0)
+        out.append(g.export(sorted=True, raw=True))
+        g.close()
+    (ka, pa), (kb, pb) = out
+    assert np.array_equal(ka, kb)
+    assert ka.shape[0] > 1000000
+    scale = np.maximum(1.0, np.abs(pb[:, 4:5]))
+    assert (np.abs(pa - pb) / scale).max() < 1e-5
+
+
 def test_fusion_counters_match_oracle(pkg, O):
     seq, g, o = _mk(pkg, O, n=2)
     tot_u = tot_v = 0
