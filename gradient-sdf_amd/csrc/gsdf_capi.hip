@@ -240,12 +240,12 @@ const char* gsdf_last_error(void) { return g_err.c_str(); }
 /* experiment switch for kernel ablations (tools/); not part of include/gsdf.h */
 void gsdf_debug_flags(int flags) { g_fuse_debug = flags; }
 /* experiment counters of the kernels (tools/ only; not part of the ABI in include/gsdf.h) */
-int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[4]) {
+int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[8]) {
     if (!c || !out) return GSDF_ERR_INVALID;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
     gsdf_dev_state h;
     if (hipMemcpy(&h, c->st, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
-    for (int i = 0; i < 4; ++i) out[i] = h.dbg[i];
+    for (int i = 0; i < 8; ++i) out[i] = h.dbg[i];
     return GSDF_OK;
 }
 const char* gsdf_version(void) { return "gsdf-mi355x 0.1 (gfx950)"; }

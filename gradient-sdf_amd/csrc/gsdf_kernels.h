@@ -48,7 +48,7 @@ struct gsdf_dev_state {
     long long log_rows;
     long long frame_cur;          /* counter_ snapshot for the running update (k_normals -> k_fuse) */
     gsdf_trk_buf trk[2];
-    unsigned long long dbg[4];    /* experiment counters (gsdf_debug_flags & 128), see tools/go_count.py */
+    unsigned long long dbg[8];    /* experiment counters (gsdf_debug_flags & 128), see tools/go_count.py */
 };
 
 struct gsdf_frame_geom {

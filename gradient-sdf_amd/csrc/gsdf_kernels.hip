@@ -238,6 +238,7 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #define FUSE_BATCH 3
 #define FUSE_ZSPLIT 2
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t gsdf_u32x4 __attribute__((ext_vector_type(4)));
 
 struct fuse_args {
     gsdf_frame_geom g;
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     __shared__ fuse_lds L;
     if (a.use_dev_pose && !a.st->converged) return;        /* main_scan_3d.cpp:261: if (conv) update */
     const int tid = threadIdx.x;
+    const unsigned long long T0 = (a.debug & 128) ? wall_clock64() : 0ull;
     float R[9], t[3];
     if (a.use_dev_pose) {
 #pragma unroll
@@ -348,18 +350,18 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
         valid = px < g.W && py < g.H;
         z = 0.f;
         if (valid) {
+            /* all seven loads are issued together: one memory round trip, not two */
             const size_t idx = (size_t)py * g.W + px;
             z = dp[idx];
+            const gsdf_v3 xy = { x0p[idx], y0p[idx], 1.f };                /* :90 */
+            const gsdf_v3 n = { nxp[idx], nyp[idx], nzp[idx] };            /* :92 */
+            const float ninv = nip[idx];
             valid = !(z <= g.zmin || z >= g.zmax);                         /* MapGradPixelSdf.cpp:87 */
-            if (valid) {
-                const gsdf_v3 xy = { x0p[idx], y0p[idx], 1.f };            /* :90 */
-                const gsdf_v3 n = { nxp[idx], nyp[idx], nzp[idx] };        /* :92 */
-                Rxy = gsdf_matvec(R, xy);                                  /* :91 */
-                Rn = gsdf_matvec(R, n);                                    /* :93 */
-                if ((double)gsdf_dot3(n, n) < .1) valid = false;           /* :95 */
-                const float nd = gsdf_dot3(n, xy);
-                if (nd * nd * nip[idx] < .25) valid = false;               /* :98 */
-            }
+            Rxy = gsdf_matvec(R, xy);                                      /* :91 */
+            Rn = gsdf_matvec(R, n);                                        /* :93 */
+            if ((double)gsdf_dot3(n, n) < .1) valid = false;               /* :95 (same comparison as the reference: NaN passes) */
+            const float nd = gsdf_dot3(n, xy);
+            if (nd * nd * ninv < .25) valid = false;                       /* :98 */
         }
     };
     /* the common case is one band: load its pixels now, the loads overlap the table clear */
@@ -431,10 +433,11 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
         const float s_lo = __uint_as_float(zmin_bits) - ((float)g.factor + 1.f) * g.vs;
         const float s_hi = __uint_as_float(zmax_bits) + ((float)g.factor + 1.f) * g.vs;
         float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f };
+        const float rfx = __frcp_rn(g.fx), rfy = __frcp_rn(g.fy);       /* a bounding box with margin: no parity item */
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float u = (float)(tile_x * FUSE_T + ((c & 1) ? FUSE_T : -1)), v = (float)(tile_y * FUSE_T + ((c & 2) ? FUSE_T : -1));
-            const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ (u - g.cx) / g.fx, (v - g.cy) / g.fy, 1.f });
+            const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ (u - g.cx) * rfx, (v - g.cy) * rfy, 1.f });
             mn[0] = fminf(mn[0], fminf(s_lo * d.x, s_hi * d.x));
             mn[1] = fminf(mn[1], fminf(s_lo * d.y, s_hi * d.y));
             mn[2] = fminf(mn[2], fminf(s_lo * d.z, s_hi * d.z));
@@ -447,6 +450,8 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     }
     float n_upd = 0.f, n_val = 0.f;
     unsigned int dbg_go = 0u, dbg_full = 0u, dbg_lost = 0u;
+    unsigned long long T1 = (a.debug & 128) ? wall_clock64() : 0ull;
+    if ((a.debug & 128) && tid == 0) atomicAdd(&a.st->dbg[4], T1 - T0);
     for (int pass = 0; pass < n_pass; ++pass) {
     /* lanes -> (pixel of the band, slice of the ray walk).  One band: as loaded above, 2 slices.  Two bands
      * of 16x8 pixels: 2 waves (8x8 each) per slice, 4 slices.  Four bands of 16x4: 1 wave per slice, 8 slices. */
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     const int k_lo = -g.factor + (zs * nk_all) / (2 * n_pass);
     const int k_hi = -g.factor + ((zs + 1) * nk_all) / (2 * n_pass) - 1;
     const int nk = __builtin_amdgcn_readfirstlane(k_hi - k_lo + 1);       /* the same for the whole wave */
-    if (nk > 0) {
+    if (nk > 0 && __any(valid)) {                    /* ~18 % of the 8x8 sub-tiles have no valid pixel at all */
         for (int c0 = 0; c0 < nk; c0 += FUSE_BATCH) {
             unsigned long long gkey[FUSE_BATCH], q[FUSE_BATCH][5];
             uint32_t key[FUSE_BATCH], bk[FUSE_BATCH];
@@ -587,6 +592,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
         dbg_go = dbg_full = dbg_lost = 0u;
     }
     __syncthreads();
+    if ((a.debug & 128) && tid == 0) { const unsigned long long T2 = wall_clock64(); atomicAdd(&a.st->dbg[2], T2 - T1); T1 = T2; }
     /* Flush the tile's distinct voxels: read-modify-write of the HBM payload with NO atomics.
      *
      * Mutual exclusion between tiles comes from two facts:
@@ -661,31 +667,34 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
         __syncthreads();                                              /* the wait above is over (or timed out) */
         const bool ordered = L.ordered != 0u;
         if (ordered) {
-            unsigned long long q0[NE], q1[NE], q2[NE];
+            /* a record is 32 bytes, 32-byte aligned: two 16-byte agent-scope (sc1) accesses each way -- narrower
+             * write-through stores cost one fabric write each (3 x 8 B measured 2x slower).  hipcc does not
+             * count asm memory operations: the wait statement below names every destination register. */
+            gsdf_u32x4 ra[NE], rb[NE];
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
+                ra[e] = gsdf_u32x4{ 0u, 0u, 0u, 0u }; rb[e] = ra[e];
                 if (ekey[e] == GSDF_KEY_EMPTY) continue;
-                unsigned long long* q = reinterpret_cast<unsigned long long*>(P[e]);
-                q0[e] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                q1[e] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                q2[e] = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ra[e]) : "v"(P[e]) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=v"(rb[e]) : "v"(P[e]) : "memory");
             }
+            static_assert(NE == 4, "the wait statement names 4 x 2 destination registers");
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[2]), "+v"(rb[2]), "+v"(ra[3]), "+v"(rb[3])
+                         :: "memory");
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 if (ekey[e] == GSDF_KEY_EMPTY) continue;
                 const int i = tid + FUSE_THREADS * e;
-                const float w = __uint_as_float((uint32_t)q0[e]) + fix2f(L.w[i]);
-                const float sd = __uint_as_float((uint32_t)(q0[e] >> 32)) + fix2f(L.s[i]);
-                const float gx = __uint_as_float((uint32_t)q1[e]) + fix2f(L.gx[i]);
-                const float gy = __uint_as_float((uint32_t)(q1[e] >> 32)) + fix2f(L.gy[i]);
-                const float gz = __uint_as_float((uint32_t)q2[e]) + fix2f(L.gz[i]);
-                unsigned long long* q = reinterpret_cast<unsigned long long*>(P[e]);
-                __hip_atomic_store(q, (unsigned long long)__float_as_uint(w) | ((unsigned long long)__float_as_uint(sd) << 32),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(gx) | ((unsigned long long)__float_as_uint(gy) << 32),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(q + 2, (unsigned long long)__float_as_uint(gz) | ((unsigned long long)a.tag << 32),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gsdf_u32x4 oa, ob;
+                oa.x = __float_as_uint(__uint_as_float(ra[e].x) + fix2f(L.w[i]));
+                oa.y = __float_as_uint(__uint_as_float(ra[e].y) + fix2f(L.s[i]));
+                oa.z = __float_as_uint(__uint_as_float(ra[e].z) + fix2f(L.gx[i]));
+                oa.w = __float_as_uint(__uint_as_float(ra[e].w) + fix2f(L.gy[i]));
+                ob.x = __float_as_uint(__uint_as_float(rb[e].x) + fix2f(L.gz[i]));
+                ob.y = a.tag; ob.z = 0u; ob.w = 0u;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(P[e]), "v"(oa) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(P[e]), "v"(ob) : "memory");
                 vis_mark(a, P[e], frame_cur);
             }
             /* hand the voxels on: every storing wave drains its stores, then ONE lane publishes the flag */
@@ -727,6 +736,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     } else if (tid == 0) {
         __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if ((a.debug & 128) && tid == 0) { const unsigned long long T3 = wall_clock64(); atomicAdd(&a.st->dbg[3], T3 - T1); T1 = T3; }
     if (pass + 1 < n_pass) {                                          /* next band: start from an empty table */
         __syncthreads();
         for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
@@ -803,7 +813,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
         a.first[c] = n;
         n += ((ntx - (c & 1) + 1) / 2) * ((nty - (c >> 1) + 1) / 2);
     }
-    hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), (g_fuse_debug & 4096) ? 8192 : 0, s, a);   /* experiment: 1 workgroup per CU */
     hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate,
                        use_dev_pose ? log_rows : nullptr, max_rows);
 }

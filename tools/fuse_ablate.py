@@ -19,7 +19,8 @@ names = {0: "full", 1: "no flush", 2: "no LDS accumulate (flush empty)", 3: "com
 names = {0: 'full', 1: 'no flush', 2: 'no LDS lookups/adds (flush empty)', 3: 'compute only', 17: 'no flush, lookups only (no adds)', 33: 'no flush, adds only (slot from hash)', 8: 'flush without waiting (WRONG results)', 64: 'full, no skew', 65: 'no flush, no skew', 81: 'no flush, lookups only, no skew'}
 names[256] = 'full, single band forced'; names[512] = 'full, 4 bands forced'
 names[1024] = 'band limit 0.9'; names[2048] = 'band limit 1.1'
-for flags in (0, 1, 17, 33, 3, 0):
+names[4096] = 'full, 1 workgroup per CU'; names[4097] = 'no flush, 1 workgroup per CU'; names[4099] = 'compute only, 1 workgroup per CU'
+for flags in (0, 1, 17, 33, 3, 4096, 0):
     L.gsdf_debug_flags(flags)
     g.reset()
     for rep in range(2):

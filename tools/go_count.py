@@ -11,15 +11,29 @@ g = pkg.GradSdf(vs, T, 640, 480, seq.K, capacity_log2=22)
 L = pkg.binding.load()
 L.gsdf_debug_flags(128)
 dev = [g.upload(f[0]) for f in frames]
-for i in range(n):
+import ctypes
+def rd():
+    o = (ctypes.c_ulonglong * 8)()
+    L.gsdf_debug_read(g.h, o)
+    return np.array(list(o), dtype=np.float64)
+for i in range(n // 2):
     g.update_dev(dev[i], frames[i][1], frames[i][2])
 g.sync()
+mid = rd()
+for i in range(n // 2, n):
+    g.update_dev(dev[i], frames[i][1], frames[i][2])
+g.sync()
+late = rd() - mid
+wgl = 1200.0 * (n - n // 2)
+print("frames %d..%d, mean per workgroup (clock ticks): prologue %.0f  ray walk %.0f  flush %.0f" % (n // 2, n - 1, late[4] / wgl, late[2] / wgl, late[3] / wgl))
 st = g.stats()
 print("go per frame", st["n_hit"] / n, "wave-samples per frame", 1200 * 8 * 10.5, "ratio", st["n_hit"] / n / (1200 * 8 * 10.5))
 import ctypes
-out = (ctypes.c_ulonglong * 4)()
+out = (ctypes.c_ulonglong * 8)()
 L.gsdf_debug_read(g.h, out)
 print("wave-level events per frame: bucket full", out[0] / n, "CAS lost", out[1] / n)
+wg = 1200.0 * n
+print("mean per workgroup (us): prologue %.2f  ray walk %.2f  flush %.2f" % (out[4] / wg / 100.0, out[2] / wg / 100.0, out[3] / wg / 100.0))
 print("n_upd/frame", st["n_upd"] / n, "voxels", g.count())
 L.gsdf_debug_flags(0)
 g.close()
