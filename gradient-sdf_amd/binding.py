@@ -104,6 +104,7 @@ def load():
         "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
         "gsdf_query": (C.c_int, [vp, fp, C.c_int64, fp, fp, fp]),
+        "gsdf_raycast": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]),
         "gsdf_dev_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_int64]),
         "gsdf_dev_free": (C.c_int, [vp, vp]),
         "gsdf_dev_upload": (C.c_int, [vp, vp, vp, C.c_int64]),
@@ -127,7 +128,7 @@ ABI_SYMBOLS = [
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
     "gsdf_ba_setup", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
-    "gsdf_merge_raw_dev", "gsdf_query",
+    "gsdf_merge_raw_dev", "gsdf_query", "gsdf_raycast",
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_timer_start", "gsdf_timer_stop_ms",
     "gsdf_profile", "gsdf_profile_read",
 ]
@@ -331,6 +332,19 @@ class GradSdf:
         w = np.empty(n, np.float32)
         self._chk(self.L.gsdf_query(self.h, _fp(p), n, _fp(dist), _fp(grad), _fp(w)))
         return dist, grad, w
+
+    def raycast(self, R, t, zmin=0.5, zmax=3.5, W=None, H=None, K=None, normals=True):
+        """Voxel-hash raycaster: (depth[H,W] camera z, 0 = no hit; normals[3,H,W] camera frame or None)."""
+        W = self.W if W is None else int(W)
+        H = self.H if H is None else int(H)
+        K = self.K if K is None else _f32(K).reshape(9)
+        R = _f32(R).reshape(9)
+        t = _f32(t).reshape(3)
+        d = np.empty((H, W), np.float32)
+        n = np.empty((3, H, W), np.float32) if normals else None
+        self._chk(self.L.gsdf_raycast(self.h, _fp(K), _fp(R), _fp(t), W, H, C.c_float(zmin), C.c_float(zmax), _fp(d),
+                                      _fp(n) if normals else None))
+        return d, n
 
     # -- timing -------------------------------------------------------------------------------
     def timer_start(self):

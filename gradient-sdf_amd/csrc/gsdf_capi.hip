@@ -830,6 +830,28 @@ int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float
     return GSDF_OK;
 }
 
+int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
+                 float* depth_out, float* normals_out) {
+    if (!c || !K || !R || !t || !depth_out) return fail(GSDF_ERR_INVALID, "null argument");
+    if (W <= 0 || H <= 0 || !(zmax > zmin) || !(zmin > 0.f)) return fail(GSDF_ERR_INVALID, "W,H > 0 and 0 < zmin < zmax required");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t N = (size_t)W * H;
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 4 * N * sizeof(float)));
+    gsdf_pose_arg pose;
+    std::memcpy(pose.R, R, sizeof(pose.R));
+    std::memcpy(pose.t, t, sizeof(pose.t));
+    gsdf_launch_raycast(c->stream, c->tab, c->voxel_size, c->voxel_size_inv, W, H, K, pose, zmin, zmax, d,
+                        normals_out ? d + N : nullptr);
+    hipError_t e = hipMemcpyAsync(depth_out, d, N * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && normals_out)
+        e = hipMemcpyAsync(normals_out, d + N, 3 * N * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
+    return GSDF_OK;
+}
+
 int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes) {
     if (!c || !dev_ptr || bytes <= 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));

@@ -1191,3 +1191,68 @@ void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, co
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_query, dim3(blocks), dim3(256), 0, s, tab, vs, inv_vs, pts, n, dist, grad, w);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Voxel-hash raycaster (BASELINE.json north_star; absent from the reference): defined
+ * on top of weights()/tsdf() -- MapGradPixelSdf.h:109-125 -- and the tracker's back-projection
+ * (RigidPointOptimizer.cpp:46-47,67-70): p(s) = s R (x0, y0, 1) + t; 4-voxel steps while the voxel under
+ * p(s) is missing, 1-voxel steps inside the band; hit = first sign change phi_prev < 0 <= phi of two
+ * consecutive in-band samples (the SDF is negative in front of a surface); depth by linear interpolation,
+ * normal = R^T grad/|grad| of the sample behind the surface.  The test suite holds a CPU statement of the same
+ * definition.
+ * One lane per pixel, 16x16-pixel workgroups (neighbouring rays walk the same blocks: the block keys
+ * are L2 hits, records share lines).  The walk is a chain of dependent lookups per ray: 4-voxel steps
+ * through empty space (one key probe each), 1-voxel steps inside the band.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float inv_vs, int W, int H, float fx, float fy,
+                                                  float cx, float cy, gsdf_pose_arg pose, float zmin, float zmax,
+                                                  float* __restrict__ depth, float* __restrict__ normals) {
+    const int u = blockIdx.x * 16 + (threadIdx.x & 15), v = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (u >= W || v >= H) return;
+    const float* R = pose.R;
+    const float fx_inv = 1.f / fx, fy_inv = 1.f / fy;
+    const float x0 = ((float)u - cx) * fx_inv, y0 = ((float)v - cy) * fy_inv;
+    const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ x0, y0, 1.f });
+    const float fine = vs, coarse = 4.f * vs;
+    float out_z = 0.f;
+    gsdf_v3 out_n = { 0.f, 0.f, 0.f };
+    bool prev_ok = false;
+    float phi_prev = 0.f, s_prev = 0.f;
+    for (float s = zmin; s < zmax;) {
+        const gsdf_v3 p = { s * d.x + pose.t[0], s * d.y + pose.t[1], s * d.z + pose.t[2] };
+        const int vx = gsdf_float2vox1(inv_vs, p.x), vy = gsdf_float2vox1(inv_vs, p.y), vz = gsdf_float2vox1(inv_vs, p.z);
+        const gsdf_payload* sl = gsdf_key_in_range(vx, vy, vz) ? gsdf_find(tab, gsdf_key_pack(vx, vy, vz)) : nullptr;
+        float w0 = 0.f;
+        float2 ws = make_float2(0.f, 0.f), gxy = ws, gz_ = ws;
+        if (sl) {
+            const float2* q = reinterpret_cast<const float2*>(sl);
+            ws = q[0]; gxy = q[1]; gz_ = q[2];
+            w0 = ws.x;
+        }
+        if (w0 > 0.f) {
+            const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ gxy.x, gxy.y, gz_.x });
+            const gsdf_v3 g = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };
+            const gsdf_v3 c = { vs * (float)vx - p.x, vs * (float)vy - p.y, vs * (float)vz - p.z };
+            const float phi = ws.y / w0 + gsdf_dot3(g, c);
+            if (prev_ok && phi_prev < 0.f && phi >= 0.f) {   /* the stored SDF is negative in front of the surface */
+                out_z = s_prev + (s - s_prev) * (phi_prev / (phi_prev - phi));
+                out_n = gsdf_v3{ gsdf_sum3(R[0] * gn.x, R[3] * gn.y, R[6] * gn.z), gsdf_sum3(R[1] * gn.x, R[4] * gn.y, R[7] * gn.z),
+                                 gsdf_sum3(R[2] * gn.x, R[5] * gn.y, R[8] * gn.z) };
+                break;
+            }
+            prev_ok = true; phi_prev = phi; s_prev = s;
+            s += fine;
+        } else {
+            prev_ok = false;
+            s += coarse;
+        }
+    }
+    const size_t i = (size_t)v * W + u;
+    depth[i] = out_z;
+    if (normals) { normals[i] = out_n.x; normals[(size_t)W * H + i] = out_n.y; normals[2 * (size_t)W * H + i] = out_n.z; }
+}
+void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, int W, int H, const float K[9],
+                         const gsdf_pose_arg& pose, float zmin, float zmax, float* depth, float* normals) {
+    hipLaunchKernelGGL(k_raycast, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, s, tab, vs, inv_vs, W, H, K[0], K[4], K[2],
+                       K[5], pose, zmin, zmax, depth, normals);
+}

@@ -54,6 +54,12 @@ float MapGradPixelSdf::tsdf(Vec3f point, Vec3f* grad_ptr) const {
     return d;
 }
 
+void MapGradPixelSdf::raycast(const Mat3f& K, const SE3& pose, int W, int H, float* depth_out, float* normals_out) const {
+    const Mat3f R = pose.rotationMatrix();
+    const Vec3f t = pose.translation();
+    check(gsdf_raycast(ctx_, K.m, R.m, t.data(), W, H, zmin_, zmax_, depth_out, normals_out), "gsdf_raycast");
+}
+
 int64_t MapGradPixelSdf::size() const {
     int64_t n = 0;
     check(gsdf_count(ctx_, &n), "gsdf_count");

@@ -47,6 +47,10 @@ public:
     int64_t size() const;
     int64_t frame_counter() const;
 
+    /* voxel-hash raycaster (BASELINE.json north_star; the reference has none): depth (camera z, 0 = no hit)
+     * and camera-frame normals (3 planes, may be null) of the map seen from `pose` through K */
+    void raycast(const Mat3f& K, const SE3& pose, int W, int H, float* depth_out, float* normals_out) const;
+
     bool extract_pc(std::string filename) override;                    /* MapGradPixelSdf.cpp:177-220 */
     bool save_sdf(std::string filename) override;                      /* MapGradPixelSdf.cpp:222-296 */
     bool extract_mesh(std::string filename) override;                  /* MapGradPixelSdf.cpp:124-175 */

@@ -151,6 +151,13 @@ int gsdf_merge_raw_dev(gsdf_ctx* c, const int32_t* keys_dev, const float* payloa
  * w[i]==0 marks a missing voxel (dist/grad are then 0; the reference's .at() would throw). */
 int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w);
 
+/* Voxel-hash raycaster: depth (camera z, 0 = no hit) and camera-frame normals (3 planes, nullable) of the
+ * fused map seen from pose (R, t) through K.  Named in BASELINE.json's north_star but ABSENT from the
+ * reference: it is defined on top of Sdf::weights / Sdf::tsdf (MapGradPixelSdf.h:109-125) and the
+ * tracker's back-projection (RigidPointOptimizer.cpp:46-47,67-70); DESIGN.md states the definition. */
+int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
+                 float* depth_out, float* normals_out);
+
 /* device-memory plumbing so callers can stage frames in HBM without another runtime */
 int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes);
 int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr);

@@ -393,6 +393,56 @@ void gsdfo_query(const gsdfo* o, const float* pts, int64_t n, float* dist, float
     }
 }
 
+/* ---- voxel-hash raycaster ----------------------------------------------------------------------
+ * BASELINE.json's north_star names a "voxel-hash raycaster"; the reference has none, so
+ * there is nothing to restate: this is the DEFINITION the HIP kernel k_raycast is checked against,
+ * built only from the reference's point query weights()/tsdf() (MapGradPixelSdf.h:109-125) and the
+ * tracker's back-projection (RigidPointOptimizer.cpp:46-47,67-70).  PARITY UNPINNED (self-defined).
+ *
+ * Pixel (u,v): d = R (x0, y0, 1), p(s) = s d + t, s = camera depth.  March s from zmin: 4 voxels per
+ * step while the voxel under p(s) is missing (the band in front of a surface is `factor` >= 4 voxels
+ * thick, so the walk cannot jump over it), 1 voxel per step inside the band.  A hit is the first sign
+ * change phi_prev < 0 <= phi (the reference's SDF is negative in front of the surface) between two consecutive in-band samples; depth = linear interpolation of
+ * s, normal = R^T grad/|grad| of the sample behind the surface (camera frame, like NormalEstimator). */
+void gsdfo_raycast(const gsdfo* o, const float K[9], const float R[9], const float t[3], int W, int H,
+                   float zmin, float zmax, float* depth, float* normals) {
+    const float fx_inv = 1.f / K[0], fy_inv = 1.f / K[4], cx = K[2], cy = K[5];
+    const float fine = o->voxel_size_, coarse = 4.f * o->voxel_size_;
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) {
+            const float x0 = ((float)u - cx) * fx_inv, y0 = ((float)v - cy) * fy_inv;
+            const V3 d = matvec(R, V3{ x0, y0, 1.f });
+            float out_z = 0.f;
+            V3 out_n = { 0.f, 0.f, 0.f };
+            bool prev_ok = false;
+            float phi_prev = 0.f, s_prev = 0.f;
+            for (float s = zmin; s < zmax;) {
+                const V3 p = { s * d.x + t[0], s * d.y + t[1], s * d.z + t[2] };
+                const SdfVoxel* vox; Key idx;
+                const float w0 = oracle_weights(o, p, &vox, &idx);
+                if (w0 > 0.f) {
+                    V3 g;
+                    const float phi = oracle_tsdf(o, *vox, idx, p, &g);
+                    if (prev_ok && phi_prev < 0.f && phi >= 0.f) {   /* the stored SDF is negative in front of the surface */
+                        out_z = s_prev + (s - s_prev) * (phi_prev / (phi_prev - phi));
+                        const V3 gn = normalized3(V3{ vox->grad[0], vox->grad[1], vox->grad[2] });
+                        out_n = V3{ sum3(R[0] * gn.x, R[3] * gn.y, R[6] * gn.z), sum3(R[1] * gn.x, R[4] * gn.y, R[7] * gn.z),
+                                    sum3(R[2] * gn.x, R[5] * gn.y, R[8] * gn.z) };
+                        break;
+                    }
+                    prev_ok = true; phi_prev = phi; s_prev = s;
+                    s += fine;
+                } else {
+                    prev_ok = false;
+                    s += coarse;
+                }
+            }
+            const size_t i = (size_t)v * W + u;
+            depth[i] = out_z;
+            if (normals) { normals[i] = out_n.x; normals[(size_t)W * H + i] = out_n.y; normals[2 * (size_t)W * H + i] = out_n.z; }
+        }
+}
+
 /* ---- Eigen / Sophus restatements (third-party code absent, unpinned) ---------------------- */
 
 /* Eigen::QuaternionBase::toRotationMatrix */

@@ -65,6 +65,12 @@ void   gsdfo_export_vis(const gsdfo* o, uint32_t* words, int words_per_voxel);
  * w[i]=0 when the voxel is absent (then dist/grad are 0; the reference would throw from .at()). */
 void   gsdfo_query(const gsdfo* o, const float* pts, int64_t n, float* dist, float* grad, float* w);
 
+/* Voxel-hash raycaster (named in BASELINE.json's north_star, ABSENT from the reference):
+ * self-defined on weights()/tsdf() (MapGradPixelSdf.h:109-125), see gsdf_oracle.cpp.  depth: H*W camera-z
+ * (0 = no hit); normals (nullable): 3 planes H*W, camera frame.  PARITY UNPINNED. */
+void   gsdfo_raycast(const gsdfo* o, const float K[9], const float R[9], const float t[3], int W, int H,
+                     float zmin, float zmax, float* depth, float* normals);
+
 /* RigidPointOptimizer::optimize_sampled(depth, K, 1) -- RigidPointOptimizer.cpp:40-99.
  * pose7 in/out.  trace (optional, may be NULL): per executed iteration 36 floats =
  * E, g[6], H upper-tri[21] row-major, count, xi[6], |xi|^2.  hits (optional) = N_hit per iteration.

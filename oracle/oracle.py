@@ -50,6 +50,7 @@ def lib():
         L.gsdfo_export.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp]
         L.gsdfo_export_vis.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
         L.gsdfo_query.argtypes = [C.c_void_p, fp, C.c_int64, fp, fp, fp]
+        L.gsdfo_raycast.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]
         L.gsdfo_track.restype = C.c_int
         L.gsdfo_track.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_float, C.c_float, C.c_int,
                                   C.POINTER(C.c_int), fp, C.POINTER(C.c_int64)]
@@ -135,6 +136,18 @@ class Oracle:
         w = np.empty(n, np.float32)
         self.L.gsdfo_query(self.h, _fp(p), n, _fp(dist), _fp(grad), _fp(w))
         return dist, grad, w
+
+    def raycast(self, R, t, zmin=0.5, zmax=3.5, W=None, H=None, K=None):
+        """Self-defined voxel-hash raycaster (absent from the reference): (depth[H,W], normals[3,H,W])."""
+        W = self.W if W is None else int(W)
+        H = self.H if H is None else int(H)
+        K = self.K if K is None else _f32(K).reshape(9)
+        R = _f32(R).reshape(9)
+        t = _f32(t).reshape(3)
+        d = np.zeros((H, W), np.float32)
+        n = np.zeros((3, H, W), np.float32)
+        self.L.gsdfo_raycast(self.h, _fp(K), _fp(R), _fp(t), W, H, np.float32(zmin), np.float32(zmax), _fp(d), _fp(n))
+        return d, n
 
     def track(self, depth, pose7, iters=25, conv=1e-3, damping=1.0, omp=False):
         """Returns (converged, pose7, iters_used, trace[iters_used,36], hits[iters_used])."""

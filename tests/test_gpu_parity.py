@@ -342,3 +342,31 @@ def test_vis_bitvectors_match_oracle(pkg, O):
     assert np.array_equal(vg, vo)
     assert (vg[:, 0] > 0).all() and vg[:, 1].max() == 0 and int(vg[:, 0].max()) < (1 << seq.n)
     g.close()
+
+
+def test_raycast_matches_definition_and_input_depth(pkg, O):
+    """Voxel-hash raycaster (north_star; absent from the reference): the HIP kernel against its CPU definition
+    (oracle.gsdfo_raycast, built on weights()/tsdf()), and self-consistency: rendering the fused map from
+    a fused pose gives the input depth back (within a voxel) and normals close to the input normals."""
+    seq, g, o = _mk(pkg, O, kind="tum", W=320, H=240, vs=0.01, trunc=10, cap=21, n=4)
+    for i in range(seq.n):
+        d, R, t = seq.frame(i)
+        g.update(d, R, t)
+        o.update(d, R, t)
+    d, R, t = seq.frame(1)
+    zg, ng = g.raycast(R, t)
+    zo, no = o.raycast(R, t)
+    hit_g, hit_o = zg > 0, zo > 0
+    assert (hit_g == hit_o).mean() > 0.999                      # borderline sign decisions may flip (sums differ in the last bits)
+    both = hit_g & hit_o
+    assert both.mean() > 0.5
+    dz = np.abs(zg - zo)[both]
+    assert np.percentile(dz, 99.9) <= TOL and np.median(dz) <= 1e-6
+    assert np.percentile(np.abs(ng - no)[:, both], 99.9) <= 1e-3
+    # self-consistency against the frame that was fused from this pose
+    m = both & (d > 0.5) & (d < 3.5)
+    assert np.median(np.abs(zg - d)[m]) < 0.01                  # one voxel
+    n_in = g.normals(d)
+    cosang = (n_in * ng).sum(axis=0)[m & np.isfinite(n_in).all(axis=0)]
+    assert np.median(cosang) > 0.95
+    g.close()

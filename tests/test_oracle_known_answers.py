@@ -243,3 +243,28 @@ def test_tracker_step_solves_the_normal_equations(O, pkg):
         assert np.abs(row[29:35] - xi).max() <= 2e-3 * max(1e-6, np.abs(xi).max())
         assert row[35] == pytest.approx(float((row[29:35].astype(np.float64) ** 2).sum()), rel=1e-5)
         assert row[28] == hits[0] or row[28] > 0
+
+
+def test_raycast_recovers_the_plane(O, pkg):
+    """The self-defined voxel-hash raycaster (absent from the reference): a fronto-parallel plane fused once is
+    rendered back at its depth (within half a voxel) with normal +z; a map seen from behind gives no hit."""
+    W, H = 160, 120
+    K = pkg.synth.intrinsics(W, H)
+    z0 = np.float32(1.5)
+    depth = np.full((H, W), z0, np.float32)
+    o = O.Oracle(VS, T10, W, H, K)
+    o.update(depth, np.eye(3), np.zeros(3))
+    z, n = o.raycast(np.eye(3), np.zeros(3))
+    assert (z > 0).all()
+    assert np.abs(z - z0).max() < 0.5 * float(VS)
+    inner = (slice(8, H - 8), slice(8, W - 8))
+    assert np.abs(n[2][inner] - 1).max() < 1e-3
+    # camera 3 m further down the axis, looking back at the plane from its far side: the SDF goes + -> -, no hit
+    Rb = np.diag([-1.0, 1.0, -1.0]).astype(np.float32)
+    zb, _ = o.raycast(Rb, np.array([0, 0, 3.0], np.float32))
+    assert (zb == 0).all()
+    # a window narrower than the band in front of the surface still finds it; one that ends before it does not
+    z2, _ = o.raycast(np.eye(3), np.zeros(3), zmin=1.45, zmax=1.6)
+    assert np.abs(z2 - z0).max() < 0.5 * float(VS)
+    z3, _ = o.raycast(np.eye(3), np.zeros(3), zmin=0.5, zmax=1.4)
+    assert (z3 == 0).all()
