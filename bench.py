@@ -204,7 +204,9 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            traffic = json.load(f).get("traffic_bytes_per_fusion")
+            # measured on the default workload only: report it for that workload, null otherwise
+            if (W, H) == (640, 480) and abs(float(vs) - 0.01) < 1e-6 and args.trunc == 10.0:
+                traffic = json.load(f).get("traffic_bytes_per_fusion")
     except (OSError, ValueError):
         pass
 
