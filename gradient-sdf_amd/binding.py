@@ -31,7 +31,8 @@ class GsdfError(RuntimeError):
 
 class Stats(C.Structure):
     _fields_ = [("n_upd", C.c_int64), ("n_valid", C.c_int64), ("n_hit", C.c_int64),
-                ("track_passes", C.c_int32), ("converged", C.c_int32), ("frames", C.c_int64)]
+                ("track_passes", C.c_int32), ("converged", C.c_int32), ("frames", C.c_int64),
+                ("n_deferred", C.c_int64), ("fuse_timeouts", C.c_int64)]
 
 
 def build(force=False):

@@ -529,6 +529,8 @@ int gsdf_get_stats(gsdf_ctx* c, gsdf_stats* out) {
     out->track_passes = s.passes;
     out->converged = s.converged;
     out->frames = s.frames;
+    out->n_deferred = (int64_t)s.n_deferred;
+    out->fuse_timeouts = (int64_t)s.fuse_timeouts;
     return GSDF_OK;
 }
 

@@ -44,6 +44,7 @@ struct gsdf_dev_state {
     int status;                   /* GSDF_STATUS_* bits, sticky */
     int pad0;
     unsigned long long n_upd, n_valid, n_hit, n_occupied;
+    unsigned long long n_deferred; /* contributions added by k_fuse_resolve so far */
     long long frames;             /* Sdf::counter_ */
     long long log_rows;
     long long frame_cur;          /* counter_ snapshot for the running update (k_normals -> k_fuse) */

@@ -769,7 +769,8 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
 /* adds the deferred contributions (voxels shared by several tiles, LDS overflow) after k_fuse.
  * The list counter is cleared by the k_normals launch that precedes every k_fuse. */
 __global__ __launch_bounds__(256) void k_fuse_resolve(const gsdf_deferred* list, const unsigned int* count, unsigned int cap,
-                                                       gsdf_dev_state* gate, float* log_rows, long long max_rows) {
+                                                       gsdf_dev_state* gate, gsdf_dev_state* st, float* log_rows,
+                                                       long long max_rows) {
     /* per-frame log row: pose7, converged, passes, hits of the last pass (main_scan_3d.cpp:268-280) */
     if (log_rows && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long r = gate->log_rows;
@@ -783,6 +784,7 @@ __global__ __launch_bounds__(256) void k_fuse_resolve(const gsdf_deferred* list,
     if (gate && !gate->converged) return;
     unsigned int n = *count;
     n = n < cap ? n : cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_deferred += n;
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const gsdf_deferred d = list[i];
         unsafeAtomicAdd(&d.p->w, d.w);
@@ -814,7 +816,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
         n += ((ntx - (c & 1) + 1) / 2) * ((nty - (c >> 1) + 1) / 2);
     }
     hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), (g_fuse_debug & 4096) ? 8192 : 0, s, a);   /* experiment: 1 workgroup per CU */
-    hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate,
+    hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st,
                        use_dev_pose ? log_rows : nullptr, max_rows);
 }
 int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T); }

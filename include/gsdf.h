@@ -51,6 +51,9 @@ typedef struct gsdf_stats {
     int32_t track_passes; /* tracker reduction passes executed in the last optimize()   */
     int32_t converged;    /* result of the last optimize()                              */
     int64_t frames;       /* Sdf::counter_ (Sdf.h:65)                                   */
+    int64_t n_deferred;   /* voxel contributions that took the deferred (float-atomic) route of the fusion flush
+                             since create/reset: near tiles, LDS overflow, timed-out waits (0 in steady state)  */
+    int64_t fuse_timeouts;/* fusion tiles whose bounded wait for a neighbouring tile expired (they deferred)     */
 } gsdf_stats;
 
 const char* gsdf_last_error(void);

@@ -85,6 +85,9 @@ def test_fusion_forced_paths_match_oracle(pkg, O, flags, name):
     finally:
         L.gsdf_debug_flags(0)
     assert _cmp_tables(g, o) > 10000
+    st = g.stats()
+    assert st["fuse_timeouts"] == 0
+    assert (st["n_deferred"] > 10000) == bool(flags & 4) or flags == 256      # only the forced-deferred runs defer wholesale
     g.close()
 
 
@@ -97,7 +100,7 @@ def test_fusion_handoff_loses_nothing_at_full_size(pkg):
     seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=3)
     vs = np.float32(0.01); T = np.float32(10) * vs
     L = pkg.binding.load()
-    out = []
+    out, stats = [], []
     for flags in (0, 4):
         g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=22)
         L.gsdf_debug_flags(flags)
@@ -109,8 +112,11 @@ def test_fusion_handoff_loses_nothing_at_full_size(pkg):
         finally:
             L.gsdf_debug_flags(0)
         out.append(g.export(sorted=True, raw=True))
+        stats.append(g.stats())
         g.close()
     (ka, pa), (kb, pb) = out
+    assert stats[0]["fuse_timeouts"] == 0 and stats[0]["n_deferred"] < 10000   # the fast path really ran (a few LDS overflows defer)
+    assert stats[1]["n_deferred"] > 1000000
     assert np.array_equal(ka, kb)
     assert ka.shape[0] > 1000000
     scale = np.maximum(1.0, np.abs(pb[:, 4:5]))
