@@ -63,6 +63,7 @@ struct gsdf_ctx {
     unsigned int deferred_cap = 0;
     unsigned int fuse_tag = 0;                     /* serial of the last fusion launch */
     unsigned int* tile_flags = nullptr;            /* per-tile hand-off flags of k_fuse */
+    uint32_t* tile_order = nullptr;                /* launch order of the fusion tiles (gsdf_fuse_tile_order) */
     uint32_t* vis = nullptr;                       /* optional vis_ bit-vectors, n_slots x vis_words */
     int vis_words = 0;
     /* PhotoBA (PhotometricOptimizer) */
@@ -173,7 +174,7 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
         }
         gsdf_launch_fuse(c->stream, g, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N, pose,
                          use_dev_pose, c->tab, c->st, c->blk_counters, c->deferred, c->deferred_count,
-                         c->deferred_cap, c->fuse_tag, c->tile_flags, c->frame_log, c->frame_log_cap, c->vis, c->vis_words);
+                         c->deferred_cap, c->fuse_tag, c->tile_flags, c->tile_order, c->frame_log, c->frame_log_cap, c->vis, c->vis_words);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
@@ -308,7 +309,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     void* ptrs[] = { c->tab.vox, c->tab.bkeys, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
-                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->tile_flags, c->vis, c->ba_images, c->ba_Rt,
+                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->progress) (void)hipHostFree((void*)c->progress);
@@ -345,9 +346,9 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     void* old[] = { c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log, c->deferred,
-                    c->deferred_count, c->tile_flags };
+                    c->deferred_count, c->tile_flags, c->tile_order };
     for (void* p : old) if (p) (void)hipFree(p);
-    c->tile_flags = nullptr;
+    c->tile_flags = nullptr; c->tile_order = nullptr;
     c->planes = c->depth_stage = c->normals = c->partials = nullptr;
     c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr;
     c->W = W; c->H = H; c->win = win;
@@ -365,6 +366,12 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipMalloc((void**)&c->tile_flags, (size_t)c->fuse_blocks * sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(c->tile_flags, 0, (size_t)c->fuse_blocks * sizeof(unsigned int), c->stream));
+    {
+        std::vector<uint32_t> order((size_t)c->fuse_blocks);
+        gsdf_fuse_tile_order(W, H, order.data());
+        HIP_TRY(hipMalloc((void**)&c->tile_order, order.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(c->tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     /* deferred list: contributions of near tiles and LDS overflow; bounded by the samples of a frame */
     c->deferred_cap = (unsigned int)std::min<size_t>((size_t)1 << 26, std::max<size_t>((size_t)1 << 18,
                                                      N * (size_t)(2 * c->factor + 1)));   /* every sample of a frame */

@@ -16,6 +16,7 @@
 #include "gsdf_math.h"
 
 #include <hip/hip_runtime.h>
+#include <vector>
 
 #define FULL_MASK 0xFFFFFFFFFFFFFFFFull
 
@@ -256,7 +257,8 @@ struct fuse_args {
     unsigned int tag;                   /* serial of this fusion launch, never 0: value of a published tile flag */
     unsigned int* tile_flags;           /* [nty][ntx]: tag of the last launch in which the tile finished its flush */
     int ntx, nty;                       /* tiles per image row / column */
-    int first[4];                       /* first workgroup of each colour (workgroups are numbered colour-major) */
+    const uint32_t* tile_order;         /* workgroup -> tile (x | y << 16): colour-major, and workgroup b (which runs on
+                                           XCD b % 8) gets a tile of image stripe b % 8, so neighbouring tiles share an L2 */
     uint32_t* vis;                      /* optional per-voxel frame bit-vectors (vis_, MapGradPixelSdf.h:70); nullable */
     int vis_words;
     int debug;                          /* experiment switches (gsdf_debug_flags); 0 in production */
@@ -338,10 +340,8 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     const int zhalf = wave >> 2;
     const int lx = lane & 7, ly = lane >> 3;
     const int bid = (int)blockIdx.x;
-    const int col = (bid >= a.first[1]) + (bid >= a.first[2]) + (bid >= a.first[3]);
-    const int ntx_c = (a.ntx - (col & 1) + 1) >> 1;
-    const int tile_x = 2 * ((bid - a.first[col]) % ntx_c) + (col & 1);
-    const int tile_y = 2 * ((bid - a.first[col]) / ntx_c) + (col >> 1);
+    const uint32_t tile_id = a.tile_order[bid];
+    const int tile_x = (int)(tile_id & 0xFFFFu), tile_y = (int)(tile_id >> 16);
     bool valid = false;
     float z = 0.f;
     gsdf_v3 Rxy = { 0.f, 0.f, 0.f }, Rn = { 0.f, 0.f, 0.f };
@@ -799,8 +799,8 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
                       int use_dev_pose, gsdf_table tab, gsdf_dev_state* st, unsigned long long* blk_counters,
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
-                      unsigned int tag, unsigned int* tile_flags, float* log_rows, long long max_rows, uint32_t* vis,
-                      int vis_words) {
+                      unsigned int tag, unsigned int* tile_flags, const uint32_t* tile_order, float* log_rows,
+                      long long max_rows, uint32_t* vis, int vis_words) {
     fuse_args a;
     a.vis = vis; a.vis_words = vis_words;
     a.debug = g_fuse_debug;
@@ -809,17 +809,41 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     a.deferred = deferred; a.deferred_count = deferred_count; a.deferred_cap = deferred_cap; a.tag = tag;
     const int ntx = (g.W + FUSE_T - 1) / FUSE_T, nty = (g.H + FUSE_T - 1) / FUSE_T;
     gsdf_dev_state* gate = use_dev_pose ? st : nullptr;
-    a.tile_flags = tile_flags; a.ntx = ntx; a.nty = nty;
-    int n = 0;
-    for (int c = 0; c < 4; ++c) {                 /* colour-major numbering: a tile only waits for lower colours */
-        a.first[c] = n;
-        n += ((ntx - (c & 1) + 1) / 2) * ((nty - (c >> 1) + 1) / 2);
-    }
+    a.tile_flags = tile_flags; a.ntx = ntx; a.nty = nty; a.tile_order = tile_order;
+    const int n = ntx * nty;
     hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), (g_fuse_debug & 4096) ? 8192 : 0, s, a);   /* experiment: 1 workgroup per CU */
     hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st,
                        use_dev_pose ? log_rows : nullptr, max_rows);
 }
 int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T); }
+/* Launch order of the fusion tiles.  Colour-major (colour = parity of tile x, y): a tile only ever waits for tiles
+ * of lower colour, which were dispatched before it.  Within that, workgroup b -- which the hardware places on XCD
+ * b % 8 (observed; a performance assumption only) -- takes its tile from vertical image stripe b % 8, so the tiles
+ * that share voxel records and block keys meet in one XCD's L2. */
+void gsdf_fuse_tile_order(int W, int H, uint32_t* order) {
+    const int ntx = (W + FUSE_T - 1) / FUSE_T, nty = (H + FUSE_T - 1) / FUSE_T;
+    std::vector<uint32_t> lists[4][8];
+    for (int ty = 0; ty < nty; ++ty)
+        for (int tx = 0; tx < ntx; ++tx)
+            lists[(tx & 1) + 2 * (ty & 1)][(int)((long long)tx * 8 / ntx)].push_back((uint32_t)tx | ((uint32_t)ty << 16));
+    size_t next[4][8] = {};
+    int b = 0;
+    for (int c = 0; c < 4; ++c) {
+        size_t left = 0;
+        for (int r = 0; r < 8; ++r) left += lists[c][r].size();
+        for (; left > 0; --left, ++b) {
+            int r = b % 8;
+            if (next[c][r] >= lists[c][r].size()) {           /* stripe exhausted: take from the fullest one */
+                size_t best = 0;
+                for (int q = 0; q < 8; ++q) {
+                    const size_t rem = lists[c][q].size() - next[c][q];
+                    if (rem > best) { best = rem; r = q; }
+                }
+            }
+            order[b] = lists[c][r][next[c][r]++];
+        }
+    }
+}
 
 /* ------------------------------------------------------------------------------------------------
  * RigidPointOptimizer::optimize_sampled -- one Gauss-Newton pass per launch.
