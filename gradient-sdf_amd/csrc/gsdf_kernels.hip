@@ -207,27 +207,27 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 /* ------------------------------------------------------------------------------------------------
  * MapGradPixelSdf::update -- fusion.
  *
- * Work decomposition: one workgroup = one 16x16 pixel tile (4 waves, each an 8x8 sub-tile so a
- * wave's 64 rays stay spatially compact) x one half of the ray walk (blockIdx.z: k <= 0 / k > 0).
- * Each lane walks its ray's samples.  Neighbouring pixels and consecutive samples hit the same
- * voxels (~5 updates per distinct voxel per frame), so updates are first combined in a
- * workgroup-private bucketed hash table in LDS; only the distinct voxels of the tile are flushed
- * to the HBM table.
+ * Work decomposition: one workgroup = one 16x16 pixel tile, 512 lanes = 4 waves (each an 8x8
+ * sub-tile, so a wave's 64 rays stay spatially compact) x 2 halves of the ray walk.  Each lane walks
+ * its ray's samples.  Neighbouring pixels and consecutive samples hit the same voxels (~4.5 updates
+ * per distinct voxel per frame), so updates are first combined in a workgroup-private hash table in
+ * LDS; only the distinct voxels of the tile are flushed to the HBM map.  Far tiles / small voxels
+ * (more distinct voxels than the table holds) are walked as 2 or 4 row bands, each flushed on its own.
  *
- * What the MI355X measurements (tools/atomics_bench.hip, profiles/) dictated:
+ * What the MI355X measurements (tools/atomics_bench.hip, tools/fuse_ablate.py, profiles/) dictated:
  *  - ds_add_f32 is lane-serial (~190 cycles per wave instruction), ds_add_u64 costs 8-29: the
- *    LDS accumulators are 64-bit FIXED POINT (2^-40).  Every float term converts exactly, so the
- *    per-tile sums are exact and order-independent; one rounding to float happens at the flush.
- *  - LDS lookups are latency chains (read bucket -> compare -> CAS): three samples per lane are
- *    in flight at once, a bucket (4 keys) is fetched with two ds_read_b128, and at most one CAS
- *    is issued per probe.  Lanes start at skewed sample indices so that neighbouring lanes (same
- *    voxel at the same k) do not serialise on one LDS address.
- *  - device-scope atomics run at only ~20-50 G/s chip-wide, so the flush takes OWNERSHIP instead
- *    of adding atomically: one atomicExch of the per-launch tag on the voxel's aux word; the first
- *    tile to tag a voxel updates its payload with plain loads/stores (nobody else touches it in
- *    this launch), every later tile appends its contribution to a deferred list that k_fuse_resolve
- *    adds after the launch.  ~84 % of the (tile, voxel) pairs are owners: 1 atomic instead of 5.
- * Samples that do not fit the LDS table go to the deferred list as well.
+ *    LDS accumulators are 64-bit FIXED POINT (2^-40); sums are exact and order-independent, one
+ *    rounding to float happens at the flush.
+ *  - the LDS lookup dominated: 32-bit TILE-LOCAL keys (one ds_read_b128 per bucket of 4) and a
+ *    LATTICE hash of the local coordinates bring it to ~1 probe iteration per wave-sample (a random
+ *    hash of 64-bit keys needed 2.8); three samples per lane are in flight, and samples no lane still
+ *    waits for are skipped with wave-uniform branches.
+ *  - device-scope atomics run at only ~20-50 G/s chip-wide: the flush uses NONE.  Tiles hand their
+ *    voxels on in colour order with plain read-modify-write (see the flush); only tiles that are too
+ *    near for that, timed-out waits and LDS overflow go through a deferred list that k_fuse_resolve
+ *    adds with float atomics after the launch.
+ *  - the kernel is VALU-issue / latency bound at 2 workgroups (16 waves) per CU: instruction count
+ *    matters more than bytes (double-rate fixed-point conversion, packed f32 math, uniform skips).
  * ---------------------------------------------------------------------------------------------- */
 #define FUSE_T 16
 #define FUSE_THREADS 512                 /* 4 waves (8x8 pixels each) x 2 halves of the ray walk */
@@ -237,8 +237,6 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #define FUSE_LKEY_DEFER 0x80000000u      /* flush: the entry goes to the deferred list, low 31 bits = voxel record index */
 #define FUSE_LPROBE 12
 #define FUSE_BATCH 3
-#define FUSE_ZSPLIT 2
-typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t gsdf_u32x4 __attribute__((ext_vector_type(4)));
 
 struct fuse_args {
