@@ -605,9 +605,9 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
      *      (Dispatch order is only a performance assumption: the wait is bounded, and a tile whose wait
      *      times out defers its contributions instead.)
      * Hand-off between workgroups (other CUs, other XCDs: neither L1 nor the per-XCD L2s are coherent for
-     * plain accesses): payloads are read and written with agent-scope (sc1) 8-byte accesses, every
+     * plain accesses): voxel records are read and written with agent-scope (sc1) 16-byte accesses, every
      * storing wave drains its stores, then one lane publishes the tile's flag with an agent-scope store.
-     * Bucket keys are insert-only, so plain (possibly stale) key loads can only show EMPTY and the CAS
+     * Block keys are insert-only, so plain (possibly stale) key loads can only show EMPTY and the CAS
      * settles it.  Each lane owns FUSE_LCAP/FUSE_THREADS LDS slots and drives them through the stages
      * together, so the dependent HBM round trips (bucket keys -> payload) of its entries overlap. */
     if (!(a.debug & 1)) {
