@@ -376,3 +376,19 @@ def test_raycast_matches_definition_and_input_depth(pkg, O):
     cosang = (n_in * ng).sum(axis=0)[m & np.isfinite(n_in).all(axis=0)]
     assert np.median(cosang) > 0.95
     g.close()
+
+
+def test_argument_errors_of_the_newer_entries(pkg):
+    """Error behaviour of entries added after the first ABI: bad arguments are reported, nothing crashes."""
+    import ctypes as C
+    L = pkg.binding.load()
+    with pytest.raises(pkg.binding.GsdfError):
+        pkg.GradSdf(np.float32(0.01), np.float32(0.1), 64, 48, pkg.synth.intrinsics(64, 48), capacity_log2=31)
+    g = pkg.GradSdf(np.float32(0.02), np.float32(0.1), 64, 48, pkg.synth.intrinsics(64, 48), capacity_log2=14)
+    with pytest.raises(pkg.binding.GsdfError):
+        g.raycast(np.eye(3), np.zeros(3), zmin=1.0, zmax=0.5)
+    z, n = g.raycast(np.eye(3), np.zeros(3))                  # empty map: no hits, no NaN
+    assert (z == 0).all() and (n == 0).all()
+    st = g.stats()
+    assert st["n_deferred"] == 0 and st["fuse_timeouts"] == 0
+    g.close()

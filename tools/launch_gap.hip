@@ -33,5 +33,26 @@ int main() {
                             std::chrono::duration<double, std::micro>(t1 - t0).count() / N, std::chrono::duration<double, std::micro>(t2 - t0).count() / N);
         }
     }
+    // GPU-side boundary: the same chains replayed from a captured graph (no host launch cost between kernels)
+    for (int cfg = 1; cfg < 4; ++cfg) {
+        const int wg = 256, thr = cfg == 3 ? 512 : 256, N = 500;
+        hipGraph_t graph; hipGraphExec_t exec;
+        hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+        for (int i = 0; i < N; ++i) {
+            if (cfg < 2) hipLaunchKernelGGL(k_trivial, dim3(wg), dim3(thr), 0, st, p, i);
+            else hipLaunchKernelGGL(k_rows, dim3(wg), dim3(thr), 0, st, (i & 1) ? r1 : r0, (i & 1) ? r0 : r1, wg);
+        }
+        hipStreamEndCapture(st, &graph);
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipStreamSynchronize(st);
+            auto t0 = std::chrono::steady_clock::now();
+            hipGraphLaunch(exec, st);
+            hipStreamSynchronize(st);
+            auto t2 = std::chrono::steady_clock::now();
+            if (rep == 2) printf("graph cfg %d (%d WG x %d thr, %s): %.2f us/kernel\n", cfg, wg, thr, cfg < 2 ? "trivial" : "rows",
+                                 std::chrono::duration<double, std::micro>(t2 - t0).count() / N);
+        }
+    }
     return 0;
 }
