@@ -54,7 +54,8 @@ struct gsdf_ctx {
     float* normals = nullptr;                      /* 3 planes */
     /* tracker */
     gsdf_dev_state* st = nullptr;
-    float* partials = nullptr;
+    double* partials = nullptr;                    /* 3 rotating buffers of tracker partial sums */
+    unsigned int track_rot = 0;                    /* tracker launches issued so far (selects the buffers) */
     int track_blocks = 0;
     unsigned long long* blk_counters = nullptr;
     int fuse_blocks = 0;
@@ -207,6 +208,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     for (int k = 0; k <= iters; ++k) {
         if (adaptive && c->progress[1] == tp.serial) break;  /* device finished this optimize() */
         tp.pass_index = k;
+        tp.rot = c->track_rot++;
         {
             prof_scope ps(c, 2);
             gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks, tp);
@@ -349,7 +351,7 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
                     c->deferred_count, c->tile_flags, c->tile_order };
     for (void* p : old) if (p) (void)hipFree(p);
     c->tile_flags = nullptr; c->tile_order = nullptr;
-    c->planes = c->depth_stage = c->normals = c->partials = nullptr;
+    c->planes = c->depth_stage = c->normals = nullptr; c->partials = nullptr;
     c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr;
     c->W = W; c->H = H; c->win = win;
     std::memcpy(c->K, K, 9 * sizeof(float));
@@ -360,7 +362,9 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     /* tracker grid: a multiple of the 256 CUs when the frame is large enough, 1-4 pixels per lane */
     c->track_blocks = N >= (size_t)1 << 20 ? 2 * GSDF_TRACK_MAXBLK : N >= (size_t)1 << 18 ? GSDF_TRACK_MAXBLK
                                                 : (int)std::max<size_t>(1, (N + 511) / 512);
-    HIP_TRY(hipMalloc((void**)&c->partials, (size_t)2 * c->track_blocks * 32 * sizeof(float)));   /* two row sets */
+    HIP_TRY(hipMalloc((void**)&c->partials, (size_t)3 * GSDF_TRACK_ROWSET * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->partials, 0, (size_t)3 * GSDF_TRACK_ROWSET * sizeof(double), c->stream));
+    c->track_rot = 0;
     c->fuse_blocks = gsdf_fuse_grid_blocks(W, H);
     HIP_TRY(hipMalloc((void**)&c->blk_counters, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));

@@ -21,6 +21,8 @@
                                     (measured: 512 x 256 thr 16.3 us per pass, 256 x 512 thr 13.8, 1024 x 256 thr 21.4) */
 #endif
 #define GSDF_TRACK_NSUM    29     /* E, g[6], H upper triangle[21], count */
+#define GSDF_TRACK_GROUPS  32     /* partial-sum groups of a tracker pass (workgroup b -> group b % 32) */
+#define GSDF_TRACK_ROWSET  (GSDF_TRACK_GROUPS * 32)   /* doubles per buffer; three buffers rotate */
 
 /* Device-resident engine state: the tracker's pose (RigidOptimizer::pose_, RigidOptimizer.h:64),
  * per-optimize flags, sticky launch status and the counters the stats API reports. */
@@ -100,10 +102,12 @@ struct gsdf_track_params {
     unsigned int serial;          /* optimize() call number, for the host progress words */
     unsigned int* progress;       /* pinned host memory: [0] = serial<<8 | passes, [1] = serial when done; nullable */
     int debug;                    /* experiment switches (gsdf_debug_flags >> 8); 0 in production */
+    unsigned int rot;             /* number of tracker launches issued on this context so far: selects the sum buffers */
 };
 void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st);
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
-                            gsdf_dev_state* st, float* partials, int n_blocks, const gsdf_track_params& tp);
+                            gsdf_dev_state* st, double* partials /* 3 * GSDF_TRACK_ROWSET, zeroed */, int n_blocks,
+                            const gsdf_track_params& tp);
 void gsdf_launch_set_pose(hipStream_t s, gsdf_dev_state* st, const float* pose7_dev_or_null,
                           const float pose7_host[7]);
 void gsdf_launch_export(hipStream_t s, gsdf_table tab, size_t n_slots, unsigned long long* keys_out,

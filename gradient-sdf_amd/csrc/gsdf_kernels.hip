@@ -867,14 +867,27 @@ void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st) { hipLaunchKernel
 
 __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
                                                                  gsdf_table tab, gsdf_dev_state* st,
-                                                                 float* rows, int rows_stride, gsdf_track_params tp) {
+                                                                 double* rows, gsdf_track_params tp) {
     __shared__ float wsum[GSDF_TRACK_BLOCK / 64][32];
+    __shared__ double gsum[GSDF_TRACK_BLOCK / 32][32];
     __shared__ float tot[32];
     __shared__ float sh_pose[8];
     __shared__ int sh_done;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = tp.pass_index;
     float pose[7];
+    /* Partial sums of a pass: 32 groups x 32 doubles (29 used); workgroup b adds its sums to group b % 32 with
+     * f64 atomics, so the next launch's head reads 8 KB instead of one 128-byte row per workgroup (32 KB at 256
+     * workgroups -- that re-reduction was ~25 % of a pass).  Three buffers rotate with the launch number (which
+     * runs on across optimize() calls, tp.rot): launch j accumulates into buffer j % 3, reads j - 1 and clears
+     * j + 1, which nothing has touched since launch j - 2 read it.  Every launch does the clearing first, also
+     * the ones that return early. */
+    double* acc_cur = rows + (size_t)(tp.rot % 3u) * GSDF_TRACK_ROWSET;
+    const double* acc_prev = rows + (size_t)((tp.rot + 2u) % 3u) * GSDF_TRACK_ROWSET;
+    if (blockIdx.x == 0) {
+        double* nxt = rows + (size_t)((tp.rot + 1u) % 3u) * GSDF_TRACK_ROWSET;
+        for (int i = threadIdx.x; i < GSDF_TRACK_ROWSET; i += GSDF_TRACK_BLOCK) nxt[i] = 0.0;
+    }
 
     if (k == 0) {
         /* a new optimize(): the pose is RigidOptimizer::pose_ (kept in st->pose7 between frames) */
@@ -892,34 +905,22 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
          * another one inside a launch; workgroup 0 publishes the result for the next launch / the host ---- */
         /* the row reads do not depend on the state words: issue them first so that both memory round
          * trips overlap (a launch that finds `done` set wasted 16 loads per lane, and is rare) */
-        const float* prev = rows + (size_t)((k - 1) & 1) * rows_stride;
-        const int r8 = lane >> 3, c4 = lane & 7;
-        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        /* coalesced: 8 lanes read one 128-byte row (16 B each), a wave reads 8 rows per instruction;
-         * lane (r8, c4) accumulates columns 4*c4..4*c4+3 over its rows in increasing order */
-        for (unsigned int b = (unsigned int)(wave * 8 + r8); b < gridDim.x; b += 8 * (GSDF_TRACK_BLOCK / 64)) {
-            const float4 v = *reinterpret_cast<const float4*>(prev + (size_t)b * 32 + 4 * c4);
-            a4.x += v.x; a4.y += v.y; a4.z += v.z; a4.w += v.w;
-        }
+        /* lane (g, v) = (tid / 32, tid % 32) sums groups g, g + T/32, ... of value v, in increasing order */
+        double gs = 0.0;
+        for (int grp = tid >> 5; grp < GSDF_TRACK_GROUPS; grp += GSDF_TRACK_BLOCK / 32) gs += acc_prev[grp * 32 + (tid & 31)];
         const gsdf_trk_buf& in = st->trk[(k - 1) & 1];
         const int in_done = in.done;
 #pragma unroll
         for (int i = 0; i < 7; ++i) pose[i] = in.pose7[i];
         const int passes = in.passes + 1;
         if (in_done) return;                                              /* this optimize() already ended */
-        /* the 8 row groups of a wave are combined with xor shuffles, the 4 waves through LDS */
-#pragma unroll
-        for (int m = 8; m < 64; m <<= 1) {
-            a4.x += __shfl_xor(a4.x, m); a4.y += __shfl_xor(a4.y, m);
-            a4.z += __shfl_xor(a4.z, m); a4.w += __shfl_xor(a4.w, m);
-        }
-        if (r8 == 0) { wsum[wave][4 * c4] = a4.x; wsum[wave][4 * c4 + 1] = a4.y; wsum[wave][4 * c4 + 2] = a4.z; wsum[wave][4 * c4 + 3] = a4.w; }
+        gsum[tid >> 5][tid & 31] = gs;
         __syncthreads();
         if (tid < GSDF_TRACK_NSUM) {
-            float v = wsum[0][tid];
+            double v = gsum[0][tid];
 #pragma unroll
-            for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
-            tot[tid] = v;
+            for (int w = 1; w < GSDF_TRACK_BLOCK / 32; ++w) v += gsum[w][tid];
+            tot[tid] = (float)v;
         }
         __syncthreads();
         if (tid == 0) {
@@ -1086,14 +1087,14 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
             for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
         }
-        rows[(size_t)(k & 1) * rows_stride + (size_t)blockIdx.x * 32 + tid] = v;   /* read by the next launch's head */
+        /* the workgroup's sums (float, fixed order) join its group; f64 adds of ~256 terms stay far below float
+         * resolution whatever their order */
+        if (tid < GSDF_TRACK_NSUM) unsafeAtomicAdd(&acc_cur[(blockIdx.x % GSDF_TRACK_GROUPS) * 32 + tid], (double)v);
     }
 }
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
-                            gsdf_dev_state* st, float* partials, int n_blocks, const gsdf_track_params& tp) {
-    /* partials holds two row sets (pass parity): a launch reads the previous set while writing its own */
-    hipLaunchKernelGGL(k_track_pass, dim3(n_blocks), dim3(GSDF_TRACK_BLOCK), 0, s, g, depth, tab, st, partials,
-                       n_blocks * 32, tp);
+                            gsdf_dev_state* st, double* partials, int n_blocks, const gsdf_track_params& tp) {
+    hipLaunchKernelGGL(k_track_pass, dim3(n_blocks), dim3(GSDF_TRACK_BLOCK), 0, s, g, depth, tab, st, partials, tp);
 }
 
 struct pose7_arg { float p[7]; };
