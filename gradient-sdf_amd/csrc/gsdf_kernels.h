@@ -21,7 +21,9 @@
                                     (measured: 512 x 256 thr 16.3 us per pass, 256 x 512 thr 13.8, 1024 x 256 thr 21.4) */
 #endif
 #define GSDF_TRACK_NSUM    29     /* E, g[6], H upper triangle[21], count */
-#define GSDF_TRACK_GROUPS  32     /* partial-sum groups of a tracker pass (workgroup b -> group b % 32) */
+#ifndef GSDF_TRACK_GROUPS
+#define GSDF_TRACK_GROUPS  16     /* partial-sum groups of a tracker pass (workgroup b -> group b % 16); 8..32 measured within 0.4 us, 64 slower */
+#endif
 #define GSDF_TRACK_ROWSET  (GSDF_TRACK_GROUPS * 32)   /* doubles per buffer; three buffers rotate */
 
 /* Device-resident engine state: the tracker's pose (RigidOptimizer::pose_, RigidOptimizer.h:64),

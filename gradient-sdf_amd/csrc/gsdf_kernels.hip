@@ -876,8 +876,8 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = tp.pass_index;
     float pose[7];
-    /* Partial sums of a pass: 32 groups x 32 doubles (29 used); workgroup b adds its sums to group b % 32 with
-     * f64 atomics, so the next launch's head reads 8 KB instead of one 128-byte row per workgroup (32 KB at 256
+    /* Partial sums of a pass: GSDF_TRACK_GROUPS groups x 32 doubles (29 used); workgroup b adds its sums to group
+     * b % GROUPS with f64 atomics, so the next launch's head reads 4 KB instead of one 128-byte row per workgroup (32 KB at 256
      * workgroups -- that re-reduction was ~25 % of a pass).  Three buffers rotate with the launch number (which
      * runs on across optimize() calls, tp.rot): launch j accumulates into buffer j % 3, reads j - 1 and clears
      * j + 1, which nothing has touched since launch j - 2 read it.  Every launch does the clearing first, also
