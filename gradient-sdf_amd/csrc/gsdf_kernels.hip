@@ -865,141 +865,55 @@ void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st) { hipLaunchKernel
 #define TRK_PPT 3          /* pixels per lane handled as one batch: independent gathers in flight */
 #endif
 
-__global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
-                                                                 gsdf_table tab, gsdf_dev_state* st,
-                                                                 double* rows, gsdf_track_params tp) {
-    __shared__ float wsum[GSDF_TRACK_BLOCK / 64][32];
-    __shared__ double gsum[GSDF_TRACK_BLOCK / 32][32];
-    __shared__ float tot[32];
-    __shared__ float sh_pose[8];
-    __shared__ int sh_done;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = tp.pass_index;
-    float pose[7];
-    /* Partial sums of a pass: GSDF_TRACK_GROUPS groups x 32 doubles (29 used); workgroup b adds its sums to group
-     * b % GROUPS with f64 atomics, so the next launch's head reads 4 KB instead of one 128-byte row per workgroup (32 KB at 256
-     * workgroups -- that re-reduction was ~25 % of a pass).  Three buffers rotate with the launch number (which
-     * runs on across optimize() calls, tp.rot): launch j accumulates into buffer j % 3, reads j - 1 and clears
-     * j + 1, which nothing has touched since launch j - 2 read it.  Every launch does the clearing first, also
-     * the ones that return early. */
-    double* acc_cur = rows + (size_t)(tp.rot % 3u) * GSDF_TRACK_ROWSET;
-    const double* acc_prev = rows + (size_t)((tp.rot + 2u) % 3u) * GSDF_TRACK_ROWSET;
-    if (blockIdx.x == 0) {
-        double* nxt = rows + (size_t)((tp.rot + 1u) % 3u) * GSDF_TRACK_ROWSET;
-        for (int i = threadIdx.x; i < GSDF_TRACK_ROWSET; i += GSDF_TRACK_BLOCK) nxt[i] = 0.0;
-    }
-
-    if (k == 0) {
-        /* a new optimize(): the pose is RigidOptimizer::pose_ (kept in st->pose7 between frames) */
+/* One Gauss-Newton step from the 29 sums (RigidPointOptimizer.cpp:86-98): solve, test, apply.  `passes` counts
+ * this pass.  Identical arithmetic wherever it runs (every workgroup computes it redundantly). */
+__device__ __forceinline__ void trk_solve_update(const float* tot, float damping, float conv_sq, int passes, int max_passes,
+                                                 int no_solve, float pose[7], int* done, int* converged) {
+    float gvec[6], Hm[36];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) pose[i] = st->pose7[i];
-        if (blockIdx.x == 0 && tid == 0) {
-            gsdf_trk_buf& o = st->trk[0];
+    for (int i = 0; i < 6; ++i) gvec[i] = tot[1 + i];
+    int q = 7;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) o.pose7[i] = pose[i];
-            o.done = 0; o.converged = 0; o.passes = 0;
-        }
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) { Hm[6 * i + j] = tot[q]; Hm[6 * j + i] = tot[q]; ++q; }
+    float xi[6];
+    if (no_solve) { for (int i = 0; i < 6; ++i) xi[i] = 1.f; }            /* experiment switch */
+    else gsdf_llt_solve6(Hm, gvec, xi);                                   /* RigidPointOptimizer.cpp:86 */
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xi[i] = damping * xi[i];
+    const float nrm = gsdf_sum3(xi[0] * xi[0], xi[1] * xi[1], xi[2] * xi[2]) +
+                      gsdf_sum3(xi[3] * xi[3], xi[4] * xi[4], xi[5] * xi[5]);
+    *done = 0; *converged = 0;
+    if (nrm < conv_sq) {                                                  /* :88-91 (xi is NOT applied) */
+        *converged = 1;
+        *done = 1;
     } else {
-        /* ---- head: every workgroup reduces the rows of pass k-1 in the same fixed order, solves the
-         * 6x6 system and applies the update -- bit-identical everywhere, so no workgroup has to wait for
-         * another one inside a launch; workgroup 0 publishes the result for the next launch / the host ---- */
-        /* the row reads do not depend on the state words: issue them first so that both memory round
-         * trips overlap (a launch that finds `done` set wasted 16 loads per lane, and is rare) */
-        /* lane (g, v) = (tid / 32, tid % 32) sums groups g, g + T/32, ... of value v, in increasing order */
-        double gs = 0.0;
-        for (int grp = tid >> 5; grp < GSDF_TRACK_GROUPS; grp += GSDF_TRACK_BLOCK / 32) gs += acc_prev[grp * 32 + (tid & 31)];
-        const gsdf_trk_buf& in = st->trk[(k - 1) & 1];
-        const int in_done = in.done;
+        bool nan = false;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) pose[i] = in.pose7[i];
-        const int passes = in.passes + 1;
-        if (in_done) return;                                              /* this optimize() already ended */
-        gsum[tid >> 5][tid & 31] = gs;
-        __syncthreads();
-        if (tid < GSDF_TRACK_NSUM) {
-            double v = gsum[0][tid];
+        for (int i = 0; i < 6; ++i) nan = nan || isnan(xi[i]);
+        if (!nan && !no_solve) {                                          /* :94-95 */
+            float mxi[6];
 #pragma unroll
-            for (int w = 1; w < GSDF_TRACK_BLOCK / 32; ++w) v += gsum[w][tid];
-            tot[tid] = (float)v;
+            for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
+            gsdf_se3_exp_mul(mxi, pose);
         }
-        __syncthreads();
-        if (tid == 0) {
-            float gvec[6], Hm[36];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) gvec[i] = tot[1 + i];
-            int q = 7;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = i; j < 6; ++j) { Hm[6 * i + j] = tot[q]; Hm[6 * j + i] = tot[q]; ++q; }
-            float xi[6];
-            if (tp.debug & 1) { for (int i = 0; i < 6; ++i) xi[i] = 1.f; }   /* experiment: no solve */
-            else
-            gsdf_llt_solve6(Hm, gvec, xi);                                /* RigidPointOptimizer.cpp:86 */
-#pragma unroll
-            for (int i = 0; i < 6; ++i) xi[i] = tp.damping * xi[i];
-            const float nrm = gsdf_sum3(xi[0] * xi[0], xi[1] * xi[1], xi[2] * xi[2]) +
-                              gsdf_sum3(xi[3] * xi[3], xi[4] * xi[4], xi[5] * xi[5]);
-            int done = 0, converged = 0;
-            if (nrm < tp.conv_sq) {                                       /* :88-91 (xi is NOT applied) */
-                converged = 1;
-                done = 1;
-            } else {
-                bool nan = false;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) nan = nan || isnan(xi[i]);
-                if (!nan && !(tp.debug & 1)) {                            /* :94-95 */
-                    float mxi[6];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
-                    gsdf_se3_exp_mul(mxi, pose);
-                }
-                if (passes >= tp.max_passes) done = 1;                    /* :98 return false */
-            }
-#pragma unroll
-            for (int i = 0; i < 7; ++i) sh_pose[i] = pose[i];
-            sh_done = done;
-            if (blockIdx.x == 0) {
-                gsdf_trk_buf& o = st->trk[k & 1];
-#pragma unroll
-                for (int i = 0; i < 7; ++i) { o.pose7[i] = pose[i]; st->pose7[i] = pose[i]; }
-                o.done = done; o.converged = converged; o.passes = passes;
-                /* make `done` sticky in the other parity as well: launches that the host queued beyond the
-                 * end of this optimize() must not take the older buffer for live state and redo the step
-                 * (workgroups of THIS launch that still read it return early, which is what they do anyway) */
-                if (done) st->trk[(k - 1) & 1].done = 1;
-                gsdf_quat_to_R(pose + 3, st->R);
-                st->converged = converged;
-                st->passes = passes;
-                st->last_hits = tot[28];
-                st->n_hit += (unsigned long long)tot[28];
-                /* progress for the host's adaptive pass issue (pinned host memory, system scope) */
-                if (tp.progress) {
-                    __hip_atomic_store(&tp.progress[0], (tp.serial << 8) | (unsigned int)passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (done) __hip_atomic_store(&tp.progress[1], tp.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-        }
-        __syncthreads();
-        if (sh_done) return;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) pose[i] = sh_pose[i];
+        if (passes >= max_passes) *done = 1;                              /* :98 return false */
     }
-    if (k >= tp.max_passes || (tp.debug & 2)) return;                     /* head-only launch */
+}
 
-    /* ---- gather + normal-equation sums of pass k with the current pose ---- */
+/* Gather + normal-equation sums of one pass for this lane's pixels (base, base + nthreads, ...): back-project,
+ * voxel lookup (block key from the L2-resident key array, then the 32-byte record), residual, Jacobian.
+ * z_first (nullable): depth of the first batch, already in registers. */
+__device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_table& tab, const float* __restrict__ depth,
+                                           const float* z_first, const float pose[7], int base0, int nthreads,
+                                           float (&acc)[GSDF_TRACK_NSUM]) {
     float R[9];
     gsdf_quat_to_R(pose + 3, R);                                          /* RigidPointOptimizer.cpp:53-54 */
     const float t[3] = { pose[0], pose[1], pose[2] };
     const float fx_inv = 1.f / g.fx, fy_inv = 1.f / g.fy;                 /* :46-47 */
-
-    float acc[GSDF_TRACK_NSUM];
-#pragma unroll
-    for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
-
     const int N = g.W * g.H;
-    const int nthreads = gridDim.x * GSDF_TRACK_BLOCK;
-    for (int base = blockIdx.x * GSDF_TRACK_BLOCK + tid; base < N; base += TRK_PPT * nthreads) {
+    for (int base = base0; base < N; base += TRK_PPT * nthreads) {
         /* stage A: depth */
         float z[TRK_PPT];
         bool ok[TRK_PPT];
@@ -1007,7 +921,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
         for (int j = 0; j < TRK_PPT; ++j) {
             const int pix = base + j * nthreads;
             ok[j] = pix < N;
-            z[j] = ok[j] ? depth[pix] : 0.f;
+            z[j] = (z_first && base == base0) ? z_first[j] : (ok[j] ? depth[pix] : 0.f);
         }
         /* stage B: back-project, voxel key, block key at the home entry (L2-resident key array) */
         gsdf_v3 p[TRK_PPT];
@@ -1073,6 +987,105 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
             acc[28] += 1.f;                                               /* :81 */
         }
     }
+}
+
+__global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
+                                                                 gsdf_table tab, gsdf_dev_state* st,
+                                                                 double* rows, gsdf_track_params tp) {
+    __shared__ float wsum[GSDF_TRACK_BLOCK / 64][32];
+    __shared__ double gsum[GSDF_TRACK_BLOCK / 32][32];
+    __shared__ float tot[32];
+    __shared__ float sh_pose[8];
+    __shared__ int sh_done;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = tp.pass_index;
+    float pose[7];
+    /* Partial sums of a pass: GSDF_TRACK_GROUPS groups x 32 doubles (29 used); workgroup b adds its sums to group
+     * b % GROUPS with f64 atomics, so the next launch's head reads 4 KB instead of one 128-byte row per workgroup (32 KB at 256
+     * workgroups -- that re-reduction was ~25 % of a pass).  Three buffers rotate with the launch number (which
+     * runs on across optimize() calls, tp.rot): launch j accumulates into buffer j % 3, reads j - 1 and clears
+     * j + 1, which nothing has touched since launch j - 2 read it.  Every launch does the clearing first, also
+     * the ones that return early. */
+    double* acc_cur = rows + (size_t)(tp.rot % 3u) * GSDF_TRACK_ROWSET;
+    const double* acc_prev = rows + (size_t)((tp.rot + 2u) % 3u) * GSDF_TRACK_ROWSET;
+    if (blockIdx.x == 0) {
+        double* nxt = rows + (size_t)((tp.rot + 1u) % 3u) * GSDF_TRACK_ROWSET;
+        for (int i = threadIdx.x; i < GSDF_TRACK_ROWSET; i += GSDF_TRACK_BLOCK) nxt[i] = 0.0;
+    }
+
+    if (k == 0) {
+        /* a new optimize(): the pose is RigidOptimizer::pose_ (kept in st->pose7 between frames) */
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose[i] = st->pose7[i];
+        if (blockIdx.x == 0 && tid == 0) {
+            gsdf_trk_buf& o = st->trk[0];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) o.pose7[i] = pose[i];
+            o.done = 0; o.converged = 0; o.passes = 0;
+        }
+    } else {
+        /* ---- head: every workgroup reduces the rows of pass k-1 in the same fixed order, solves the
+         * 6x6 system and applies the update -- bit-identical everywhere, so no workgroup has to wait for
+         * another one inside a launch; workgroup 0 publishes the result for the next launch / the host ---- */
+        /* the row reads do not depend on the state words: issue them first so that both memory round
+         * trips overlap (a launch that finds `done` set wasted 16 loads per lane, and is rare) */
+        /* lane (g, v) = (tid / 32, tid % 32) sums groups g, g + T/32, ... of value v, in increasing order */
+        double gs = 0.0;
+        for (int grp = tid >> 5; grp < GSDF_TRACK_GROUPS; grp += GSDF_TRACK_BLOCK / 32) gs += acc_prev[grp * 32 + (tid & 31)];
+        const gsdf_trk_buf& in = st->trk[(k - 1) & 1];
+        const int in_done = in.done;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose[i] = in.pose7[i];
+        const int passes = in.passes + 1;
+        if (in_done) return;                                              /* this optimize() already ended */
+        gsum[tid >> 5][tid & 31] = gs;
+        __syncthreads();
+        if (tid < GSDF_TRACK_NSUM) {
+            double v = gsum[0][tid];
+#pragma unroll
+            for (int w = 1; w < GSDF_TRACK_BLOCK / 32; ++w) v += gsum[w][tid];
+            tot[tid] = (float)v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int done, converged;
+            trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, tp.debug & 1, pose, &done, &converged);
+#pragma unroll
+            for (int i = 0; i < 7; ++i) sh_pose[i] = pose[i];
+            sh_done = done;
+            if (blockIdx.x == 0) {
+                gsdf_trk_buf& o = st->trk[k & 1];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) { o.pose7[i] = pose[i]; st->pose7[i] = pose[i]; }
+                o.done = done; o.converged = converged; o.passes = passes;
+                /* make `done` sticky in the other parity as well: launches that the host queued beyond the
+                 * end of this optimize() must not take the older buffer for live state and redo the step
+                 * (workgroups of THIS launch that still read it return early, which is what they do anyway) */
+                if (done) st->trk[(k - 1) & 1].done = 1;
+                gsdf_quat_to_R(pose + 3, st->R);
+                st->converged = converged;
+                st->passes = passes;
+                st->last_hits = tot[28];
+                st->n_hit += (unsigned long long)tot[28];
+                /* progress for the host's adaptive pass issue (pinned host memory, system scope) */
+                if (tp.progress) {
+                    __hip_atomic_store(&tp.progress[0], (tp.serial << 8) | (unsigned int)passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (done) __hip_atomic_store(&tp.progress[1], tp.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+        __syncthreads();
+        if (sh_done) return;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose[i] = sh_pose[i];
+    }
+    if (k >= tp.max_passes || (tp.debug & 2)) return;                     /* head-only launch */
+
+    /* ---- gather + normal-equation sums of pass k with the current pose ---- */
+    float acc[GSDF_TRACK_NSUM];
+#pragma unroll
+    for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
+    trk_gather(g, tab, depth, nullptr, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, gridDim.x * GSDF_TRACK_BLOCK, acc);
     __syncthreads();                                                      /* wsum is reused */
     wave_sum_to_lane63(acc);
     if (lane == 63) {
