@@ -42,6 +42,7 @@ def main():
         for i in range(n - 1):                      # fuse all but the last frame at the GT poses
             counts.append(o.update(depth[i], Rs[i], ts[i]))
         keys, pay = o.export()
+        ray_z, ray_n = o.raycast(Rs[n - 2], ts[n - 2])        # self-defined raycaster (absent from the reference)
         p0 = np.concatenate([ts[n - 2], O.R_to_quat(Rs[n - 2])]).astype(np.float32)
         conv, pose, used, trace, hits = o.track(depth[n - 1], p0)
         _, pose1, _, _, _ = o.track(depth[n - 1], p0, iters=1)       # one Gauss-Newton pass: no chaos amplification
@@ -50,7 +51,8 @@ def main():
             os.path.join(HERE, name + ".npz"), kind=kind, W=W, H=H, voxel_size=vs, trunc_dist=T, unit=np.float32(seq.unit),
             K=seq.K, depth_u16=d16, R=Rs, t=ts, probes=probes, normals_at_probes=nrm, counts=np.array(counts, np.int64),
             keys=keys, payload=pay, track_start=p0, track_converged=conv, track_pose=pose, track_passes=used,
-            track_trace=trace, track_hits=hits, track_pose_1pass=pose1, track_pose_3pass=pose3)
+            track_trace=trace, track_hits=hits, track_pose_1pass=pose1, track_pose_3pass=pose3,
+            raycast_depth=ray_z, raycast_normals=ray_n)
         print(name, "voxels", len(keys), "passes", used, "converged", conv)
 
 

@@ -31,6 +31,8 @@ def test_oracle_reproduces_golden(O, path):
         assert (nu, nv) == tuple(z["counts"][i])
     keys, pay = o.export()
     assert np.array_equal(keys, z["keys"]) and np.array_equal(pay, z["payload"])
+    rz, rn = o.raycast(z["R"][n - 2], z["t"][n - 2])
+    assert np.array_equal(rz, z["raycast_depth"]) and np.array_equal(rn, z["raycast_normals"])
     conv, pose, used, trace, hits = o.track(depth[n - 1], z["track_start"])
     assert conv == bool(z["track_converged"]) and used == int(z["track_passes"])
     assert np.array_equal(pose, z["track_pose"]) and np.array_equal(trace, z["track_trace"], equal_nan=True)
@@ -61,6 +63,14 @@ def test_hip_path_matches_golden(pkg, path):
     scale = np.maximum(1.0, gp[:, 4])
     assert np.abs(pay[:, 0] - gp[:, 0]).max() <= TOL
     assert (np.abs(pay[:, 1:] - gp[:, 1:]).max(axis=1) / scale).max() <= TOL
+    # the self-defined raycaster: same hits, same depth (sign decisions on sums that differ in the last bits may flip)
+    rz, rn = g.raycast(z["R"][n - 2], z["t"][n - 2])
+    gz = z["raycast_depth"]
+    assert ((rz > 0) == (gz > 0)).mean() > 0.995
+    both = (rz > 0) & (gz > 0)
+    if both.any():
+        assert np.percentile(np.abs(rz - gz)[both], 99.5) <= TOL
+        assert np.percentile(np.abs(rn - z["raycast_normals"])[:, both], 99.5) <= 1e-3
     # one and three Gauss-Newton passes: robust to summation order (a full 25-pass run that never
     # converges at this resolution amplifies last-bit differences and is not a parity quantity)
     conv, pose, passes = g.track(depth[n - 1], z["track_start"], iters=1)
