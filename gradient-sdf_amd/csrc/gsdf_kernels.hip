@@ -695,10 +695,14 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                 asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(P[e]), "v"(ob) : "memory");
                 vis_mark(a, P[e], frame_cur);
             }
-            /* hand the voxels on: every storing wave drains its stores, then ONE lane publishes the flag */
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            /* hand the voxels on: every storing wave drains its stores, then ONE lane publishes the flag.  Nobody
+             * waits for a tile of the highest colour: after its last band it just ends (the kernel boundary
+             * completes its stores); between bands the drain orders this workgroup's own re-reads. */
+            if (colour < 3 || pass + 1 < n_pass) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             /* near tile (or timed-out wait): everything goes through the deferred list */
             unsigned int my_defer = 0u;
