@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define GSDF_OK               0
-#define GSDF_ERR_TABLE_FULL   1   /* open-addressed table ran out of probe budget (new failure mode) */
+#define GSDF_ERR_TABLE_FULL   1   /* the block table (or the deferred list) ran out of room (new failure mode) */
 #define GSDF_ERR_KEY_RANGE    2   /* voxel index outside the packable +-2^20 range */
 #define GSDF_ERR_INVALID      3   /* bad argument / call order */
 #define GSDF_ERR_HIP          4   /* HIP runtime error (message in gsdf_last_error) */
@@ -60,7 +60,9 @@ const char* gsdf_last_error(void);
 const char* gsdf_version(void);
 
 /* MapGradPixelSdf(voxel_size, T) + table allocation -- MapGradPixelSdf.h:99-103, Sdf.h:103-107.
- * capacity_log2: number of 32-byte slots = 2^capacity_log2 (BASELINE configs: 22 and 25).
+ * capacity_log2 in [10, 30]: 2^capacity_log2 32-byte voxel records, organised as 2^(capacity_log2-6) blocks of
+ * 4x4x4 voxels (BASELINE configs: 22 and 25).  A surface map fills its blocks to ~70 %, so it holds about
+ * 0.6 * 2^capacity_log2 voxels before GSDF_ERR_TABLE_FULL.
  * device: HIP device ordinal.  Fails with GSDF_ERR_NO_DEVICE when no GPU is present. */
 int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device);
 /* delete tSDF -- main_scan_3d.cpp:314 */
