@@ -251,7 +251,11 @@ int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = h.dbg[i];
     return GSDF_OK;
 }
+#ifdef GSDF_EXPERIMENTS
+const char* gsdf_version(void) { return "gsdf-mi355x 0.1 (gfx950) +experiments"; }
+#else
 const char* gsdf_version(void) { return "gsdf-mi355x 0.1 (gfx950)"; }
+#endif
 
 int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device) {
     if (!out) return fail(GSDF_ERR_INVALID, "out == NULL");

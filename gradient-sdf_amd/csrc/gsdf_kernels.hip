@@ -13,6 +13,15 @@
  * bound by LDS/L2 atomics and HBM gathers.  Wave = 64 lanes throughout.
  */
 #include "gsdf_kernels.h"
+
+/* Measurement switches of the ablation tools (tools/fuse_ablate.py, go_count.py, track_ablate.py) exist only in
+ * builds made with -DGSDF_EXPERIMENTS (make EXPERIMENTS=1); the path-forcing hooks the tests use (debug bits 4, 256,
+ * 512 of k_fuse) are always present. */
+#ifdef GSDF_EXPERIMENTS
+#define GSDF_EXPERIMENT(flags, mask) (((flags) & (mask)) != 0)
+#else
+#define GSDF_EXPERIMENT(flags, mask) (false)
+#endif
 #include "gsdf_math.h"
 
 #include <hip/hip_runtime.h>
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     __shared__ fuse_lds L;
     if (a.use_dev_pose && !a.st->converged) return;        /* main_scan_3d.cpp:261: if (conv) update */
     const int tid = threadIdx.x;
-    const unsigned long long T0 = (a.debug & 128) ? wall_clock64() : 0ull;
+    const unsigned long long T0 = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
     float R[9], t[3];
     if (a.use_dev_pose) {
 #pragma unroll
@@ -448,8 +457,8 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     }
     float n_upd = 0.f, n_val = 0.f;
     unsigned int dbg_go = 0u, dbg_full = 0u, dbg_lost = 0u;
-    unsigned long long T1 = (a.debug & 128) ? wall_clock64() : 0ull;
-    if ((a.debug & 128) && tid == 0) atomicAdd(&a.st->dbg[4], T1 - T0);
+    unsigned long long T1 = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
+    if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) atomicAdd(&a.st->dbg[4], T1 - T0);
     for (int pass = 0; pass < n_pass; ++pass) {
     /* lanes -> (pixel of the band, slice of the ray walk).  One band: as loaded above, 2 slices.  Two bands
      * of 16x8 pixels: 2 waves (8x8 each) per slice, 4 slices.  Four bands of 16x4: 1 wave per slice, 8 slices. */
@@ -514,8 +523,8 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
             int slot[FUSE_BATCH];
             bool pend[FUSE_BATCH];
 #pragma unroll
-            for (int j = 0; j < FUSE_BATCH; ++j) { slot[j] = -1; pend[j] = act[j] && local[j] && !(a.debug & 2); }
-            if (a.debug & 32) {                   /* experiment: no lookup, slot straight from the hash */
+            for (int j = 0; j < FUSE_BATCH; ++j) { slot[j] = -1; pend[j] = act[j] && local[j] && !GSDF_EXPERIMENT(a.debug, 2); }
+            if (GSDF_EXPERIMENT(a.debug, 32)) {                   /* experiment: no lookup, slot straight from the hash */
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j) { if (act[j]) slot[j] = (int)(4 * bk[j] + (key[j] & 3)); pend[j] = false; }
             }
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                     if (pend[j] && hit >= 0) { slot[j] = (int)(4 * bk[j]) + hit; pend[j] = false; }
                     cas_at[j] = (pend[j] && emp >= 0) ? (int)(4 * bk[j]) + emp : -1;
                     if (pend[j] && emp < 0) bk[j] = bk[j] + 1 == FUSE_NB ? 0 : bk[j] + 1;   /* bucket full of others */
-                    if ((a.debug & 128) && __any(pend[j] && emp < 0)) ++dbg_full;
+                    if (GSDF_EXPERIMENT(a.debug, 128) && __any(pend[j] && emp < 0)) ++dbg_full;
                 }
                 uint32_t old[FUSE_BATCH];
 #pragma unroll
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
 #pragma unroll
                 for (int j = 0; j < FUSE_BATCH; ++j)
                     if (go[j] && cas_at[j] >= 0 && (old[j] == FUSE_LKEY_EMPTY || old[j] == key[j])) { slot[j] = cas_at[j]; pend[j] = false; }
-                if (a.debug & 128) {
+                if (GSDF_EXPERIMENT(a.debug, 128)) {
 #pragma unroll
                     for (int j = 0; j < FUSE_BATCH; ++j) if (go[j] && __any(cas_at[j] >= 0 && pend[j])) ++dbg_lost;
                 }
@@ -567,8 +576,8 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
             /* 5. accumulate (exact 64-bit integer adds) */
 #pragma unroll
             for (int j = 0; j < FUSE_BATCH; ++j) {
-                if (j >= nb || !act[j] || (a.debug & 2)) continue;
-                if (a.debug & 16) continue;
+                if (j >= nb || !act[j] || GSDF_EXPERIMENT(a.debug, 2)) continue;
+                if (GSDF_EXPERIMENT(a.debug, 16)) continue;
                 if (slot[j] >= 0) {
                     atomicAdd(&L.w[slot[j]], q[j][0]);
                     atomicAdd(&L.s[slot[j]], q[j][1]);
@@ -584,13 +593,13 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
             }
         }
     }
-    if ((a.debug & 128) && lane == 0) {
+    if (GSDF_EXPERIMENT(a.debug, 128) && lane == 0) {
         atomicAdd(&a.st->n_hit, (unsigned long long)dbg_go);
         atomicAdd(&a.st->dbg[0], (unsigned long long)dbg_full); atomicAdd(&a.st->dbg[1], (unsigned long long)dbg_lost);
         dbg_go = dbg_full = dbg_lost = 0u;
     }
     __syncthreads();
-    if ((a.debug & 128) && tid == 0) { const unsigned long long T2 = wall_clock64(); atomicAdd(&a.st->dbg[2], T2 - T1); T1 = T2; }
+    if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T2 = wall_clock64(); atomicAdd(&a.st->dbg[2], T2 - T1); T1 = T2; }
     /* Flush the tile's distinct voxels: read-modify-write of the HBM payload with NO atomics.
      *
      * Mutual exclusion between tiles comes from two facts:
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
      * Block keys are insert-only, so plain (possibly stale) key loads can only show EMPTY and the CAS
      * settles it.  Each lane owns FUSE_LCAP/FUSE_THREADS LDS slots and drives them through the stages
      * together, so the dependent HBM round trips (bucket keys -> payload) of its entries overlap. */
-    if (!(a.debug & 1)) {
+    if (!GSDF_EXPERIMENT(a.debug, 1)) {
         constexpr int NE = (FUSE_LCAP + FUSE_THREADS - 1) / FUSE_THREADS;
         unsigned long long ekey[NE], bkey[NE], k0[NE];
         uint32_t home[NE];
@@ -637,7 +646,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
             if (lane < 8) {
                 const int j = lane < 4 ? lane : lane + 1;             /* 3x3 neighbourhood without the centre */
                 const int nx = tile_x + (j % 3) - 1, ny = tile_y + (j / 3) - 1;
-                if (nx >= 0 && nx < a.ntx && ny >= 0 && ny < a.nty && (nx & 1) + 2 * (ny & 1) < colour && !(a.debug & 8)) {
+                if (nx >= 0 && nx < a.ntx && ny >= 0 && ny < a.nty && (nx & 1) + 2 * (ny & 1) < colour && !GSDF_EXPERIMENT(a.debug, 8)) {
                     need = true;
                     flag = a.tile_flags + (size_t)ny * a.ntx + nx;
                 }
@@ -738,7 +747,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     } else if (tid == 0) {
         __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if ((a.debug & 128) && tid == 0) { const unsigned long long T3 = wall_clock64(); atomicAdd(&a.st->dbg[3], T3 - T1); T1 = T3; }
+    if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T3 = wall_clock64(); atomicAdd(&a.st->dbg[3], T3 - T1); T1 = T3; }
     if (pass + 1 < n_pass) {                                          /* next band: start from an empty table */
         __syncthreads();
         for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
@@ -813,7 +822,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     gsdf_dev_state* gate = use_dev_pose ? st : nullptr;
     a.tile_flags = tile_flags; a.ntx = ntx; a.nty = nty; a.tile_order = tile_order;
     const int n = ntx * nty;
-    hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), (g_fuse_debug & 4096) ? 8192 : 0, s, a);   /* experiment: 1 workgroup per CU */
+    hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(g_fuse_debug, 4096) ? 8192 : 0, s, a);   /* experiment: 1 workgroup per CU */
     hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st,
                        use_dev_pose ? log_rows : nullptr, max_rows);
 }
@@ -1053,7 +1062,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
         __syncthreads();
         if (tid == 0) {
             int done, converged;
-            trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, tp.debug & 1, pose, &done, &converged);
+            trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, GSDF_EXPERIMENT(tp.debug, 1), pose, &done, &converged);
 #pragma unroll
             for (int i = 0; i < 7; ++i) sh_pose[i] = pose[i];
             sh_done = done;
@@ -1083,7 +1092,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
         for (int i = 0; i < 7; ++i) pose[i] = sh_pose[i];
     }
-    if (k >= tp.max_passes || (tp.debug & 2)) return;                     /* head-only launch */
+    if (k >= tp.max_passes || GSDF_EXPERIMENT(tp.debug, 2)) return;                     /* head-only launch */
 
     /* ---- gather + normal-equation sums of pass k with the current pose ---- */
     float acc[GSDF_TRACK_NSUM];

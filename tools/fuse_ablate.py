@@ -12,6 +12,11 @@ vs = np.float32(0.01); T = np.float32(10) * vs
 frames = [seq.frame(i) for i in range(n)]
 g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=22)
 L = pkg.binding.load()
+import ctypes as _ct
+L.gsdf_version.restype = _ct.c_char_p
+if b"experiments" not in L.gsdf_version():
+    print("NOTE: libgsdf.so was built without the measurement switches; rebuild with `make -C gradient-sdf_amd/csrc -B EXPERIMENTS=1`"
+          " (and plain `make -B` afterwards) or every variant below measures the full kernel")
 dev = [g.upload(f[0]) for f in frames]
 names = {0: "full", 1: "no flush", 2: "no LDS accumulate (flush empty)", 3: "compute only", 4: "flush: probe only",
          8: "flush: plain RMW", 17: "no flush, no overflow-to-HBM", 65: "no flush, count overflows", 16: "no overflow-to-HBM",

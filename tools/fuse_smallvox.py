@@ -11,6 +11,11 @@ vs = np.float32(float(sys.argv[1]) if len(sys.argv) > 1 else 0.005); T = np.floa
 frames = [seq.frame(i) for i in range(n)]
 g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=25)
 L = pkg.binding.load()
+import ctypes as _ct
+L.gsdf_version.restype = _ct.c_char_p
+if b"experiments" not in L.gsdf_version():
+    print("NOTE: libgsdf.so was built without the measurement switches; rebuild with `make -C gradient-sdf_amd/csrc -B EXPERIMENTS=1`"
+          " (and plain `make -B` afterwards) or every variant below measures the full kernel")
 dev = [g.upload(f[0]) for f in frames]
 for flags in (0, 256, 512, 0):
     L.gsdf_debug_flags(flags)

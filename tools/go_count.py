@@ -9,6 +9,11 @@ vs = np.float32(0.01); T = np.float32(10) * vs
 frames = [seq.frame(i) for i in range(n)]
 g = pkg.GradSdf(vs, T, 640, 480, seq.K, capacity_log2=22)
 L = pkg.binding.load()
+import ctypes as _ct
+L.gsdf_version.restype = _ct.c_char_p
+if b"experiments" not in L.gsdf_version():
+    print("NOTE: libgsdf.so was built without the measurement switches; rebuild with `make -C gradient-sdf_amd/csrc -B EXPERIMENTS=1`"
+          " (and plain `make -B` afterwards) or every variant below measures the full kernel")
 L.gsdf_debug_flags(128)
 dev = [g.upload(f[0]) for f in frames]
 import ctypes

@@ -11,6 +11,11 @@ vs = np.float32(0.01); T = np.float32(10) * vs
 frames = [seq.frame(i) for i in range(n)]
 g = pkg.GradSdf(vs, T, 640, 480, seq.K, capacity_log2=22)
 L = pkg.binding.load()
+import ctypes as _ct
+L.gsdf_version.restype = _ct.c_char_p
+if b"experiments" not in L.gsdf_version():
+    print("NOTE: libgsdf.so was built without the measurement switches; rebuild with `make -C gradient-sdf_amd/csrc -B EXPERIMENTS=1`"
+          " (and plain `make -B` afterwards) or every variant below measures the full kernel")
 for i in range(6):
     g.update(frames[i][0], frames[i][1], frames[i][2])
 q = pkg.synth.R_to_quat_np(frames[6][1]).astype(np.float32)
