@@ -55,7 +55,7 @@ struct gsdf_ctx {
     /* tracker */
     gsdf_dev_state* st = nullptr;
     double* partials = nullptr;                    /* 3 rotating buffers of tracker partial sums */
-    unsigned int track_rot = 0;                    /* tracker launches issued so far (selects the buffers) */
+    unsigned int track_rot = 0;                    /* tracker launches issued so far, mod 3 (selects the sum buffers) */
     int track_blocks = 0;
     unsigned long long* blk_counters = nullptr;
     int fuse_blocks = 0;
@@ -208,7 +208,8 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     for (int k = 0; k <= iters; ++k) {
         if (adaptive && c->progress[1] == tp.serial) break;  /* device finished this optimize() */
         tp.pass_index = k;
-        tp.rot = c->track_rot++;
+        tp.rot = c->track_rot;
+        c->track_rot = (c->track_rot + 1u) % 3u;              /* kept in [0, 3): no discontinuity at wrap-around */
         {
             prof_scope ps(c, 2);
             gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks, tp);

@@ -104,7 +104,7 @@ struct gsdf_track_params {
     unsigned int serial;          /* optimize() call number, for the host progress words */
     unsigned int* progress;       /* pinned host memory: [0] = serial<<8 | passes, [1] = serial when done; nullable */
     int debug;                    /* experiment switches (gsdf_debug_flags >> 8); 0 in production */
-    unsigned int rot;             /* number of tracker launches issued on this context so far: selects the sum buffers */
+    unsigned int rot;             /* tracker launches issued on this context so far, mod 3: selects the sum buffers */
 };
 void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st);
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
