@@ -106,6 +106,7 @@ def load():
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
         "gsdf_query": (C.c_int, [vp, fp, C.c_int64, fp, fp, fp]),
         "gsdf_raycast": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]),
+        "gsdf_extract_mesh": (C.c_int, [vp, C.c_float, C.POINTER(C.c_int8), fp, C.c_int64, C.POINTER(C.c_int64)]),
         "gsdf_dev_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_int64]),
         "gsdf_dev_free": (C.c_int, [vp, vp]),
         "gsdf_dev_upload": (C.c_int, [vp, vp, vp, C.c_int64]),
@@ -129,7 +130,7 @@ ABI_SYMBOLS = [
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
     "gsdf_ba_setup", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
-    "gsdf_merge_raw_dev", "gsdf_query", "gsdf_raycast",
+    "gsdf_merge_raw_dev", "gsdf_query", "gsdf_raycast", "gsdf_extract_mesh",
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_timer_start", "gsdf_timer_stop_ms",
     "gsdf_profile", "gsdf_profile_read",
 ]
@@ -346,6 +347,17 @@ class GradSdf:
         self._chk(self.L.gsdf_raycast(self.h, _fp(K), _fp(R), _fp(t), W, H, C.c_float(zmin), C.c_float(zmax), _fp(d),
                                       _fp(n) if normals else None))
         return d, n
+
+    def extract_mesh(self, tri_table, iso=0.0):
+        """GPU marching cubes: float32 [n, 3, 3] triangles in the reference's sweep order (tri_table: int8 [256,16])."""
+        tt = np.ascontiguousarray(tri_table, dtype=np.int8).reshape(256 * 16)
+        n = C.c_int64(0)
+        self._chk(self.L.gsdf_extract_mesh(self.h, C.c_float(iso), tt.ctypes.data_as(C.POINTER(C.c_int8)), None, 0, C.byref(n)))
+        out = np.empty((max(n.value, 1), 3, 3), np.float32)
+        if n.value:
+            self._chk(self.L.gsdf_extract_mesh(self.h, C.c_float(iso), tt.ctypes.data_as(C.POINTER(C.c_int8)), _fp(out), n.value,
+                                               C.byref(n)))
+        return out[:n.value]
 
     # -- timing -------------------------------------------------------------------------------
     def timer_start(self):

@@ -870,6 +870,48 @@ int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[
     return GSDF_OK;
 }
 
+int gsdf_extract_mesh(gsdf_ctx* c, float iso, const int8_t tri_table[256 * 16], float* triangles_out, int64_t max_tris,
+                      int64_t* n_tris) {
+    if (!c || !tri_table || !n_tris || (max_tris > 0 && !triangles_out)) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    *n_tris = 0;
+    /* upper bound of the output: 5 triangles per cube, one cube per voxel; sized by the caller through max_tris */
+    const long long cap = max_tris > 0 ? (long long)max_tris : 0;
+    int* d_mn = nullptr; signed char* d_tab = nullptr; float* d_tris = nullptr; unsigned long long* d_keys = nullptr;
+    hipError_t e = hipMalloc((void**)&d_mn, 3 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_tab, 256 * 16);
+    if (e == hipSuccess && cap) e = hipMalloc((void**)&d_tris, (size_t)cap * 9 * sizeof(float));
+    if (e == hipSuccess && cap) e = hipMalloc((void**)&d_keys, (size_t)cap * sizeof(unsigned long long));
+    const int big[3] = { 2147483647, 2147483647, 2147483647 };
+    if (e == hipSuccess) e = hipMemcpyAsync(d_mn, big, sizeof(big), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tri_table, 256 * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream);
+    unsigned long long n = 0;
+    std::vector<unsigned long long> keys;
+    std::vector<float> tris;
+    if (e == hipSuccess) {
+        gsdf_launch_mesh(c->stream, c->tab, c->n_slots, c->voxel_size, iso, d_mn, d_tab, d_tris, d_keys, c->counter, cap);
+        e = hipMemcpyAsync(&n, c->counter, sizeof(n), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    const size_t got = (size_t)std::min<unsigned long long>(n, (unsigned long long)cap);
+    if (e == hipSuccess && got) {
+        keys.resize(got); tris.resize(got * 9);
+        e = hipMemcpy(keys.data(), d_keys, got * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(tris.data(), d_tris, got * 9 * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_mn); (void)hipFree(d_tab); (void)hipFree(d_tris); (void)hipFree(d_keys);
+    if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
+    *n_tris = (int64_t)n;                                    /* total found, also when it exceeds max_tris */
+    if (n > (unsigned long long)cap) return cap ? fail(GSDF_ERR_INVALID, "gsdf_extract_mesh: max_tris too small (n_tris holds the need)") : GSDF_OK;
+    /* the reference's order: z-y-x sweep, triangles of a cube in table order */
+    std::vector<uint32_t> order(got);
+    for (size_t i = 0; i < got; ++i) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+    for (size_t i = 0; i < got; ++i) std::memcpy(triangles_out + 9 * i, tris.data() + 9 * (size_t)order[i], 9 * sizeof(float));
+    return GSDF_OK;
+}
+
 int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes) {
     if (!c || !dev_ptr || bytes <= 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));

@@ -125,6 +125,10 @@ void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, co
 void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, int W, int H, const float K[9],
                          const gsdf_pose_arg& pose, float zmin, float zmax, float* depth_dev, float* normals_dev_or_null);
 
+/* iso-surface: bounding-box minimum (mn_dev preset to INT_MAX x3), then triangles + sort keys appended through `counter` */
+void gsdf_launch_mesh(hipStream_t s, gsdf_table tab, size_t n_slots, float vs, float iso, int* mn_dev, const signed char* tri_table_dev,
+                      float* tris_dev, unsigned long long* keys_dev, unsigned long long* counter, long long max_tris);
+
 /* PhotoBA (gsdf_ba.hip): device-side problem description, same layout as the kernels' ba_args */
 struct gsdf_ba_dev {
     gsdf_table tab;

@@ -1307,3 +1307,113 @@ void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, 
     hipLaunchKernelGGL(k_raycast, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, s, tab, vs, inv_vs, W, H, K[0], K[4], K[2],
                        K[5], pose, zmin, zmax, depth, normals);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Iso-surface extraction on the device: LayeredMarchingCubesNoColor::computeIsoSurface
+ * (mesh/LayeredMarchingCubesNoColor.cpp:354-712) without the layer buffers -- one lane per voxel record; a lane
+ * whose voxel exists is the (0,0,0) corner of a cube, gathers the other 7 corners through the block map
+ * (computeLutIndex :593-639: a cube is skipped when any corner has weight 0), interpolates the crossing edges
+ * (interpolate :642-662: 1e-7 guards, double mu, clamp) and appends its non-degenerate triangles (:686-712)
+ * with a sort key (voxel key in z-y-x order, triangle number): the host sorts them into the reference's sweep
+ * order.  The 256 x 16 triangle table comes from the caller.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(256) void k_mesh_bbox(gsdf_table tab, size_t n_slots, int* mn /* [3], preset to INT_MAX */) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int m[3] = { 2147483647, 2147483647, 2147483647 };
+    for (; i < n_slots; i += stride) {
+        const unsigned long long bk = tab.bkeys[i / GSDF_BLOCK_VOX];
+        if (bk == GSDF_KEY_EMPTY) continue;
+        if (!(tab.vox[i].w > 0.f)) continue;
+        int x, y, z;
+        gsdf_key_unpack(gsdf_voxel_key(bk, (uint32_t)(i % GSDF_BLOCK_VOX)), &x, &y, &z);
+        m[0] = x < m[0] ? x : m[0]; m[1] = y < m[1] ? y : m[1]; m[2] = z < m[2] ? z : m[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int v = m[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(v, o); v = other < v ? other : v; }
+        if ((threadIdx.x & 63) == 0 && v != 2147483647) atomicMin(&mn[a], v);
+    }
+}
+
+__device__ __forceinline__ gsdf_v3 mesh_interpolate(float t0, float t1, gsdf_v3 v0, gsdf_v3 v1, float iso) {
+    if (fabs((double)(iso - t0)) < 1e-7) return v0;                        /* :645-650 (float difference, double compare) */
+    if (fabs((double)(iso - t1)) < 1e-7) return v1;
+    if (fabs((double)(t0 - t1)) < 1e-7) return v0;
+    double mu = (double)((iso - t0) / (t1 - t0));
+    if (mu > 1.0) mu = 1.0; else if (mu < 0) mu = 0.0;
+    gsdf_v3 v;
+    v.x = (float)((double)v0.x + mu * (double)(v1.x - v0.x));
+    v.y = (float)((double)v0.y + mu * (double)(v1.y - v0.y));
+    v.z = (float)((double)v0.z + mu * (double)(v1.z - v0.z));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_mesh(gsdf_table tab, size_t n_slots, float vs, float iso, const int* __restrict__ mn,
+                                               const signed char* __restrict__ tri_table, float* __restrict__ tris,
+                                               unsigned long long* __restrict__ keys, unsigned long long* counter, long long max_tris) {
+    /* corner c -> (dx, dy, dz), numbering of computeLutIndex (:599-606); edge e -> its two corners */
+    const int CORNER[8][3] = { { 1, 1, 0 }, { 1, 0, 0 }, { 0, 0, 0 }, { 0, 1, 0 }, { 1, 1, 1 }, { 1, 0, 1 }, { 0, 0, 1 }, { 0, 1, 1 } };
+    const int EDGE[12][2] = { { 0, 1 }, { 1, 2 }, { 2, 3 }, { 3, 0 }, { 4, 5 }, { 5, 6 }, { 6, 7 }, { 7, 4 }, { 0, 4 }, { 1, 5 }, { 2, 6 }, { 3, 7 } };
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int m0 = mn[0], m1 = mn[1], m2 = mn[2];
+    const float o0 = -(float)m0 * vs, o1 = -(float)m1 * vs, o2 = -(float)m2 * vs;     /* origin_ (:377) */
+    for (; i < n_slots; i += stride) {
+        const unsigned long long bk = tab.bkeys[i / GSDF_BLOCK_VOX];
+        if (bk == GSDF_KEY_EMPTY) continue;
+        const gsdf_payload self = tab.vox[i];
+        if (!(self.w > 0.f)) continue;
+        int x, y, z;
+        gsdf_key_unpack(gsdf_voxel_key(bk, (uint32_t)(i % GSDF_BLOCK_VOX)), &x, &y, &z);
+        float d[8];
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c == 2) { d[c] = self.s / self.w; continue; }
+            const int cx = x + CORNER[c][0], cy = y + CORNER[c][1], cz = z + CORNER[c][2];
+            const gsdf_payload* q = gsdf_key_in_range(cx, cy, cz) ? gsdf_find(tab, gsdf_key_pack(cx, cy, cz)) : nullptr;
+            float w = 0.f, sd = 0.f;
+            if (q) { const float2 ws = *reinterpret_cast<const float2*>(q); w = ws.x; sd = ws.y; }
+            if (!(w > 0.f)) ok = false;
+            d[c] = ok ? sd / w : 0.f;
+        }
+        if (!ok) continue;
+        int idx = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (d[c] > iso) idx |= 1 << c;
+        if (idx == 0 || idx == 255) continue;
+        const signed char* t = tri_table + 16 * idx;
+        for (int k = 0; k < 15 && t[k] >= 0; k += 3) {
+            gsdf_v3 p[3];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int e = t[k + v], a = EDGE[e][0], b = EDGE[e][1];
+                const gsdf_v3 wa = { (float)(x + CORNER[a][0] - m0) * vs - o0, (float)(y + CORNER[a][1] - m1) * vs - o1,
+                                     (float)(z + CORNER[a][2] - m2) * vs - o2 };
+                const gsdf_v3 wb = { (float)(x + CORNER[b][0] - m0) * vs - o0, (float)(y + CORNER[b][1] - m1) * vs - o1,
+                                     (float)(z + CORNER[b][2] - m2) * vs - o2 };
+                p[v] = mesh_interpolate(d[a], d[b], wa, wb, iso);
+            }
+            auto same = [](const gsdf_v3& a, const gsdf_v3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; };
+            if (same(p[0], p[1]) || same(p[0], p[2]) || same(p[1], p[2])) continue;      /* computeTriangles (:686-712) */
+            const unsigned long long o = atomicAdd(counter, 1ull);
+            if ((long long)o >= max_tris) continue;
+            float* out = tris + 9 * o;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { out[3 * v] = p[v].x; out[3 * v + 1] = p[v].y; out[3 * v + 2] = p[v].z; }
+            /* sweep order of the reference: z, then y, then x (relative to the bounding-box minimum, 20 bits each),
+             * then the triangle number within the cube */
+            keys[o] = ((((unsigned long long)(uint32_t)(z - m2) << 40) | ((unsigned long long)(uint32_t)(y - m1) << 20) |
+                        (unsigned long long)(uint32_t)(x - m0)) << 3) | (unsigned long long)(k / 3);
+        }
+    }
+}
+void gsdf_launch_mesh(hipStream_t s, gsdf_table tab, size_t n_slots, float vs, float iso, int* mn_dev, const signed char* tri_table_dev,
+                      float* tris_dev, unsigned long long* keys_dev, unsigned long long* counter, long long max_tris) {
+    hipLaunchKernelGGL(k_mesh_bbox, dim3(1024), dim3(256), 0, s, tab, n_slots, mn_dev);
+    hipLaunchKernelGGL(k_mesh, dim3(2048), dim3(256), 0, s, tab, n_slots, vs, iso, mn_dev, tri_table_dev, tris_dev, keys_dev, counter,
+                       max_tris);
+}

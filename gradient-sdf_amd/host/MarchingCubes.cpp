@@ -175,6 +175,25 @@ bool MarchingCubes::computeIsoSurface(const std::vector<int32_t>& keys, const st
     return true;
 }
 
+void MarchingCubes::setTriangles(const float* tris, size_t n_tris) {
+    vertices_.clear();
+    faces_.clear();
+    vertices_.reserve(3 * n_tris);
+    faces_.reserve(n_tris);
+    for (size_t i = 0; i < n_tris; ++i) {
+        const int v0 = (int)vertices_.size();
+        for (int v = 0; v < 3; ++v) vertices_.push_back(Vec3f(tris[9 * i + 3 * v], tris[9 * i + 3 * v + 1], tris[9 * i + 3 * v + 2]));
+        faces_.push_back({ v0, v0 + 1, v0 + 2 });
+    }
+}
+
+void MarchingCubes::fill_table(int8_t out[256 * 16]) {
+    for (int c = 0; c < 256; ++c) {
+        const std::vector<int>& t = triangles(c);
+        for (int k = 0; k < 16; ++k) out[16 * c + k] = k < (int)t.size() && k < 15 ? (int8_t)t[k] : (int8_t)-1;
+    }
+}
+
 bool MarchingCubes::savePly(const std::string& filename) const {
     if (vertices_.empty()) return false;
     std::ofstream f(filename.c_str());

@@ -26,6 +26,10 @@ public:
     explicit MarchingCubes(float voxel_size) : vs_(voxel_size) {}
     /* keys int32[n][3], payload float[n][5] = dist,gx,gy,gz,weight (any order) */
     bool computeIsoSurface(const std::vector<int32_t>& keys, const std::vector<float>& payload, float isoValue = 0.f);
+    /* the same mesh from triangles computed elsewhere (gsdf_extract_mesh: 9 floats per triangle, sweep order) */
+    void setTriangles(const float* tris, size_t n_tris);
+    /* the generated table in the layout gsdf_extract_mesh takes: 256 x 16 edge ids, -1 terminated */
+    static void fill_table(int8_t out[256 * 16]);
     bool savePly(const std::string& filename) const;
     const std::vector<Vec3f>& vertices() const { return vertices_; }
     const std::vector<std::array<int, 3>>& faces() const { return faces_; }

@@ -163,6 +163,15 @@ int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float
 int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
                  float* depth_out, float* normals_out);
 
+/* Iso-surface of the map on the device -- LayeredMarchingCubesNoColor::computeIsoSurface + computeLutIndex + interpolate +
+ * computeTriangles (mesh/LayeredMarchingCubesNoColor.cpp:354-712), called by MapGradPixelSdf::extract_mesh
+ * (MapGradPixelSdf.cpp:124-175).  tri_table: the caller's 256 x 16 triangle table (edge ids, 3 per triangle, -1 ends a
+ * row; corner / edge numbering of :599-606).  triangles_out: 9 floats per triangle, in the reference's z-y-x sweep
+ * order, no vertex de-duplication, degenerate triangles dropped.  *n_tris = triangles found; call with max_tris = 0
+ * to size the buffer. */
+int gsdf_extract_mesh(gsdf_ctx* c, float iso, const int8_t tri_table[256 * 16], float* triangles_out, int64_t max_tris,
+                      int64_t* n_tris);
+
 /* device-memory plumbing so callers can stage frames in HBM without another runtime */
 int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes);
 int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr);

@@ -107,3 +107,24 @@ def test_scan3d_tracked_mode_writes_tum_poses(pkg, O, tmp_path):
             if conv:
                 o.update(d, O.quat_to_R(pose[3:]), pose[:3])
         assert np.abs(pf[i, 1:4] - pose[:3]).max() < 2e-4 and np.abs(np.abs(pf[i, 4:8]) - np.abs(pose[3:])).max() < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,W,H,vs", [("spheres", 160, 120, 0.02), ("tum", 320, 240, 0.01)])
+def test_device_marching_cubes_equals_host_sweep(pkg, kind, W, H, vs):
+    """gsdf_extract_mesh (one lane per voxel through the block map) against MarchingCubes::computeIsoSurface, the host
+    statement of LayeredMarchingCubesNoColor's z-y-x sweep over the exported map: the triangle lists must be bit-identical,
+    in the same order."""
+    import ctypes
+    _build()
+    seq = pkg.synth.Sequence(kind, W, H, n_frames=4, seed=2)
+    g = pkg.GradSdf(np.float32(vs), np.float32(5) * np.float32(vs), W, H, seq.K, capacity_log2=21)
+    for i in range(seq.n):
+        d, R, t = seq.frame(i)
+        g.update(d, R, t)
+    hl = ctypes.CDLL(os.path.join(HOST, "libgsdf_host.so"))
+    hl.gsdf_host_mesh_check.restype = ctypes.c_long
+    hl.gsdf_host_mesh_check.argtypes = [ctypes.c_void_p, ctypes.c_float]
+    n = hl.gsdf_host_mesh_check(g.h, ctypes.c_float(vs))
+    assert n > 1000, n
+    g.close()
