@@ -55,6 +55,12 @@ __global__ __launch_bounds__(256) void k_lds(float* out, int iters) {
         if (MODE == 9) { atomicAdd(&lk[(h >> 8) & 2047], 3ull); }                         // ds_add_u64 random
         if (MODE == 10) { atomicAdd((unsigned int*)&lf[((t >> 2) + it * 67) & 4095], 1u); } // ds_add_u32 4 lanes/addr
         if (MODE == 11) { atomicAdd(&lk[((t >> 2) + it * 67) & 2047], 3ull); }            // ds_add_u64 4 lanes/addr
+        if (MODE == 12) { unsafeAtomicAdd(&lf[(t + it * 67) & 4095], 1.0f); }             // hardware ds_add_f32 distinct
+        if (MODE == 13) { unsafeAtomicAdd(&lf[((t >> 2) + it * 67) & 4095], 1.0f); }      // hardware ds_add_f32 4 lanes/addr
+        if (MODE == 14) { unsafeAtomicAdd(&lf[(h >> 8) & 4095], 1.0f); }                  // hardware ds_add_f32 random
+        if (MODE == 15) { unsafeAtomicAdd((double*)&lk[(t + it * 67) & 2047], 1.0); }     // hardware ds_add_f64 distinct
+        if (MODE == 16) { unsafeAtomicAdd((double*)&lk[((t >> 2) + it * 67) & 2047], 1.0); }   // ds_add_f64 4 lanes/addr
+        if (MODE == 17) { unsafeAtomicAdd((double*)&lk[(h >> 8) & 2047], 1.0); }          // ds_add_f64 random
     }
     __syncthreads();
     if (t == 0) out[blockIdx.x] = lf[5] + acc;
@@ -75,9 +81,10 @@ int main() {
     // same but with a table small enough to sit in L2 (4 MiB / XCD): 64K slots = 2 MiB
 #define RUNS(M) { for (int r = 0; r < 3; ++r) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(k_global<M>, dim3(n / 256), dim3(256), 0, 0, tab, (uint32_t)(65536 - 1), n); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r == 2) printf("small-table mode %2d %-30s : %8.1f us\n", M, names[M], ms * 1e3); } }
     RUNS(0) RUNS(1) RUNS(4) RUNS(6)
-    const char* lnames[] = { "ds_add_f32 distinct", "ds_add_f32 4 lanes/addr", "ds_add_u32 distinct", "ds_cmpst_rtn_b64 distinct", "ds_add_f32 random", "ds_read_b64 random (dependent use)", "ds_add_f32 8 lanes/addr", "ds_add_u64 distinct", "ds_add_u64 2 lanes/addr", "ds_add_u64 random", "ds_add_u32 4 lanes/addr", "ds_add_u64 4 lanes/addr" };
+    const char* lnames[] = { "ds_add_f32 distinct", "ds_add_f32 4 lanes/addr", "ds_add_u32 distinct", "ds_cmpst_rtn_b64 distinct", "ds_add_f32 random", "ds_read_b64 random (dependent use)", "ds_add_f32 8 lanes/addr", "ds_add_u64 distinct", "ds_add_u64 2 lanes/addr", "ds_add_u64 random", "ds_add_u32 4 lanes/addr", "ds_add_u64 4 lanes/addr",
+        "unsafe ds_add_f32 distinct", "unsafe ds_add_f32 4 lanes/addr", "unsafe ds_add_f32 random", "unsafe ds_add_f64 distinct", "unsafe ds_add_f64 4 lanes/addr", "unsafe ds_add_f64 random" };
     const int iters = 2000, blocks = 256 * 4;
 #define RUNL(M) { for (int r = 0; r < 3; ++r) { CK(hipEventRecord(e0)); hipLaunchKernelGGL(k_lds<M>, dim3(blocks), dim3(256), 0, 0, out, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r == 2) { double waveinstr_per_cu = (double)blocks * 4 * iters / 256; printf("lds mode %d %-36s : %8.1f us -> %.1f cycles@2.4GHz per wave-instr per CU\n", M, lnames[M], ms * 1e3, ms * 1e-3 * 2.4e9 / waveinstr_per_cu); } } }
-    RUNL(0) RUNL(1) RUNL(2) RUNL(3) RUNL(4) RUNL(5) RUNL(6) RUNL(7) RUNL(8) RUNL(9) RUNL(10) RUNL(11)
+    RUNL(0) RUNL(1) RUNL(2) RUNL(3) RUNL(4) RUNL(5) RUNL(6) RUNL(7) RUNL(8) RUNL(9) RUNL(10) RUNL(11) RUNL(12) RUNL(13) RUNL(14) RUNL(15) RUNL(16) RUNL(17)
     return 0;
 }
