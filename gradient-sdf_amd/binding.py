@@ -105,11 +105,15 @@ def load():
         "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
         "gsdf_query": (C.c_int, [vp, fp, C.c_int64, fp, fp, fp]),
+        "gsdf_block_keys_dev": (C.c_int, [vp, vp, C.c_int64, C.POINTER(C.c_int64)]),
+        "gsdf_pack_blocks_dev": (C.c_int, [vp, vp, C.c_int64, vp]),
+        "gsdf_unpack_blocks_dev": (C.c_int, [vp, vp, C.c_int64, vp]),
         "gsdf_raycast": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]),
         "gsdf_extract_mesh": (C.c_int, [vp, C.c_float, C.POINTER(C.c_int8), fp, C.c_int64, C.POINTER(C.c_int64)]),
         "gsdf_dev_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_int64]),
         "gsdf_dev_free": (C.c_int, [vp, vp]),
         "gsdf_dev_upload": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "gsdf_dev_download": (C.c_int, [vp, vp, vp, C.c_int64]),
         "gsdf_timer_start": (C.c_int, [vp]),
         "gsdf_timer_stop_ms": (C.c_int, [vp, fp]),
         "gsdf_profile": (C.c_int, [vp, C.c_int]),
@@ -130,8 +134,9 @@ ABI_SYMBOLS = [
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
     "gsdf_ba_setup", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
-    "gsdf_merge_raw_dev", "gsdf_query", "gsdf_raycast", "gsdf_extract_mesh",
-    "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_timer_start", "gsdf_timer_stop_ms",
+    "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
+    "gsdf_query", "gsdf_raycast", "gsdf_extract_mesh",
+    "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_dev_download", "gsdf_timer_start", "gsdf_timer_stop_ms",
     "gsdf_profile", "gsdf_profile_read",
 ]
 
@@ -198,6 +203,13 @@ class GradSdf:
         R = _f32(R).reshape(9)
         t = _f32(t).reshape(3)
         self._chk(self.L.gsdf_update(self.h, _fp(d), _fp(R), _fp(t)))
+
+    def download(self, dev_ptr, shape, dtype):
+        """Copy a device buffer (pointer from upload / dev_alloc) into a new numpy array."""
+        out = np.empty(shape, dtype)
+        p = dev_ptr if isinstance(dev_ptr, C.c_void_p) else C.c_void_p(int(dev_ptr))
+        self._chk(self.L.gsdf_dev_download(self.h, out.ctypes.data_as(C.c_void_p), p, out.nbytes))
+        return out
 
     def upload(self, array):
         """Stage a host array in HBM; returns the device pointer (freed on close)."""
@@ -325,6 +337,18 @@ class GradSdf:
 
     def merge_raw_dev(self, keys_ptr, payload_ptr, n):
         self._chk(self.L.gsdf_merge_raw_dev(self.h, C.c_void_p(keys_ptr), C.c_void_p(payload_ptr), int(n)))
+
+    # -- dense block exchange (device pointers as ints, e.g. torch tensor.data_ptr()) --------------
+    def block_keys_dev(self, keys_ptr, max_n):
+        n = C.c_int64(0)
+        self._chk(self.L.gsdf_block_keys_dev(self.h, C.c_void_p(keys_ptr), int(max_n), C.byref(n)))
+        return n.value
+
+    def pack_blocks_dev(self, keys_ptr, n, dense_ptr):
+        self._chk(self.L.gsdf_pack_blocks_dev(self.h, C.c_void_p(keys_ptr), int(n), C.c_void_p(dense_ptr)))
+
+    def unpack_blocks_dev(self, keys_ptr, n, dense_ptr):
+        self._chk(self.L.gsdf_unpack_blocks_dev(self.h, C.c_void_p(keys_ptr), int(n), C.c_void_p(dense_ptr)))
 
     def query(self, pts):
         p = _f32(pts).reshape(-1, 3)

@@ -912,6 +912,33 @@ int gsdf_extract_mesh(gsdf_ctx* c, float iso, const int8_t tri_table[256 * 16], 
     return GSDF_OK;
 }
 
+int gsdf_block_keys_dev(gsdf_ctx* c, uint64_t* keys_dev, int64_t max_n, int64_t* n) {
+    if (!c || !n || (max_n > 0 && !keys_dev)) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+    gsdf_launch_block_keys(c->stream, c->tab, c->n_slots / GSDF_BLOCK_VOX, (unsigned long long*)keys_dev, c->counter, max_n);
+    unsigned long long cnt = 0;
+    HIP_TRY(hipMemcpyAsync(&cnt, c->counter, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *n = (int64_t)cnt;
+    return GSDF_OK;
+}
+int gsdf_pack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t n, float* dense_dev) {
+    if (!c || (n > 0 && (!block_keys_dev || !dense_dev))) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_launch_pack_blocks(c->stream, c->tab, (const unsigned long long*)block_keys_dev, n, dense_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GSDF_OK;
+}
+int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t n, const float* dense_dev) {
+    if (!c || (n > 0 && (!block_keys_dev || !dense_dev))) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    gsdf_launch_unpack_blocks(c->stream, c->tab, (const unsigned long long*)block_keys_dev, n, dense_dev, c->st);
+    HIP_TRY(hipGetLastError());
+    return gsdf_sync(c);
+}
+
 int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes) {
     if (!c || !dev_ptr || bytes <= 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -923,6 +950,13 @@ int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(dev_ptr));
+    return GSDF_OK;
+}
+int gsdf_dev_download(gsdf_ctx* c, void* host_dst, const void* dev_src, int64_t bytes) {
+    if (!c || !host_dst || !dev_src || bytes < 0) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(host_dst, dev_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return GSDF_OK;
 }
 int gsdf_dev_upload(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes) {

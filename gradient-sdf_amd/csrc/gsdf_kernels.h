@@ -129,6 +129,13 @@ void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, 
 void gsdf_launch_mesh(hipStream_t s, gsdf_table tab, size_t n_slots, float vs, float iso, int* mn_dev, const signed char* tri_table_dev,
                       float* tris_dev, unsigned long long* keys_dev, unsigned long long* counter, long long max_tris);
 
+/* dense block exchange (frame-sharded fusion): list of block keys; pack / unpack of 64 x 5 raw sums per listed block */
+void gsdf_launch_block_keys(hipStream_t s, gsdf_table tab, size_t n_blocks, unsigned long long* out_dev, unsigned long long* counter,
+                            long long max_n);
+void gsdf_launch_pack_blocks(hipStream_t s, gsdf_table tab, const unsigned long long* keys_dev, long long n, float* dense_dev);
+void gsdf_launch_unpack_blocks(hipStream_t s, gsdf_table tab, const unsigned long long* keys_dev, long long n, const float* dense_dev,
+                               gsdf_dev_state* st);
+
 /* PhotoBA (gsdf_ba.hip): device-side problem description, same layout as the kernels' ba_args */
 struct gsdf_ba_dev {
     gsdf_table tab;

@@ -1417,3 +1417,67 @@ void gsdf_launch_mesh(hipStream_t s, gsdf_table tab, size_t n_slots, float vs, f
     hipLaunchKernelGGL(k_mesh, dim3(2048), dim3(256), 0, s, tab, n_slots, vs, iso, mn_dev, tri_table_dev, tris_dev, keys_dev, counter,
                        max_tris);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense block exchange for the frame-sharded fusion: the ranks agree on the union of their block
+ * keys, every rank packs its raw sums (w, s, gx, gy, gz per voxel; zeros where it has nothing) for those blocks
+ * into one dense buffer, RCCL all-reduces the buffer (sum), and every rank stores the result.
+ * ---------------------------------------------------------------------------------------------- */
+__global__ __launch_bounds__(256) void k_block_keys(gsdf_table tab, size_t n_blocks, unsigned long long* out,
+                                                     unsigned long long* counter, long long max_n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n_blocks; i += stride) {
+        const unsigned long long bk = tab.bkeys[i];
+        if (bk == GSDF_KEY_EMPTY) continue;
+        const unsigned long long o = atomicAdd(counter, 1ull);
+        if ((long long)o < max_n) out[o] = bk;
+    }
+}
+/* one 64-lane wavefront per block: lane = voxel of the block */
+__global__ __launch_bounds__(256) void k_pack_blocks(gsdf_table tab, const unsigned long long* __restrict__ keys, long long n,
+                                                      float* __restrict__ dense) {
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bk = keys[b];
+    const uint32_t h = gsdf_hash(bk) & tab.block_mask;
+    const int blk = gsdf_block_find(tab, bk, h, tab.bkeys[h]);
+    float v[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+    if (blk >= 0) {
+        const gsdf_payload p = tab.vox[(size_t)blk * GSDF_BLOCK_VOX + lane];
+        v[0] = p.w; v[1] = p.s; v[2] = p.gx; v[3] = p.gy; v[4] = p.gz;
+    }
+    float* o = dense + ((size_t)b * GSDF_BLOCK_VOX + lane) * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = v[k];
+}
+__global__ __launch_bounds__(256) void k_unpack_blocks(gsdf_table tab, const unsigned long long* __restrict__ keys, long long n,
+                                                        const float* __restrict__ dense, gsdf_dev_state* st) {
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bk = keys[b];
+    const uint32_t h = gsdf_hash(bk) & tab.block_mask;
+    int blk = 0;
+    if (lane == 0) blk = gsdf_block_find_or_insert(tab, bk, h, tab.bkeys[h]);
+    blk = __shfl(blk, 0);
+    if (blk < 0) { if (lane == 0) atomicOr(&st->status, GSDF_STATUS_TABLE_FULL); return; }
+    const float* v = dense + ((size_t)b * GSDF_BLOCK_VOX + lane) * 5;
+    gsdf_payload p;
+    p.w = v[0]; p.s = v[1]; p.gx = v[2]; p.gy = v[3]; p.gz = v[4]; p.aux = 0u; p.pad[0] = 0u; p.pad[1] = 0u;
+    tab.vox[(size_t)blk * GSDF_BLOCK_VOX + lane] = p;
+}
+void gsdf_launch_block_keys(hipStream_t s, gsdf_table tab, size_t n_blocks, unsigned long long* out, unsigned long long* counter,
+                            long long max_n) {
+    hipLaunchKernelGGL(k_block_keys, dim3(256), dim3(256), 0, s, tab, n_blocks, out, counter, max_n);
+}
+void gsdf_launch_pack_blocks(hipStream_t s, gsdf_table tab, const unsigned long long* keys, long long n, float* dense) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pack_blocks, dim3((unsigned int)((n + 3) / 4)), dim3(256), 0, s, tab, keys, n, dense);
+}
+void gsdf_launch_unpack_blocks(hipStream_t s, gsdf_table tab, const unsigned long long* keys, long long n, const float* dense,
+                               gsdf_dev_state* st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_unpack_blocks, dim3((unsigned int)((n + 3) / 4)), dim3(256), 0, s, tab, keys, n, dense, st);
+}

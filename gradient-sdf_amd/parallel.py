@@ -3,8 +3,14 @@
 `MapGradPixelSdf::update` with a KNOWN pose depends only on (depth, pose) and mutates the map
 additively (W = sum w, S = sum w d, G = sum w R n; key set = union), so frames are independent units:
 each rank (one process per GPU, torch.distributed over RCCL/xGMI) fuses a contiguous frame range into
-its private table and ONE exchange step follows -- an all-gather of the compacted (key, raw sums)
-lists (32 B per occupied voxel) and a local additive merge, after which every rank holds the full map.
+its private table and ONE exchange step follows, after which every rank holds the full map.  Two forms:
+  * `allreduce_merge`  -- the all-reduce of per-voxel sums named in BASELINE.json: the map is a hash of 4x4x4 voxel
+    blocks; the ranks all-gather + unique their block ids, pack 64 x 5 raw sums per block of the union into one dense
+    device buffer (zeros where a rank has nothing), all-reduce it (sum) and store the result.  Volume per rank:
+    1280 B per block of the union, independent of the number of ranks -- the form for overlapping shards (8 GPUs
+    scanning one scene);
+  * `exchange_and_merge` -- all-gather of the compacted (key, raw sums) lists (32 B per occupied voxel per rank) and a
+    local additive merge: cheaper when the shards barely overlap.
 The tracked path cannot be sharded (frame i needs the map of all frames < i): replicas only.
 
 All functions work on CPU tensors under gloo (used by the world-size-2 tests) and on device tensors
@@ -76,3 +82,106 @@ def exchange_and_merge(g, dist):
         g.merge_raw_dev(k.data_ptr(), p.data_ptr(), k.shape[0])
     torch.cuda.synchronize()
     return sum(k.shape[0] for k, _ in lists)
+
+
+# ---- dense block all-reduce ------------------------------------------------------------------------------------
+BLOCK_VOX = 64            # voxels per 4x4x4 block (csrc/gsdf_table.h)
+
+
+def union_block_keys(local_keys, dist, device="cpu"):
+    """All-gather the ranks' block-id lists (int64 tensors of different lengths) and return the sorted union --
+    identical on every rank."""
+    import torch
+    world = dist.get_world_size()
+    local_keys = torch.as_tensor(local_keys, dtype=torch.int64, device=device).reshape(-1)
+    n = torch.tensor([local_keys.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    m = max(max(counts), 1)
+    pad = torch.zeros(m, dtype=torch.int64, device=device)
+    pad[:local_keys.shape[0]] = local_keys
+    allk = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(allk, pad)
+    return torch.unique(torch.cat([allk[r][:counts[r]] for r in range(world)]))
+
+
+def allreduce_merge(ops, dist, device="cpu"):
+    """One all-reduce of per-voxel (weight, weighted distance, weighted gradient) over the union of the ranks' blocks.
+    `ops` provides block_keys() -> int64 tensor, pack(union) -> float32 tensor [n, 64, 5], unpack(union, dense)
+    (GpuBlockOps below for a binding.GradSdf; NumpyBlockOps for the CPU tests).  Returns the number of blocks."""
+    union = union_block_keys(ops.block_keys(), dist, device=device)
+    dense = ops.pack(union)
+    dist.all_reduce(dense)                       # sum; RCCL over xGMI under the nccl backend
+    ops.unpack(union, dense)
+    return int(union.shape[0])
+
+
+class GpuBlockOps:
+    """Block exchange primitives of a binding.GradSdf on device tensors (gsdf_block_keys_dev / _pack_ / _unpack_)."""
+
+    def __init__(self, g, capacity_log2):
+        self.g = g
+        self.max_blocks = 1 << (int(capacity_log2) - 6)
+
+    def block_keys(self):
+        import torch
+        buf = torch.empty(self.max_blocks, dtype=torch.int64, device="cuda")
+        n = self.g.block_keys_dev(buf.data_ptr(), self.max_blocks)
+        return buf[:n]
+
+    def pack(self, union):
+        import torch
+        union = union.contiguous()
+        dense = torch.zeros((union.shape[0], BLOCK_VOX, 5), dtype=torch.float32, device="cuda")
+        self.g.pack_blocks_dev(union.data_ptr(), union.shape[0], dense.data_ptr())
+        return dense
+
+    def unpack(self, union, dense):
+        import torch
+        union = union.contiguous()
+        self.g.unpack_blocks_dev(union.data_ptr(), union.shape[0], dense.contiguous().data_ptr())
+        torch.cuda.synchronize()
+
+
+def block_id(keys):
+    """Block id (csrc/gsdf_table.h gsdf_block_key) and in-block index of voxel keys int[n,3]."""
+    k = np.asarray(keys, np.int64).reshape(-1, 3)
+    b = (k >> 2) + (1 << 18)
+    bid = b[:, 0] | (b[:, 1] << 19) | (b[:, 2] << 38)
+    local = (k[:, 0] & 3) | ((k[:, 1] & 3) << 2) | ((k[:, 2] & 3) << 4)
+    return bid, local
+
+
+class NumpyBlockOps:
+    """The same three primitives on a host (keys, raw payload) table: the CPU stand-in used by the gloo tests."""
+
+    def __init__(self, keys, payload):
+        self.keys = np.asarray(keys, np.int32).reshape(-1, 3)
+        self.pay = np.asarray(payload, np.float32).reshape(-1, 5)      # raw sums: s, gx, gy, gz, w  (export order)
+
+    def block_keys(self):
+        import torch
+        bid, _ = block_id(self.keys)
+        return torch.from_numpy(np.unique(bid))
+
+    def pack(self, union):
+        import torch
+        u = union.numpy()
+        dense = np.zeros((len(u), BLOCK_VOX, 5), np.float32)
+        bid, local = block_id(self.keys)
+        row = np.searchsorted(u, bid)
+        dense[row, local] = self.pay[:, [4, 0, 1, 2, 3]]                 # dense order: w, s, gx, gy, gz
+        return torch.from_numpy(dense)
+
+    def unpack(self, union, dense):
+        u = union.numpy()
+        d = dense.numpy()
+        b, l = np.nonzero(d[:, :, 0] > 0)                                # a voxel exists iff w > 0
+        bx = (u[b] & 0x7FFFF) - (1 << 18)
+        by = ((u[b] >> 19) & 0x7FFFF) - (1 << 18)
+        bz = ((u[b] >> 38) & 0x7FFFF) - (1 << 18)
+        keys = np.stack([bx * 4 + (l & 3), by * 4 + ((l >> 2) & 3), bz * 4 + ((l >> 4) & 3)], 1).astype(np.int32)
+        pay = d[b, l][:, [1, 2, 3, 4, 0]].astype(np.float32)
+        order = np.lexsort((keys[:, 0], keys[:, 1], keys[:, 2]))
+        self.keys, self.pay = keys[order], pay[order]

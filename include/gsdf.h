@@ -152,6 +152,16 @@ int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, i
 int gsdf_export_raw_dev(gsdf_ctx* c, int32_t* keys_dev, float* payload_raw_dev, int64_t max_n, int64_t* n);
 int gsdf_merge_raw_dev(gsdf_ctx* c, const int32_t* keys_dev, const float* payload_raw_dev, int64_t n);
 
+/* Dense variant of the exchange: the all-reduce of per-voxel (weight, weighted distance, weighted gradient) named in
+ * BASELINE.json's north_star.  The map is a hash of 4x4x4 voxel blocks; block ids are opaque 64-bit words, identical
+ * across contexts.  (1) gsdf_block_keys_dev lists this map's block ids (*n = count, also when > max_n); the ranks
+ * all-gather and unique them; (2) gsdf_pack_blocks_dev writes 64 x 5 raw sums (w, s, gx, gy, gz; zeros for voxels or
+ * blocks this map lacks) per listed block into a DEVICE buffer, which RCCL all-reduces (sum); (3)
+ * gsdf_unpack_blocks_dev stores the reduced sums (inserting missing blocks).  All pointers are device pointers. */
+int gsdf_block_keys_dev(gsdf_ctx* c, uint64_t* block_keys_dev, int64_t max_n, int64_t* n);
+int gsdf_pack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t n, float* dense_dev);
+int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t n, const float* dense_dev);
+
 /* Sdf::weights(point) and Sdf::tsdf(point, &grad) at n points -- MapGradPixelSdf.h:109-125.
  * w[i]==0 marks a missing voxel (dist/grad are then 0; the reference's .at() would throw). */
 int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w);
@@ -176,6 +186,7 @@ int gsdf_extract_mesh(gsdf_ctx* c, float iso, const int8_t tri_table[256 * 16], 
 int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes);
 int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr);
 int gsdf_dev_upload(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes);
+int gsdf_dev_download(gsdf_ctx* c, void* host_dst, const void* dev_src, int64_t bytes);
 /* HIP-event timing on the context's stream: t0/t1 bracket whatever is enqueued between them */
 int gsdf_timer_start(gsdf_ctx* c);
 int gsdf_timer_stop_ms(gsdf_ctx* c, float* ms);          /* synchronises */

@@ -266,6 +266,39 @@ def test_device_export_merge_is_the_shard_exchange(pkg, O):
     gb.close()
 
 
+def test_dense_block_allreduce_is_the_shard_exchange(pkg, O):
+    """gsdf_block_keys_dev -> (all-gather, unique) -> gsdf_pack_blocks_dev -> (all-reduce) -> gsdf_unpack_blocks_dev: the dense
+    form of the exchange, here as two logical shards on one GPU with the sum done on the host."""
+    seq, ga, o = _mk(pkg, O, n=4, cap=19)
+    gb = pkg.GradSdf(np.float32(0.02), np.float32(5) * np.float32(0.02), 160, 120, seq.K, capacity_log2=19)
+    for i in range(seq.n):
+        d, R, t = seq.frame(i)
+        (ga if i < 2 else gb).update(d, R, t)
+        o.update(d, R, t)
+    cap = 1 << (19 - 6)
+    lists = []
+    for g in (ga, gb):
+        buf = g.upload(np.zeros(cap, np.int64))
+        n = g.block_keys_dev(buf.value, cap)
+        assert 0 < n <= cap
+        lists.append(g.download(buf, (n,), np.int64))
+    union = np.unique(np.concatenate(lists))
+    dense = []
+    for g in (ga, gb):
+        kd = g.upload(union)
+        dd = g.upload(np.zeros((len(union), 64, 5), np.float32))
+        g.pack_blocks_dev(kd.value, len(union), dd.value)
+        dense.append(g.download(dd, (len(union), 64, 5), np.float32))
+    total = dense[0] + dense[1]                                        # what the all-reduce leaves on every rank
+    for g in (ga, gb):
+        kd = g.upload(union)
+        dd = g.upload(total)
+        g.unpack_blocks_dev(kd.value, len(union), dd.value)
+        _cmp_tables(g, o)
+    ga.close()
+    gb.close()
+
+
 def test_stress_config_c3_small_slice(pkg, O):
     """BASELINE config C3 geometry (5 mm voxels, trunc 10, K scaled) on a 1280x960 frame, capacity 2^23."""
     W, H = 1280, 960

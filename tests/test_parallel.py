@@ -41,12 +41,16 @@ def _worker(rank, world, port, out_dir):
     raw[:, 0] = pay[:, 0] * pay[:, 4]                    # dist -> sum w*d (the wire format carries sums)
     lists = pkg.parallel.allgather_lists(keys, raw, dist)
     k, p = pkg.parallel.merge_numpy([(a.numpy(), b.numpy()) for a, b in lists])
+    # the dense form: one all-reduce of per-voxel sums over the union of the ranks' 4x4x4 blocks
+    ops = pkg.parallel.NumpyBlockOps(keys, raw)
+    n_blocks = pkg.parallel.allreduce_merge(ops, dist)
     # barrier + max-over-ranks reduction used by bench.py's timing
     import torch
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), keys=k, pay=p, tmax=t.numpy(), lo=lo, hi=hi)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), keys=k, pay=p, tmax=t.numpy(), lo=lo, hi=hi, keys_ar=ops.keys, pay_ar=ops.pay,
+             n_blocks=n_blocks)
     dist.destroy_process_group()
 
 
@@ -78,6 +82,10 @@ def test_frame_sharded_fusion_world2_gloo(pkg, O, tmp_path):
     assert (int(a["lo"]), int(a["hi"]), int(b["lo"]), int(b["hi"])) == (0, 3, 3, 5)
     assert a["tmax"][0] == 2.0 and b["tmax"][0] == 2.0
     assert np.array_equal(a["keys"], b["keys"]) and np.array_equal(a["pay"], b["pay"])
+    # the all-reduce form gives the same map on both ranks, and the same map as the all-gather form
+    assert np.array_equal(a["keys_ar"], b["keys_ar"]) and np.array_equal(a["pay_ar"], b["pay_ar"]) and int(a["n_blocks"]) > 10
+    assert np.array_equal(a["keys_ar"], a["keys"])
+    assert np.abs(a["pay_ar"] - a["pay"]).max() <= 1e-5 * max(1.0, float(np.abs(a["pay"]).max()))
     # single-process reference over all frames
     W, H, n = 96, 72, 5
     seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=9, step_deg=3.0)

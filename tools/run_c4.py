@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""BASELINE config C4: frame-sharded GT-pose fusion of a synthetic sphere stream with one RCCL exchange
-(all-gather of the (key, raw sums) lists + additive merge), then a single-GPU marching-cubes export.
+"""BASELINE config C4: frame-sharded GT-pose fusion of a synthetic sphere stream with one RCCL exchange -- by default the
+all-reduce of per-voxel sums over the union of the ranks' 4x4x4 blocks (--exchange allgather: all-gather of the (key, raw
+sums) lists + additive merge) -- then the marching-cubes export on the device.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/run_c4.py --frames 2000
 
@@ -16,6 +17,8 @@ def main():
     ap.add_argument("--frames", type=int, default=2000)
     ap.add_argument("--out", default="/tmp/c4_mesh.ply")
     ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather"])
+    ap.add_argument("--force-exchange", action="store_true", help="run the exchange also with one rank (degenerate, for testing)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -43,7 +46,15 @@ def main():
             g.L.gsdf_dev_free(g.h, d)
         g._dev = []
     t0 = time.perf_counter()
-    exchanged = pkg.parallel.exchange_and_merge(g, dist) if world > 1 else 0
+    exchanged = 0
+    if world > 1 or args.force_exchange:
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(args.dist_backend, rank=0, world_size=1)
+        if args.exchange == "allreduce":
+            exchanged = pkg.parallel.allreduce_merge(pkg.parallel.GpuBlockOps(g, 23), dist, device="cuda") * 64
+        else:
+            exchanged = pkg.parallel.exchange_and_merge(g, dist)
     t_merge = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([t_fuse, t_merge], dtype=torch.float64, device="cuda")
@@ -57,10 +68,10 @@ def main():
         faces = hl.gsdf_host_extract_mesh(g.h, vs, args.out.encode())
         print(json.dumps({"config": "C4 frame-sharded fusion", "n_gpus": world, "frames": args.frames,
                           "fused_fps_total": round(args.frames / t_fuse, 1), "fuse_s": round(t_fuse, 3),
-                          "merge_s": round(t_merge, 4), "exchanged_voxels": exchanged, "voxels": g.count(),
+                          "exchange": args.exchange, "merge_s": round(t_merge, 4), "exchanged_voxels": exchanged, "voxels": g.count(),
                           "mesh_faces": faces, "mesh_s": round(time.perf_counter() - t0, 2), "mesh": args.out}))
     g.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
