@@ -160,19 +160,25 @@ class NumpyBlockOps:
         self.keys = np.asarray(keys, np.int32).reshape(-1, 3)
         self.pay = np.asarray(payload, np.float32).reshape(-1, 5)      # raw sums: s, gx, gy, gz, w  (export order)
 
+    def block_keys_numpy(self):
+        bid, _ = block_id(self.keys)
+        return np.unique(bid)
+
     def block_keys(self):
         import torch
-        bid, _ = block_id(self.keys)
-        return torch.from_numpy(np.unique(bid))
+        return torch.from_numpy(self.block_keys_numpy())
 
-    def pack(self, union):
-        import torch
-        u = union.numpy()
+    def pack_numpy(self, u):
+        """dense float32 [len(u), 64, 5] (w, s, gx, gy, gz) of the blocks listed in the sorted id array `u`."""
         dense = np.zeros((len(u), BLOCK_VOX, 5), np.float32)
         bid, local = block_id(self.keys)
         row = np.searchsorted(u, bid)
         dense[row, local] = self.pay[:, [4, 0, 1, 2, 3]]                 # dense order: w, s, gx, gy, gz
-        return torch.from_numpy(dense)
+        return dense
+
+    def pack(self, union):
+        import torch
+        return torch.from_numpy(self.pack_numpy(union.numpy()))
 
     def unpack(self, union, dense):
         u = union.numpy()

@@ -299,6 +299,29 @@ def test_dense_block_allreduce_is_the_shard_exchange(pkg, O):
     gb.close()
 
 
+def test_block_ids_and_dense_layout_match_the_host_statement(pkg, O):
+    """parallel.NumpyBlockOps (used by the world-2 gloo test) and the device kernels agree on block ids, the in-block
+    voxel order and the dense (w, s, gx, gy, gz) layout."""
+    seq, g, o = _mk(pkg, O, n=3, cap=19)
+    for i in range(seq.n):
+        g.update(*seq.frame(i))
+    cap = 1 << (19 - 6)
+    buf = g.upload(np.zeros(cap, np.int64))
+    n = g.block_keys_dev(buf.value, cap)
+    dev_ids = np.sort(g.download(buf, (n,), np.int64))
+    keys, raw = g.export(sorted=True, raw=True)
+    ops = pkg.parallel.NumpyBlockOps(keys, raw)
+    host_ids = ops.block_keys_numpy()
+    assert np.array_equal(dev_ids, host_ids)
+    kd = g.upload(host_ids)
+    dd = g.upload(np.zeros((n, 64, 5), np.float32))
+    g.pack_blocks_dev(kd.value, n, dd.value)
+    dense_dev = g.download(dd, (n, 64, 5), np.float32)
+    dense_host = ops.pack_numpy(host_ids)
+    assert np.array_equal(dense_dev, dense_host)
+    g.close()
+
+
 def test_stress_config_c3_small_slice(pkg, O):
     """BASELINE config C3 geometry (5 mm voxels, trunc 10, K scaled) on a 1280x960 frame, capacity 2^23."""
     W, H = 1280, 960
