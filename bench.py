@@ -202,11 +202,14 @@ def main():
 
     # HBM traffic of one fusion (k_fuse + k_fuse_resolve) from the committed rocprofv3 PMC passes
     traffic = None
+    l2_atomics = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             # measured on the default workload only: report it for that workload, null otherwise
             if (W, H) == (640, 480) and abs(float(vs) - 0.01) < 1e-6 and args.trunc == 10.0:
-                traffic = json.load(f).get("traffic_bytes_per_fusion")
+                pmc = json.load(f)
+                traffic = pmc.get("traffic_bytes_per_fusion")
+                l2_atomics = round(pmc.get("k_fuse", {}).get("TCC_ATOMIC", 0) + pmc.get("k_fuse_resolve", {}).get("TCC_ATOMIC", 0))
     except (OSError, ValueError):
         pass
 
@@ -240,6 +243,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(fuse_ms * 1e3, 2),
                 "launches": prof["fusion"]["launches"],
+                "l2_atomics_per_launch": l2_atomics,       # the C2 table is cache resident, so report atomics too
             },
             "cpu_baseline": cpu,
         }
