@@ -76,16 +76,19 @@ def test_fusion_forced_paths_match_oracle(pkg, O, flags, name):
     seq, g, o = _mk(pkg, O, kind="tum", W=320, H=240, vs=0.01, trunc=10, cap=21, n=3)
     L = pkg.binding.load()
     L.gsdf_debug_flags(flags)
+    nu = nv = 0
     try:
         for i in range(seq.n):
             d, R, t = seq.frame(i)
             g.update(d, R, t)
-            o.update(d, R, t)
+            a, b = o.update(d, R, t)
+            nu += a; nv += b
         g.sync()
     finally:
         L.gsdf_debug_flags(0)
     assert _cmp_tables(g, o) > 10000
     st = g.stats()
+    assert st["n_upd"] == nu and st["n_valid"] == nv                          # every sample and pixel counted exactly once
     assert st["fuse_timeouts"] == 0
     assert (st["n_deferred"] > 10000) == bool(flags & 4) or flags == 256      # only the forced-deferred runs defer wholesale
     g.close()
