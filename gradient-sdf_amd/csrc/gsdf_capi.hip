@@ -859,7 +859,7 @@ int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[
     gsdf_pose_arg pose;
     std::memcpy(pose.R, R, sizeof(pose.R));
     std::memcpy(pose.t, t, sizeof(pose.t));
-    gsdf_launch_raycast(c->stream, c->tab, c->voxel_size, c->voxel_size_inv, W, H, K, pose, zmin, zmax, d,
+    gsdf_launch_raycast(c->stream, c->tab, c->voxel_size, c->voxel_size_inv, c->factor, W, H, K, pose, zmin, zmax, d,
                         normals_out ? d + N : nullptr);
     hipError_t e = hipMemcpyAsync(depth_out, d, N * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && normals_out)

@@ -122,7 +122,7 @@ void gsdf_launch_merge_raw(hipStream_t s, gsdf_table tab, const int32_t* keys, c
 void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, const float* pts, long long n,
                        float* dist, float* grad, float* w);
 
-void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, int W, int H, const float K[9],
+void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, int factor /* band half-width in voxels */, int W, int H, const float K[9],
                          const gsdf_pose_arg& pose, float zmin, float zmax, float* depth_dev, float* normals_dev_or_null);
 
 /* iso-surface: bounding-box minimum (mn_dev preset to INT_MAX x3), then triangles + sort keys appended through `counter` */

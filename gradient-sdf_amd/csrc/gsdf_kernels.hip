@@ -1246,8 +1246,8 @@ void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, co
 /* ------------------------------------------------------------------------------------------------
  * Voxel-hash raycaster (BASELINE.json north_star; absent from the reference): defined
  * on top of weights()/tsdf() -- MapGradPixelSdf.h:109-125 -- and the tracker's back-projection
- * (RigidPointOptimizer.cpp:46-47,67-70): p(s) = s R (x0, y0, 1) + t; 4-voxel steps while the voxel under
- * p(s) is missing, 1-voxel steps inside the band; hit = first sign change phi_prev < 0 <= phi of two
+ * (RigidPointOptimizer.cpp:46-47,67-70): p(s) = s R (x0, y0, 1) + t; min(4, factor)-voxel steps while the voxel
+ * under p(s) is missing, 1-voxel steps inside the band; hit = first sign change phi_prev < 0 <= phi of two
  * consecutive in-band samples (the SDF is negative in front of a surface); depth by linear interpolation,
  * normal = R^T grad/|grad| of the sample behind the surface.  The test suite holds a CPU statement of the same
  * definition.
@@ -1255,7 +1255,7 @@ void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, co
  * are L2 hits, records share lines).  The walk is a chain of dependent lookups per ray: 4-voxel steps
  * through empty space (one key probe each), 1-voxel steps inside the band.
  * ---------------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float inv_vs, int W, int H, float fx, float fy,
+__global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float inv_vs, int factor, int W, int H, float fx, float fy,
                                                   float cx, float cy, gsdf_pose_arg pose, float zmin, float zmax,
                                                   float* __restrict__ depth, float* __restrict__ normals) {
     const int u = blockIdx.x * 16 + (threadIdx.x & 15), v = blockIdx.y * 16 + (threadIdx.x >> 4);
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
     const float fx_inv = 1.f / fx, fy_inv = 1.f / fy;
     const float x0 = ((float)u - cx) * fx_inv, y0 = ((float)v - cy) * fy_inv;
     const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ x0, y0, 1.f });
-    const float fine = vs, coarse = 4.f * vs;
+    const float fine = vs, coarse = (float)(factor < 1 ? 1 : (factor > 4 ? 4 : factor)) * vs;   /* never wider than the band */
     float out_z = 0.f;
     gsdf_v3 out_n = { 0.f, 0.f, 0.f };
     bool prev_ok = false;
@@ -1302,9 +1302,9 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
     depth[i] = out_z;
     if (normals) { normals[i] = out_n.x; normals[(size_t)W * H + i] = out_n.y; normals[2 * (size_t)W * H + i] = out_n.z; }
 }
-void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, int W, int H, const float K[9],
+void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, int factor, int W, int H, const float K[9],
                          const gsdf_pose_arg& pose, float zmin, float zmax, float* depth, float* normals) {
-    hipLaunchKernelGGL(k_raycast, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, s, tab, vs, inv_vs, W, H, K[0], K[4], K[2],
+    hipLaunchKernelGGL(k_raycast, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, s, tab, vs, inv_vs, factor, W, H, K[0], K[4], K[2],
                        K[5], pose, zmin, zmax, depth, normals);
 }
 

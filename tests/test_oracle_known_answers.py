@@ -268,3 +268,15 @@ def test_raycast_recovers_the_plane(O, pkg):
     assert np.abs(z2 - z0).max() < 0.5 * float(VS)
     z3, _ = o.raycast(np.eye(3), np.zeros(3), zmin=0.5, zmax=1.4)
     assert (z3 == 0).all()
+
+
+def test_raycast_thin_band(O, pkg):
+    """Truncation of 2 voxels: the walk through empty space must not be wider than the band in front of the surface."""
+    W, H = 96, 72
+    K = pkg.synth.intrinsics(W, H)
+    z0 = np.float32(1.2345)
+    o = O.Oracle(VS, np.float32(2) * VS, W, H, K)
+    o.update(np.full((H, W), z0, np.float32), np.eye(3), np.zeros(3))
+    for zmin in (0.5, 0.503, 0.507, 0.511):                         # every phase of the coarse steps relative to the band
+        z, _ = o.raycast(np.eye(3), np.zeros(3), zmin=zmin)
+        assert (z > 0).all() and np.abs(z - z0).max() < 0.5 * float(VS)
