@@ -1246,7 +1246,7 @@ void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, co
 /* ------------------------------------------------------------------------------------------------
  * Voxel-hash raycaster (BASELINE.json north_star; absent from the reference): defined
  * on top of weights()/tsdf() -- MapGradPixelSdf.h:109-125 -- and the tracker's back-projection
- * (RigidPointOptimizer.cpp:46-47,67-70): p(s) = s R (x0, y0, 1) + t; min(4, factor)-voxel steps while the voxel
+ * (RigidPointOptimizer.cpp:46-47,67-70): p(s) = s R (x0, y0, 1) + t; min(4, factor - 1)-voxel steps (at least 1) while the voxel
  * under p(s) is missing, 1-voxel steps inside the band; hit = first sign change phi_prev < 0 <= phi of two
  * consecutive in-band samples (the SDF is negative in front of a surface); depth by linear interpolation,
  * normal = R^T grad/|grad| of the sample behind the surface.  The test suite holds a CPU statement of the same
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
     const float fx_inv = 1.f / fx, fy_inv = 1.f / fy;
     const float x0 = ((float)u - cx) * fx_inv, y0 = ((float)v - cy) * fy_inv;
     const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ x0, y0, 1.f });
-    const float fine = vs, coarse = (float)(factor < 1 ? 1 : (factor > 4 ? 4 : factor)) * vs;   /* never wider than the band */
+    const float fine = vs, coarse = (float)(factor < 2 ? 1 : (factor > 5 ? 4 : factor - 1)) * vs;   /* narrower than the band in front of a surface */
     float out_z = 0.f;
     gsdf_v3 out_n = { 0.f, 0.f, 0.f };
     bool prev_ok = false;

@@ -400,7 +400,7 @@ void gsdfo_query(const gsdfo* o, const float* pts, int64_t n, float* dist, float
  * tracker's back-projection (RigidPointOptimizer.cpp:46-47,67-70).  PARITY UNPINNED (self-defined).
  *
  * Pixel (u,v): d = R (x0, y0, 1), p(s) = s d + t, s = camera depth.  March s from zmin: 4 voxels per
- * step (fewer when the truncation band is thinner: min(4, factor) voxels) while the voxel under p(s) is
+ * step (fewer when the truncation band is thinner: min(4, factor - 1) voxels, at least 1) while the voxel under p(s) is
  * missing, so that the walk cannot jump over the band in front of a surface; 1 voxel per step inside the band.  A hit is the first sign
  * change phi_prev < 0 <= phi (the reference's SDF is negative in front of the surface) between two consecutive in-band samples; depth = linear interpolation of
  * s, normal = R^T grad/|grad| of the sample behind the surface (camera frame, like NormalEstimator). */
@@ -408,7 +408,7 @@ void gsdfo_raycast(const gsdfo* o, const float K[9], const float R[9], const flo
                    float zmin, float zmax, float* depth, float* normals) {
     const float fx_inv = 1.f / K[0], fy_inv = 1.f / K[4], cx = K[2], cy = K[5];
     const int factor = (int)std::floor(o->T_ / o->voxel_size_);          /* band half-width in voxels (MapGradPixelSdf.cpp:79) */
-    const float fine = o->voxel_size_, coarse = (float)std::max(1, std::min(4, factor)) * o->voxel_size_;
+    const float fine = o->voxel_size_, coarse = (float)std::max(1, std::min(4, factor - 1)) * o->voxel_size_;
     for (int v = 0; v < H; ++v)
         for (int u = 0; u < W; ++u) {
             const float x0 = ((float)u - cx) * fx_inv, y0 = ((float)v - cy) * fy_inv;
