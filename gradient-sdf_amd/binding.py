@@ -19,6 +19,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GSDF_LIB", os.path.join(CSRC, "libgsdf.so"))   # GSDF_LIB: kernel-variant experiments (tools/)
+# the same sources with -DGSDF_EXPERIMENTS: path-forcing hooks for the tests, measurement switches for tools/
+TEST_LIB_PATH = os.path.join(CSRC, "libgsdf_test.so")
 
 GSDF_OK, ERR_TABLE_FULL, ERR_KEY_RANGE, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4, 5
 
@@ -58,19 +60,31 @@ def _hip_runtime_path():
     raise OSError("libamdhip64.so not found (need ROCm): libgsdf has no CPU fallback")
 
 
-_lib = None
+_libs = {}
 _hip = None
 
 
-def load():
+def load_test_lib():
+    """libgsdf_test.so: the -DGSDF_EXPERIMENTS build with per-context gsdf_debug_flags(ctx, flags) (tests/, tools/ only)."""
+    L = load(TEST_LIB_PATH)
+    L.gsdf_debug_flags.restype = C.c_int
+    L.gsdf_debug_flags.argtypes = [C.c_void_p, C.c_int]
+    L.gsdf_debug_read.restype = C.c_int
+    L.gsdf_debug_read.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    return L
+
+
+def load(path=None):
     """Load libgsdf.so (must already be built: the .so travels in-tree to the GPU box)."""
-    global _lib, _hip
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise OSError("%s missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % LIB_PATH)
-    _hip = C.CDLL(_hip_runtime_path(), mode=C.RTLD_GLOBAL)
-    L = C.CDLL(LIB_PATH)
+    global _hip
+    path = LIB_PATH if path is None else path
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise OSError("%s missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % path)
+    if _hip is None:
+        _hip = C.CDLL(_hip_runtime_path(), mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path)
     fp, i32p, i64p, vp = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_void_p
     sig = {
         "gsdf_last_error": (C.c_char_p, []),
@@ -123,7 +137,7 @@ def load():
         f = getattr(L, name)       # AttributeError if the .so does not export a declared symbol
         f.restype = res
         f.argtypes = args
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -153,8 +167,8 @@ class GradSdf:
     """MapGradPixelSdf + RigidPointOptimizer + NormalEstimator behind the C-ABI (one GPU)."""
 
     def __init__(self, voxel_size, trunc_dist, W, H, K, win=11, capacity_log2=22, device=0,
-                 zmin=0.5, zmax=3.5):
-        self.L = load()
+                 zmin=0.5, zmax=3.5, lib=None):
+        self.L = load() if lib is None else lib         # lib: load_test_lib() for the path-forcing tests
         self.h = C.c_void_p()
         self._chk(self.L.gsdf_create(C.byref(self.h), np.float32(voxel_size), np.float32(trunc_dist),
                                      int(capacity_log2), int(device)))
@@ -184,6 +198,10 @@ class GradSdf:
 
     def reset(self):
         self._chk(self.L.gsdf_reset(self.h))
+
+    def debug_flags(self, flags):
+        """Path-forcing / measurement switches; exists only in the test build (lib=load_test_lib())."""
+        self._chk(self.L.gsdf_debug_flags(self.h, int(flags)))
 
     # -- normals ------------------------------------------------------------------------------
     def normals_cache(self):
@@ -372,16 +390,20 @@ class GradSdf:
                                       _fp(n) if normals else None))
         return d, n
 
-    def extract_mesh(self, tri_table, iso=0.0):
-        """GPU marching cubes: float32 [n, 3, 3] triangles in the reference's sweep order (tri_table: int8 [256,16])."""
-        tt = np.ascontiguousarray(tri_table, dtype=np.int8).reshape(256 * 16)
+    def extract_mesh(self, tri_table=None, iso=0.0):
+        """GPU marching cubes: float32 [n, 3, 3] triangles in the reference's sweep order
+        (tri_table: None = the reference's classic triTable, or int8 [256,16])."""
+        tp = None
+        if tri_table is not None:
+            tt = np.ascontiguousarray(tri_table, dtype=np.int8).reshape(256 * 16)
+            tp = tt.ctypes.data_as(C.POINTER(C.c_int8))
         n = C.c_int64(0)
-        self._chk(self.L.gsdf_extract_mesh(self.h, C.c_float(iso), tt.ctypes.data_as(C.POINTER(C.c_int8)), None, 0, C.byref(n)))
+        self._chk(self.L.gsdf_extract_mesh(self.h, C.c_float(iso), tp, None, 0, C.byref(n)))
         out = np.empty((max(n.value, 1), 3, 3), np.float32)
         if n.value:
-            self._chk(self.L.gsdf_extract_mesh(self.h, C.c_float(iso), tt.ctypes.data_as(C.POINTER(C.c_int8)), _fp(out), n.value,
-                                               C.byref(n)))
+            self._chk(self.L.gsdf_extract_mesh(self.h, C.c_float(iso), tp, _fp(out), n.value, C.byref(n)))
         return out[:n.value]
+
 
     # -- timing -------------------------------------------------------------------------------
     def timer_start(self):

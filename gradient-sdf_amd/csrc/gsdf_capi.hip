@@ -7,6 +7,7 @@
  * GSDF_ERR_NO_DEVICE.
  */
 #include "../../include/gsdf.h"
+#include "../../include/gsdf_mc_tables.h"
 #include "gsdf_kernels.h"
 #include "gsdf_math.h"
 
@@ -34,7 +35,6 @@ static int fail(int code, const std::string& msg) {
             return fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
-extern int g_fuse_debug;                          /* experiment switches, see gsdf_debug_flags */
 struct gsdf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -81,6 +81,7 @@ struct gsdf_ctx {
     volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */
     unsigned int* progress_dev = nullptr;
     int adaptive = 1;                              /* issue tracker passes only as far as the device needs */
+    int debug = 0;                                 /* path-forcing / measurement switches (gsdf_debug_flags; test build only) */
     float* frame_log = nullptr;
     long long frame_log_cap = 0;
     /* misc */
@@ -175,7 +176,8 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
         }
         gsdf_launch_fuse(c->stream, g, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N, pose,
                          use_dev_pose, c->tab, c->st, c->blk_counters, c->deferred, c->deferred_count,
-                         c->deferred_cap, c->fuse_tag, c->tile_flags, c->tile_order, c->frame_log, c->frame_log_cap, c->vis, c->vis_words);
+                         c->deferred_cap, c->fuse_tag, c->tile_flags, c->tile_order, c->frame_log, c->frame_log_cap, c->vis, c->vis_words,
+                         c->debug & 0xFFFF);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
@@ -202,7 +204,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     if (tp.serial == 0) tp.serial = c->track_serial = 1;
     const bool adaptive = c->adaptive && c->progress;
     tp.progress = adaptive ? c->progress_dev : nullptr;
-    tp.debug = g_fuse_debug >> 8;
+    tp.debug = c->debug >> 16;
     /* launches 0..iters-1 gather; launch k>0 first finishes pass k-1 (reduce, solve, update); launch
      * `iters` is head-only and finishes the last pass */
     for (int k = 0; k <= iters; ++k) {
@@ -241,9 +243,15 @@ int read_state(gsdf_ctx* c, gsdf_dev_state* out) {
 extern "C" {
 
 const char* gsdf_last_error(void) { return g_err.c_str(); }
-/* experiment switch for kernel ablations (tools/); not part of include/gsdf.h */
-void gsdf_debug_flags(int flags) { g_fuse_debug = flags; }
-/* experiment counters of the kernels (tools/ only; not part of the ABI in include/gsdf.h) */
+#ifdef GSDF_EXPERIMENTS
+/* Test / measurement build only (libgsdf_test.so, make EXPERIMENTS=1); not part of include/gsdf.h and absent from the
+ * production library.  Per context.  Bits 0-15 go to k_fuse: 4 every tile defers, 256 single band, 512 four bands,
+ * 8192 every hand-off wait expires at once, 1/2/16/32/128/4096 ablation switches of tools/; bits 16+ go to the tracker. */
+int gsdf_debug_flags(gsdf_ctx* c, int flags) {
+    if (!c) return GSDF_ERR_INVALID;
+    c->debug = flags;
+    return GSDF_OK;
+}
 int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[8]) {
     if (!c || !out) return GSDF_ERR_INVALID;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
@@ -252,10 +260,9 @@ int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = h.dbg[i];
     return GSDF_OK;
 }
-#ifdef GSDF_EXPERIMENTS
-const char* gsdf_version(void) { return "gsdf-mi355x 0.1 (gfx950) +experiments"; }
+const char* gsdf_version(void) { return "gsdf-mi355x 0.2 (gfx950) +experiments"; }
 #else
-const char* gsdf_version(void) { return "gsdf-mi355x 0.1 (gfx950)"; }
+const char* gsdf_version(void) { return "gsdf-mi355x 0.2 (gfx950)"; }
 #endif
 
 int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device) {
@@ -872,7 +879,8 @@ int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[
 
 int gsdf_extract_mesh(gsdf_ctx* c, float iso, const int8_t tri_table[256 * 16], float* triangles_out, int64_t max_tris,
                       int64_t* n_tris) {
-    if (!c || !tri_table || !n_tris || (max_tris > 0 && !triangles_out)) return fail(GSDF_ERR_INVALID, "null argument");
+    if (!c || !n_tris || (max_tris > 0 && !triangles_out)) return fail(GSDF_ERR_INVALID, "null argument");
+    if (!tri_table) tri_table = GSDF_MC_TRI_TABLE;            /* the reference's triTable (LayeredMarchingCubesNoColor.cpp:96-352) */
     HIP_TRY(hipSetDevice(c->device));
     *n_tris = 0;
     /* upper bound of the output: 5 triangles per cube, one cube per voxel; sized by the caller through max_tris */

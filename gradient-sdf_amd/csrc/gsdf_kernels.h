@@ -94,7 +94,8 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       unsigned int* tile_flags /* [gsdf_fuse_grid_blocks] hand-off flags, zeroed once */,
                       const uint32_t* tile_order /* [gsdf_fuse_grid_blocks] from gsdf_fuse_tile_order, on the device */,
                       float* log_rows /* nullable: frame log, written when use_dev_pose */, long long max_rows,
-                      uint32_t* vis /* nullable: per-voxel frame bit-vectors */, int vis_words);
+                      uint32_t* vis /* nullable: per-voxel frame bit-vectors */, int vis_words,
+                      int debug /* path-forcing / measurement switches, honoured by -DGSDF_EXPERIMENTS builds only */);
 int  gsdf_fuse_grid_blocks(int W, int H);
 void gsdf_fuse_tile_order(int W, int H, uint32_t* order_host /* [gsdf_fuse_grid_blocks] */);
 /* per-launch parameters of one Gauss-Newton pass (RigidOptimizer.h:57-62) */

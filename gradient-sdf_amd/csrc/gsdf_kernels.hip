@@ -14,9 +14,9 @@
  */
 #include "gsdf_kernels.h"
 
-/* Measurement switches of the ablation tools (tools/fuse_ablate.py, go_count.py, track_ablate.py) exist only in
- * builds made with -DGSDF_EXPERIMENTS (make EXPERIMENTS=1); the path-forcing hooks the tests use (debug bits 4, 256,
- * 512 of k_fuse) are always present. */
+/* The path-forcing hooks of the tests (k_fuse debug bits 4, 256, 512, 8192) and the measurement switches of the
+ * ablation tools (tools/fuse_ablate.py, go_count.py, track_ablate.py) exist only in builds made with
+ * -DGSDF_EXPERIMENTS: libgsdf_test.so.  The production library contains none of them. */
 #ifdef GSDF_EXPERIMENTS
 #define GSDF_EXPERIMENT(flags, mask) (((flags) & (mask)) != 0)
 #else
@@ -239,13 +239,32 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
  *    matters more than bytes (double-rate fixed-point conversion, packed f32 math, uniform skips).
  * ---------------------------------------------------------------------------------------------- */
 #define FUSE_T 16
-#define FUSE_THREADS 512                 /* 4 waves (8x8 pixels each) x 2 halves of the ray walk */
-#define FUSE_LCAP 1792
+#ifndef FUSE_ZSPLIT
+#define FUSE_ZSPLIT 2                    /* slices of the ray walk: a tile is walked by 4 waves (8x8 pixels each) x FUSE_ZSPLIT */
+#endif
+#define FUSE_THREADS (256 * FUSE_ZSPLIT)
+#ifndef FUSE_LCAP
+#define FUSE_LCAP 2048                   /* LDS table entries: 512 buckets of 4 */
+#endif
 #define FUSE_NB (FUSE_LCAP / 4)
 #define FUSE_LKEY_EMPTY 0xFFFFFFFFu      /* LDS keys are 32-bit: voxel coordinates relative to the tile origin, 10 bits each */
 #define FUSE_LKEY_DEFER 0x80000000u      /* flush: the entry goes to the deferred list, low 31 bits = voxel record index */
 #define FUSE_LPROBE 12
-#define FUSE_BATCH 3
+#ifndef FUSE_BATCH
+#define FUSE_BATCH 1                     /* samples of a lane in flight through the LDS lookup: 1 measured fastest (2: +4 us, 3: +6 us per fusion) */
+#endif
+#ifndef FUSE_OCC
+#define FUSE_OCC (2 * FUSE_ZSPLIT)        /* waves per SIMD the register allocation must allow: 2 workgroups per CU */
+#endif
+/* LDS accumulators are fixed point (exact, order-independent integer adds).
+ *  - weight and weighted distance: 64 bit, 2^-40.  dist = s / w must hold to 1e-4 also for a voxel whose only sample
+ *    has a weight of 2^-24 (w = 1 - sdf/T is a multiple of 2^-24), and such a voxel must EXIST (w > 0): both sums keep
+ *    every bit of their float terms (|x| >= 2^-17 exactly, below that to 2^-40).
+ *  - weighted normal: signed 32 bit, 2^-21.  A ray's samples are >= one voxel apart, so at most 2 of them round to one
+ *    voxel: a voxel collects <= 2 x 256 terms of a tile, each |term| <= 1 => |sum| <= 512 < 2^10.  A term is truncated
+ *    to 2^-21 (2.4e-7 absolute; the gradient bar is 1e-4 relative to max(1, weight)). */
+#define FUSE_FIX_ONE 2097152.0f          /* 2^21 */
+#define FUSE_FIX_INV 4.76837158203125e-07f
 typedef uint32_t gsdf_u32x4 __attribute__((ext_vector_type(4)));
 
 struct fuse_args {
@@ -268,13 +287,15 @@ struct fuse_args {
                                            XCD b % 8) gets a tile of image stripe b % 8, so neighbouring tiles share an L2 */
     uint32_t* vis;                      /* optional per-voxel frame bit-vectors (vis_, MapGradPixelSdf.h:70); nullable */
     int vis_words;
-    int debug;                          /* experiment switches (gsdf_debug_flags); 0 in production */
+    int debug;                          /* path-forcing / measurement switches: only read by builds with -DGSDF_EXPERIMENTS */
 };
 
 struct fuse_lds {
     uint32_t key[FUSE_LCAP] __attribute__((aligned(16)));
-    unsigned long long w[FUSE_LCAP], s[FUSE_LCAP], gx[FUSE_LCAP], gy[FUSE_LCAP], gz[FUSE_LCAP];
-    float red[16];
+    unsigned long long ws[FUSE_LCAP * 2] __attribute__((aligned(16)));   /* per entry: sum w, sum w * truncated sdf (2^-40) */
+    uint32_t g[FUSE_LCAP * 3] __attribute__((aligned(16)));              /* per entry: sum w * R n (2^-21); odd stride: a wave's
+                                                                            scattered entries spread over the banks */
+    unsigned int cnt[2][4 * FUSE_ZSPLIT];   /* per wave: samples with w > 0, valid pixels */
     unsigned int n_defer, defer_base;
     unsigned int st_min[4], st_max[4];  /* per wave: smallest / largest valid depth (float bits) */
     float st_cnt[4];                    /* per wave: valid pixels */
@@ -293,6 +314,7 @@ __device__ __forceinline__ unsigned long long f2fix(float x) {
 __device__ __forceinline__ float fix2f(unsigned long long v) {
     return __ll2float_rn((long long)v) * 9.094947017729282e-13f;   /* 2^-40 */
 }
+__device__ __forceinline__ float fix2f(uint32_t v) { return (float)(int)v * FUSE_FIX_INV; }
 
 /* additive update with float atomics: merge / resolve kernels */
 __device__ __forceinline__ void hbm_accumulate(const gsdf_table& T, unsigned long long key, float w, float s,
@@ -322,8 +344,16 @@ __device__ __forceinline__ void vis_mark(const fuse_args& a, const gsdf_payload*
     atomicOr(&a.vis[slot * a.vis_words + (frame >> 5)], 1u << (frame & 31));
 }
 
-int g_fuse_debug = 0;
-__global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 waves per SIMD = 2 workgroups per CU */
+__device__ __forceinline__ void fuse_lds_clear(fuse_lds& L, int tid) {
+    gsdf_u32x4* k4 = reinterpret_cast<gsdf_u32x4*>(L.key);
+    gsdf_u32x4* a4 = reinterpret_cast<gsdf_u32x4*>(L.ws);
+    gsdf_u32x4* g4 = reinterpret_cast<gsdf_u32x4*>(L.g);
+    for (int i = tid; i < FUSE_LCAP / 4; i += FUSE_THREADS) k4[i] = gsdf_u32x4{ FUSE_LKEY_EMPTY, FUSE_LKEY_EMPTY, FUSE_LKEY_EMPTY, FUSE_LKEY_EMPTY };
+    for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) a4[i] = gsdf_u32x4{ 0u, 0u, 0u, 0u };
+    for (int i = tid; i < FUSE_LCAP * 3 / 4; i += FUSE_THREADS) g4[i] = gsdf_u32x4{ 0u, 0u, 0u, 0u };
+}
+
+__global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
     __shared__ fuse_lds L;
     if (a.use_dev_pose && !a.st->converged) return;        /* main_scan_3d.cpp:261: if (conv) update */
     const int tid = threadIdx.x;
@@ -344,14 +374,14 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     const gsdf_frame_geom& g = a.g;
     const long long frame_cur = a.vis ? a.st->frame_cur : 0;   /* Sdf::counter_ of this update (snapshot by k_normals) */
     const int wave = tid >> 6, lane = tid & 63;
-    const int zhalf = wave >> 2;
+    const int zslice = wave >> 2;
     const int lx = lane & 7, ly = lane >> 3;
     const int bid = (int)blockIdx.x;
     const uint32_t tile_id = a.tile_order[bid];
     const int tile_x = (int)(tile_id & 0xFFFFu), tile_y = (int)(tile_id >> 16);
     bool valid = false;
     float z = 0.f;
-    gsdf_v3 Rxy = { 0.f, 0.f, 0.f }, Rn = { 0.f, 0.f, 0.f };
+    gsdf_v3 Rxy = { 0.f, 0.f, 0.f }, Rn = { 0.f, 0.f, 0.f };   /* Rn carries the fixed-point scale: w * Rn is the scaled term */
     auto load_pixel = [&](int px, int py, const float* dp, const float* x0p, const float* y0p, const float* nip,
                           const float* nxp, const float* nyp, const float* nzp) {
         valid = px < g.W && py < g.H;
@@ -365,7 +395,8 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
             const float ninv = nip[idx];
             valid = !(z <= g.zmin || z >= g.zmax);                         /* MapGradPixelSdf.cpp:87 */
             Rxy = gsdf_matvec(R, xy);                                      /* :91 */
-            Rn = gsdf_matvec(R, n);                                        /* :93 */
+            const gsdf_v3 rn = gsdf_matvec(R, n);                          /* :93 */
+            Rn = gsdf_v3{ rn.x * FUSE_FIX_ONE, rn.y * FUSE_FIX_ONE, rn.z * FUSE_FIX_ONE };   /* exact (power of two) */
             if ((double)gsdf_dot3(n, n) < .1) valid = false;               /* :95 (same comparison as the reference: NaN passes) */
             const float nd = gsdf_dot3(n, xy);
             if (nd * nd * ninv < .25) valid = false;                       /* :98 */
@@ -375,32 +406,31 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     load_pixel(tile_x * FUSE_T + (wave & 1) * 8 + lx, tile_y * FUSE_T + ((wave >> 1) & 1) * 8 + ly,
                a.depth, a.nc.x0, a.nc.y0, a.nc.ninv, a.nx, a.ny, a.nz);
     /* meanwhile: empty table */
-    for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
-        L.key[i] = FUSE_LKEY_EMPTY;
-        L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
-    }
+    fuse_lds_clear(L, tid);
     if (tid == 0) {
         L.n_defer = 0u; L.defer_base = 0u;
         L.plane[0] = a.depth; L.plane[1] = a.nc.x0; L.plane[2] = a.nc.y0; L.plane[3] = a.nc.ninv;
         L.plane[4] = a.nx; L.plane[5] = a.ny; L.plane[6] = a.nz;
     }
     /* depth range of the tile and the number of valid pixels: one entry per wave of the first half */
-    if (zhalf == 0) {
+    if (zslice == 0) {
         unsigned int zb = valid ? __float_as_uint(z) : 0x7F800000u, zt = valid ? __float_as_uint(z) : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned int o1 = __shfl_xor(zb, o), o2 = __shfl_xor(zt, o);
             zb = o1 < zb ? o1 : zb; zt = o2 > zt ? o2 : zt;
         }
-        const float cnt = wave_sum(valid ? 1.f : 0.f);
+        const float cnt = (float)__popcll(__ballot(valid));
         if (lane == 0) { L.st_min[wave] = zb; L.st_max[wave] = zt; L.st_cnt[wave] = cnt; }
     }
     __syncthreads();
     const int nk_all = 2 * g.factor + 1;
     const int colour = (tile_x & 1) + 2 * (tile_y & 1);
     unsigned int* my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
-    /* every lane derives the two tile-wide decisions from the four entries (same result everywhere) */
+    /* every lane derives the tile-wide decisions from the four entries (same result everywhere) */
     int n_pass;
+    int ox, oy, oz;
+    bool range_ok;
     {
         const unsigned int zmin_bits = min(min(L.st_min[0], L.st_min[1]), min(L.st_min[2], L.st_min[3]));
         const unsigned int zmax_bits = max(max(L.st_max[0], L.st_max[1]), max(L.st_max[2], L.st_max[3]));
@@ -413,7 +443,7 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
         const float xm = fmaxf(fabsf(x_lo), fabsf(x_hi)) + 1.f, ym = fmaxf(fabsf(y_lo), fabsf(y_hi)) + 1.f;
         const float gap = (float)FUSE_T + 0.5f;                       /* true gap is FUSE_T + 1 pixels */
         bool ordered = s_min > 0.f && D * (g.fx + xm) <= gap * s_min && D * (g.fy + ym) <= gap * s_min;
-        if (a.debug & 4) ordered = false;
+        if (GSDF_EXPERIMENT(a.debug, 4)) ordered = false;
         if (tid == 0) {
             L.ordered = ordered ? 1u : 0u;                            /* read after the ray walk's barrier */
             /* a tile that writes nothing itself has nothing to hand over: publish at once */
@@ -425,18 +455,13 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
         const float ppv = fmaxf(1.f, (g.fx * g.vs / zf) * (g.fy * g.vs / zf) * 1.1f);
         const float est = n_valid * (float)nk_all / ppv;
         n_pass = est <= 0.8f * FUSE_LCAP ? 1 : (est <= 1.6f * FUSE_LCAP ? 2 : 4);
-        if (a.debug & 256) n_pass = 1;
-        if (a.debug & 512) n_pass = 4;
+        if (GSDF_EXPERIMENT(a.debug, 256)) n_pass = 1;
+        if (GSDF_EXPERIMENT(a.debug, 512)) n_pass = 4;
         if (!(n_valid > 0.f)) n_pass = 1;
         n_pass = __builtin_amdgcn_readfirstlane(n_pass);
-    }
-    /* origin of the tile-local voxel coordinates: the world bounding box of the tile's frustum chunk
-     * (4 corner rays x the two ends of the sampled depth range) minus a margin; a sample whose voxel is not
-     * within 1024 cells of it (huge depth range at tiny voxels) takes the deferred route instead */
-    int ox, oy, oz;
-    {
-        const unsigned int zmin_bits = min(min(L.st_min[0], L.st_min[1]), min(L.st_min[2], L.st_min[3]));
-        const unsigned int zmax_bits = max(max(L.st_max[0], L.st_max[1]), max(L.st_max[2], L.st_max[3]));
+        /* origin of the tile-local voxel coordinates: the world bounding box of the tile's frustum chunk
+         * (4 corner rays x the two ends of the sampled depth range) minus a margin; a sample whose voxel is not
+         * within 1024 cells of it (huge depth range at tiny voxels) takes the deferred route instead */
         const float s_lo = __uint_as_float(zmin_bits) - ((float)g.factor + 1.f) * g.vs;
         const float s_hi = __uint_as_float(zmax_bits) + ((float)g.factor + 1.f) * g.vs;
         float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f };
@@ -450,75 +475,83 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
             mn[2] = fminf(mn[2], fminf(s_lo * d.z, s_hi * d.z));
         }
         const bool any_valid = zmax_bits != 0u;
-        ox = any_valid ? (int)floorf((mn[0] + t[0]) * g.inv_vs) - 3 : 0;
-        oy = any_valid ? (int)floorf((mn[1] + t[1]) * g.inv_vs) - 3 : 0;
-        oz = any_valid ? (int)floorf((mn[2] + t[2]) * g.inv_vs) - 3 : 0;
+        /* clamped so that the integer conversion is defined whatever the pose; a clamped origin fails range_ok */
+        const float lim = 2.0e6f;
+        ox = any_valid ? (int)fminf(lim, fmaxf(-lim, floorf((mn[0] + t[0]) * g.inv_vs))) - 3 : 0;
+        oy = any_valid ? (int)fminf(lim, fmaxf(-lim, floorf((mn[1] + t[1]) * g.inv_vs))) - 3 : 0;
+        oz = any_valid ? (int)fminf(lim, fmaxf(-lim, floorf((mn[2] + t[2]) * g.inv_vs))) - 3 : 0;
         ox = __builtin_amdgcn_readfirstlane(ox); oy = __builtin_amdgcn_readfirstlane(oy); oz = __builtin_amdgcn_readfirstlane(oz);
+        /* every voxel with a local key is packable (21 bits per biased axis): the per-sample range test of the
+         * global key is only needed on the deferred route */
+        range_ok = ox >= -GSDF_KEY_OFF && ox + 1023 < GSDF_KEY_OFF && oy >= -GSDF_KEY_OFF && oy + 1023 < GSDF_KEY_OFF &&
+                   oz >= -GSDF_KEY_OFF && oz + 1023 < GSDF_KEY_OFF;
     }
-    float n_upd = 0.f, n_val = 0.f;
+    unsigned int n_upd_w = 0u, n_val_w = 0u;                          /* wave-uniform counters */
     unsigned int dbg_go = 0u, dbg_full = 0u, dbg_lost = 0u;
     unsigned long long T1 = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
     if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) atomicAdd(&a.st->dbg[4], T1 - T0);
     for (int pass = 0; pass < n_pass; ++pass) {
-    /* lanes -> (pixel of the band, slice of the ray walk).  One band: as loaded above, 2 slices.  Two bands
-     * of 16x8 pixels: 2 waves (8x8 each) per slice, 4 slices.  Four bands of 16x4: 1 wave per slice, 8 slices. */
-    const int per = FUSE_THREADS / (2 * n_pass);
+    /* lanes -> (pixel of the band, slice of the ray walk).  One band: as loaded above, FUSE_ZSPLIT slices.  Two bands
+     * of 16x8 pixels: 2 waves (8x8 each) per slice, twice the slices.  Four bands of 16x4: 1 wave per slice. */
+    const int per = FUSE_THREADS / (FUSE_ZSPLIT * n_pass);
     const int q = tid % per, zs = tid / per;
     const int bx = n_pass == 4 ? (q & 15) : ((q >> 6) & 1) * 8 + (q & 7);
     const int by = n_pass == 4 ? (q >> 4) : (q >> 7) * 8 + ((q >> 3) & 7);
     if (n_pass > 1)
         load_pixel(tile_x * FUSE_T + bx, tile_y * FUSE_T + pass * (FUSE_T / n_pass) + by,
                    L.plane[0], L.plane[1], L.plane[2], L.plane[3], L.plane[4], L.plane[5], L.plane[6]);
-    if (zs == 0 && valid) n_val += 1.f;
+    if (zs == 0) n_val_w += (unsigned int)__popcll(__ballot(valid));  /* zs is the same for a whole wave */
     /* this slice's share of the ray walk k = -factor..factor (:101); the order is free (sums) */
-    const int k_lo = -g.factor + (zs * nk_all) / (2 * n_pass);
-    const int k_hi = -g.factor + ((zs + 1) * nk_all) / (2 * n_pass) - 1;
+    const int k_lo = -g.factor + (zs * nk_all) / (FUSE_ZSPLIT * n_pass);
+    const int k_hi = -g.factor + ((zs + 1) * nk_all) / (FUSE_ZSPLIT * n_pass) - 1;
     const int nk = __builtin_amdgcn_readfirstlane(k_hi - k_lo + 1);       /* the same for the whole wave */
     if (nk > 0 && __any(valid)) {                    /* ~18 % of the 8x8 sub-tiles have no valid pixel at all */
         for (int c0 = 0; c0 < nk; c0 += FUSE_BATCH) {
-            unsigned long long gkey[FUSE_BATCH], q[FUSE_BATCH][5];
             uint32_t key[FUSE_BATCH], bk[FUSE_BATCH];
+            unsigned long long qw[FUSE_BATCH], qs[FUSE_BATCH];
+            int qg[FUSE_BATCH][3];
+            int vox[FUSE_BATCH][3];
             bool act[FUSE_BATCH], local[FUSE_BATCH];
             /* 1. the samples of this batch (the last batch of a walk may be short: wave-uniform skip) */
 #pragma unroll
             for (int j = 0; j < FUSE_BATCH; ++j) {
-                act[j] = false; local[j] = false; key[j] = 0u; gkey[j] = 0ull; bk[j] = 0u;
+                act[j] = false; local[j] = false; key[j] = 0u; bk[j] = 0u;
+                vox[j][0] = vox[j][1] = vox[j][2] = 0;
                 if (c0 + j >= nk) continue;
                 const int kk = k_lo + c0 + j;                          /* wave-uniform */
-                act[j] = valid;
                 const float s = z + (float)kk * g.vs;
                 const float pxw = s * Rxy.x + t[0], pyw = s * Rxy.y + t[1], pzw = s * Rxy.z + t[2];   /* :103 */
-                const int vx = gsdf_float2vox1(g.inv_vs, pxw);             /* :104 */
-                const int vy = gsdf_float2vox1(g.inv_vs, pyw);
-                const int vz = gsdf_float2vox1(g.inv_vs, pzw);
-                const float dx = g.vs * (float)vx - t[0], dy = g.vs * (float)vy - t[1], dz = g.vs * (float)vz - t[2];
+                /* float2vox (:104): std::round; the rounded value is kept as a float too -- (float)vi == the rounded
+                 * float for every index that fits an int, so vox2float needs no second conversion */
+                const float rx = roundf(g.inv_vs * pxw), ry = roundf(g.inv_vs * pyw), rz = roundf(g.inv_vs * pzw);
+                const int vx = (int)rx, vy = (int)ry, vz = (int)rz;
+                const float dx = g.vs * rx - t[0], dy = g.vs * ry - t[1], dz = g.vs * rz - t[2];
                 const float pc_z = gsdf_sum3(R[2] * dx, R[5] * dy, R[8] * dz);   /* :105  (Rt row 2) */
                 const float sdf = pc_z - z;                                /* :106 */
                 const float w = gsdf_weight(sdf, g.T, g.inv_T);            /* :107 */
-                act[j] = act[j] && w > 0.f;
-                /* packable iff every biased coordinate fits 21 bits (same test as gsdf_key_in_range) */
-                const uint32_t ux = (uint32_t)(vx + GSDF_KEY_OFF), uy = (uint32_t)(vy + GSDF_KEY_OFF), uz = (uint32_t)(vz + GSDF_KEY_OFF);
-                if (act[j] && ((ux | uy | uz) >> 21)) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); act[j] = false; }
-                if (act[j]) n_upd += 1.f;
-                gkey[j] = (unsigned long long)ux | ((unsigned long long)uy << 21) | ((unsigned long long)uz << 42);
+                act[j] = valid && w > 0.f;
+                n_upd_w += (unsigned int)__popcll(__ballot(act[j]));
+                vox[j][0] = vx; vox[j][1] = vy; vox[j][2] = vz;
                 /* tile-local key: 10 bits per axis relative to the tile origin */
                 const uint32_t lx3 = (uint32_t)(vx - ox), ly3 = (uint32_t)(vy - oy), lz3 = (uint32_t)(vz - oz);
-                local[j] = ((lx3 | ly3 | lz3) >> 10) == 0u;
+                local[j] = range_ok && ((lx3 | ly3 | lz3) >> 10) == 0u;
                 key[j] = lx3 | (ly3 << 10) | (lz3 << 20);
-                q[j][0] = f2fix(w);
-                q[j][1] = f2fix(w * gsdf_truncate(sdf, g.T));              /* :111 as additive sum */
-                q[j][2] = f2fix(w * Rn.x); q[j][3] = f2fix(w * Rn.y); q[j][4] = f2fix(w * Rn.z);   /* :112 */
+                qw[j] = f2fix(w);
+                qs[j] = f2fix(w * gsdf_truncate(sdf, g.T));                /* :111 as additive sum */
+                qg[j][0] = (int)(w * Rn.x); qg[j][1] = (int)(w * Rn.y); qg[j][2] = (int)(w * Rn.z);   /* :112, 2^-21 (truncating) */
                 /* LDS bucket: a LATTICE hash, not a random one.  A tile's voxels are a compact oblique prism;
-                 * x + 186 y + 234 z (mod 448) sends any two voxels closer than ~8.3 cells to different buckets
+                 * x + 98 y + 143 z (mod 512) sends any two voxels closer than ~8.6 cells to different buckets
                  * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
                  * overflow, and the distinct voxels of one wave instruction never compete for a bucket.
                  * (The HBM table keeps the full 64-bit finaliser.) */
-                static_assert(FUSE_NB == 448, "lattice constants are for 448 buckets");
-                bk[j] = (lx3 + 186u * ly3 + 234u * lz3) % (uint32_t)FUSE_NB;
+                static_assert(FUSE_NB == 512, "lattice constants are for 512 buckets");
+                bk[j] = (lx3 + 98u * ly3 + 143u * lz3) & (uint32_t)(FUSE_NB - 1);
             }
             /* 2.-4. look the voxels up in the LDS table.  All pending samples of the batch advance
-             *    together: bucket (4 keys) = two ds_read_b128, match / first-empty by selects, at most
-             *    one CAS per sample and probe.  Plain LDS reads: a stale EMPTY is resolved by the CAS. */
+             *    together: bucket (4 keys) = one ds_read_b128, match / first-empty by selects, at most
+             *    one CAS per sample and probe.  Plain LDS reads: a stale EMPTY is resolved by the CAS.
+             *    Entries are never removed and inserts take the first empty slot, so the used slots of a
+             *    bucket are a prefix. */
             const int nb = nk - c0 < FUSE_BATCH ? nk - c0 : FUSE_BATCH;   /* wave-uniform */
             int slot[FUSE_BATCH];
             bool pend[FUSE_BATCH];
@@ -548,16 +581,11 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                     if (!go[j]) continue;
                     int hit = kk4[j].w == key[j] ? 3 : -1;
                     hit = kk4[j].z == key[j] ? 2 : hit; hit = kk4[j].y == key[j] ? 1 : hit; hit = kk4[j].x == key[j] ? 0 : hit;
-                    /* first empty slot in a key-dependent rotation: different voxels that meet in one bucket
-                     * in the same instruction go for different slots, so fewer of them lose the CAS */
-                    const uint32_t m = (kk4[j].x == FUSE_LKEY_EMPTY ? 1u : 0u) | (kk4[j].y == FUSE_LKEY_EMPTY ? 2u : 0u) |
-                                       (kk4[j].z == FUSE_LKEY_EMPTY ? 4u : 0u) | (kk4[j].w == FUSE_LKEY_EMPTY ? 8u : 0u);
-                    const uint32_t r = (key[j] ^ (key[j] >> 10) ^ (key[j] >> 20)) & 3u;
-                    const uint32_t mr = ((m | (m << 4)) >> r) & 15u;
-                    const int emp = mr ? (int)((__ffs(mr) - 1 + r) & 3u) : -1;
+                    int emp = kk4[j].w == FUSE_LKEY_EMPTY ? 3 : -1;
+                    emp = kk4[j].z == FUSE_LKEY_EMPTY ? 2 : emp; emp = kk4[j].y == FUSE_LKEY_EMPTY ? 1 : emp; emp = kk4[j].x == FUSE_LKEY_EMPTY ? 0 : emp;
                     if (pend[j] && hit >= 0) { slot[j] = (int)(4 * bk[j]) + hit; pend[j] = false; }
                     cas_at[j] = (pend[j] && emp >= 0) ? (int)(4 * bk[j]) + emp : -1;
-                    if (pend[j] && emp < 0) bk[j] = bk[j] + 1 == FUSE_NB ? 0 : bk[j] + 1;   /* bucket full of others */
+                    if (pend[j] && emp < 0) bk[j] = (bk[j] + 1u) & (uint32_t)(FUSE_NB - 1);   /* bucket full of others */
                     if (GSDF_EXPERIMENT(a.debug, 128) && __any(pend[j] && emp < 0)) ++dbg_full;
                 }
                 uint32_t old[FUSE_BATCH];
@@ -573,22 +601,27 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                 }
                 /* a lost CAS (slot taken by another voxel) re-reads the same bucket in the next probe */
             }
-            /* 5. accumulate (exact 64-bit integer adds) */
+            /* 5. accumulate (integer adds: exact and order-independent) */
 #pragma unroll
             for (int j = 0; j < FUSE_BATCH; ++j) {
                 if (j >= nb || !act[j] || GSDF_EXPERIMENT(a.debug, 2)) continue;
                 if (GSDF_EXPERIMENT(a.debug, 16)) continue;
                 if (slot[j] >= 0) {
-                    atomicAdd(&L.w[slot[j]], q[j][0]);
-                    atomicAdd(&L.s[slot[j]], q[j][1]);
-                    atomicAdd(&L.gx[slot[j]], q[j][2]);
-                    atomicAdd(&L.gy[slot[j]], q[j][3]);
-                    atomicAdd(&L.gz[slot[j]], q[j][4]);
+                    atomicAdd(&L.ws[2 * slot[j]], qw[j]);
+                    atomicAdd(&L.ws[2 * slot[j] + 1], qs[j]);
+                    uint32_t* G = &L.g[3 * slot[j]];
+                    atomicAdd(G + 0, (uint32_t)qg[j][0]);
+                    atomicAdd(G + 1, (uint32_t)qg[j][1]);
+                    atomicAdd(G + 2, (uint32_t)qg[j][2]);
                 } else {
-                    /* LDS table full for this voxel (or voxel outside the local key range): deferred list */
-                    gsdf_payload* p = gsdf_find_or_insert(a.tab, gkey[j]);
+                    /* LDS table full for this voxel, or voxel outside the local key range: deferred list */
+                    if (!gsdf_key_in_range(vox[j][0], vox[j][1], vox[j][2])) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); continue; }
+                    gsdf_payload* p = gsdf_find_or_insert(a.tab, gsdf_key_pack(vox[j][0], vox[j][1], vox[j][2]));
                     if (!p) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
-                    else { defer_append(a, p, fix2f(q[j][0]), fix2f(q[j][1]), fix2f(q[j][2]), fix2f(q[j][3]), fix2f(q[j][4])); vis_mark(a, p, frame_cur); }
+                    else {
+                        defer_append(a, p, fix2f(qw[j]), fix2f(qs[j]), fix2f((uint32_t)qg[j][0]), fix2f((uint32_t)qg[j][1]), fix2f((uint32_t)qg[j][2]));
+                        vis_mark(a, p, frame_cur);
+                    }
                 }
             }
         }
@@ -657,7 +690,8 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                 if (!ok) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(8);
-                if (wall_clock64() - t0 > 200000ull) {                /* 2 ms at 100 MHz: give up, defer instead */
+                /* 2 ms at 100 MHz: give up, defer instead (the test build can make every wait expire at once) */
+                if (wall_clock64() - t0 > 200000ull || GSDF_EXPERIMENT(a.debug, 8192)) {
                     if (lane == 0) { L.ordered = 0u; atomicAdd(&a.st->fuse_timeouts, 1u); }
                     break;
                 }
@@ -685,20 +719,24 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                 asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ra[e]) : "v"(P[e]) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=v"(rb[e]) : "v"(P[e]) : "memory");
             }
-            static_assert(NE == 4, "the wait statement names 4 x 2 destination registers");
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[2]), "+v"(rb[2]), "+v"(ra[3]), "+v"(rb[3])
-                         :: "memory");
+            static_assert(NE == 4 || NE == 2, "the wait statement names NE x 2 destination registers");
+            if constexpr (NE == 4)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[NE - 2]), "+v"(rb[NE - 2]), "+v"(ra[NE - 1]), "+v"(rb[NE - 1])
+                             :: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[NE - 1]), "+v"(rb[NE - 1]) :: "memory");
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 if (ekey[e] == GSDF_KEY_EMPTY) continue;
                 const int i = tid + FUSE_THREADS * e;
+                const uint32_t* G = &L.g[3 * i];
                 gsdf_u32x4 oa, ob;
-                oa.x = __float_as_uint(__uint_as_float(ra[e].x) + fix2f(L.w[i]));
-                oa.y = __float_as_uint(__uint_as_float(ra[e].y) + fix2f(L.s[i]));
-                oa.z = __float_as_uint(__uint_as_float(ra[e].z) + fix2f(L.gx[i]));
-                oa.w = __float_as_uint(__uint_as_float(ra[e].w) + fix2f(L.gy[i]));
-                ob.x = __float_as_uint(__uint_as_float(rb[e].x) + fix2f(L.gz[i]));
+                oa.x = __float_as_uint(__uint_as_float(ra[e].x) + fix2f(L.ws[2 * i]));
+                oa.y = __float_as_uint(__uint_as_float(ra[e].y) + fix2f(L.ws[2 * i + 1]));
+                oa.z = __float_as_uint(__uint_as_float(ra[e].z) + fix2f(G[0]));
+                oa.w = __float_as_uint(__uint_as_float(ra[e].w) + fix2f(G[1]));
+                ob.x = __float_as_uint(__uint_as_float(rb[e].x) + fix2f(G[2]));
                 ob.y = a.tag; ob.z = 0u; ob.w = 0u;
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(P[e]), "v"(oa) : "memory");
                 asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(P[e]), "v"(ob) : "memory");
@@ -734,9 +772,11 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
                     if (key == FUSE_LKEY_EMPTY) continue;
                     const unsigned int o = L.defer_base + atomicAdd(&L.n_defer, 1u);
                     if (o >= a.deferred_cap) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); continue; }
+                    const uint32_t* G = &L.g[3 * i];
                     gsdf_deferred d;
                     d.p = a.tab.vox + (key & ~FUSE_LKEY_DEFER);
-                    d.w = fix2f(L.w[i]); d.s = fix2f(L.s[i]); d.gx = fix2f(L.gx[i]); d.gy = fix2f(L.gy[i]); d.gz = fix2f(L.gz[i]);
+                    d.w = fix2f(L.ws[2 * i]); d.s = fix2f(L.ws[2 * i + 1]);
+                    d.gx = fix2f(G[0]); d.gy = fix2f(G[1]); d.gz = fix2f(G[2]);
                     d.pad = 0u;
                     a.deferred[o] = d;
                 }
@@ -750,27 +790,18 @@ __global__ __launch_bounds__(FUSE_THREADS, 4) void k_fuse(fuse_args a) {   /* 4 
     if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T3 = wall_clock64(); atomicAdd(&a.st->dbg[3], T3 - T1); T1 = T3; }
     if (pass + 1 < n_pass) {                                          /* next band: start from an empty table */
         __syncthreads();
-        for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) {
-            L.key[i] = FUSE_LKEY_EMPTY;
-            L.w[i] = 0ull; L.s[i] = 0ull; L.gx[i] = 0ull; L.gy[i] = 0ull; L.gz[i] = 0ull;
-        }
+        fuse_lds_clear(L, tid);
         if (tid == 0) L.n_defer = 0u;
         __syncthreads();
     }
     }   /* pass */
     /* per-workgroup counters (plain stores into this workgroup's own row: no hot atomics) */
-    const float wu = wave_sum(n_upd), wv = wave_sum(n_val);
-    if (lane == 0) { L.red[wave] = wu; L.red[8 + wave] = wv; }
+    if (lane == 0) { L.cnt[0][wave] = n_upd_w; L.cnt[1][wave] = n_val_w; }
     __syncthreads();
     if (tid == 0) {
-        float su = 0.f;
+        unsigned long long nu = 0ull, nv = 0ull;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) su += L.red[i];
-        const unsigned long long nu = (unsigned long long)su;
-        float sv = 0.f;
-#pragma unroll
-        for (int i = 8; i < 16; ++i) sv += L.red[i];
-        const unsigned long long nv = (unsigned long long)sv;
+        for (int i = 0; i < 4 * FUSE_ZSPLIT; ++i) { nu += L.cnt[0][i]; nv += L.cnt[1][i]; }
         unsigned long long* c = a.blk_counters + 4 * ((size_t)tile_y * a.ntx + tile_x);
         c[0] = nu; c[1] = nv; c[2] += nu; c[3] += nv;
         if (tile_x == 0 && tile_y == 0) a.st->frames += 1;            /* :120 increase_counter() */
@@ -811,10 +842,10 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       int use_dev_pose, gsdf_table tab, gsdf_dev_state* st, unsigned long long* blk_counters,
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
                       unsigned int tag, unsigned int* tile_flags, const uint32_t* tile_order, float* log_rows,
-                      long long max_rows, uint32_t* vis, int vis_words) {
+                      long long max_rows, uint32_t* vis, int vis_words, int debug) {
     fuse_args a;
     a.vis = vis; a.vis_words = vis_words;
-    a.debug = g_fuse_debug;
+    a.debug = debug;
     a.g = g; a.nc = nc; a.depth = depth; a.nx = nx; a.ny = ny; a.nz = nz; a.pose = pose;
     a.use_dev_pose = use_dev_pose; a.tab = tab; a.st = st; a.blk_counters = blk_counters;
     a.deferred = deferred; a.deferred_count = deferred_count; a.deferred_cap = deferred_cap; a.tag = tag;
@@ -822,8 +853,9 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     gsdf_dev_state* gate = use_dev_pose ? st : nullptr;
     a.tile_flags = tile_flags; a.ntx = ntx; a.nty = nty; a.tile_order = tile_order;
     const int n = ntx * nty;
-    hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(g_fuse_debug, 4096) ? 8192 : 0, s, a);   /* experiment: 1 workgroup per CU */
-    hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st,
+    hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(debug, 4096) ? 81920 : 0, s, a);   /* experiment: 1 workgroup per CU */
+    /* the deferred list is normally (almost) empty: a small grid keeps the launch cheap, the stride loop covers long lists */
+    hipLaunchKernelGGL(k_fuse_resolve, dim3(64), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st,
                        use_dev_pose ? log_rows : nullptr, max_rows);
 }
 int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T); }

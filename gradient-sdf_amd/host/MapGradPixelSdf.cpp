@@ -169,15 +169,13 @@ bool MapGradPixelSdf::save_sdf(std::string filename) {
 
 /* extract_mesh -- MapGradPixelSdf.cpp:124-175 -> LayeredMarchingCubesNoColor on the exported map */
 bool MapGradPixelSdf::extract_mesh(std::string filename) {
-    /* marching cubes on the device (gsdf_extract_mesh); MarchingCubes::computeIsoSurface is the host statement of
-     * the same sweep and gives the identical triangle list (host_selftest / tests/test_host.py) */
-    int8_t table[256 * 16];
-    MarchingCubes::fill_table(table);
+    /* marching cubes on the device (gsdf_extract_mesh, tri_table = NULL: the reference's triTable); the triangle list
+     * equals LayeredMarchingCubesNoColor::computeIsoSurface's, in its order (tests/test_gpu_parity.py vs the oracle) */
     int64_t n = 0;
-    check(gsdf_extract_mesh(ctx_, 0.f, table, nullptr, 0, &n), "gsdf_extract_mesh");
+    check(gsdf_extract_mesh(ctx_, 0.f, nullptr, nullptr, 0, &n), "gsdf_extract_mesh");
     if (n <= 0) return false;
     std::vector<float> tris((size_t)n * 9);
-    check(gsdf_extract_mesh(ctx_, 0.f, table, tris.data(), n, &n), "gsdf_extract_mesh");
+    check(gsdf_extract_mesh(ctx_, 0.f, nullptr, tris.data(), n, &n), "gsdf_extract_mesh");
     MarchingCubes mc(voxel_size_);
     mc.setTriangles(tris.data(), (size_t)n);
     return mc.savePly(filename);

@@ -1,4 +1,5 @@
 #include "MarchingCubes.h"
+#include "../../include/gsdf_mc_tables.h"
 
 #include <algorithm>
 #include <cmath>
@@ -12,83 +13,15 @@ namespace {
 const int CORNER[8][3] = { { 1, 1, 0 }, { 1, 0, 0 }, { 0, 0, 0 }, { 0, 1, 0 }, { 1, 1, 1 }, { 1, 0, 1 }, { 0, 0, 1 }, { 0, 1, 1 } };
 /* edge e -> its two corners (the classic numbering: 0-3 bottom ring, 4-7 top ring, 8-11 verticals) */
 const int EDGE[12][2] = { { 0, 1 }, { 1, 2 }, { 2, 3 }, { 3, 0 }, { 4, 5 }, { 5, 6 }, { 6, 7 }, { 7, 4 }, { 0, 4 }, { 1, 5 }, { 2, 6 }, { 3, 7 } };
-/* faces: 4 corners in cyclic order */
-const int FACE[6][4] = { { 0, 1, 2, 3 }, { 4, 5, 6, 7 }, { 0, 1, 5, 4 }, { 1, 2, 6, 5 }, { 2, 3, 7, 6 }, { 3, 0, 4, 7 } };
-
-int edge_between(int a, int b) {
-    for (int e = 0; e < 12; ++e)
-        if ((EDGE[e][0] == a && EDGE[e][1] == b) || (EDGE[e][0] == b && EDGE[e][1] == a)) return e;
-    return -1;
-}
-
+/* The classic case tables (constant data, include/gsdf_mc_tables.h = LayeredMarchingCubesNoColor.cpp:67-352) as
+ * per-case edge lists: the mesh must be the reference's, triangle for triangle. */
 struct Tables {
     std::vector<int> tri[256];
     int mask[256];
     Tables() {
         for (int c = 0; c < 256; ++c) {
-            mask[c] = 0;
-            for (int e = 0; e < 12; ++e)
-                if (((c >> EDGE[e][0]) & 1) != ((c >> EDGE[e][1]) & 1)) mask[c] |= 1 << e;
-            /* contour segments on every face; each crossing edge gets exactly two neighbours */
-            int nb[12][2];
-            for (int e = 0; e < 12; ++e) nb[e][0] = nb[e][1] = -1;
-            auto link = [&](int a, int b) {
-                nb[a][nb[a][0] < 0 ? 0 : 1] = b;
-                nb[b][nb[b][0] < 0 ? 0 : 1] = a;
-            };
-            for (int f = 0; f < 6; ++f) {
-                int s[4], cross[4], n = 0;
-                for (int i = 0; i < 4; ++i) s[i] = (c >> FACE[f][i]) & 1;
-                for (int i = 0; i < 4; ++i) cross[i] = s[i] != s[(i + 1) & 3];     /* edge corner i -> i+1 */
-                for (int i = 0; i < 4; ++i) n += cross[i];
-                auto E = [&](int i) { return edge_between(FACE[f][i & 3], FACE[f][(i + 1) & 3]); };
-                if (n == 2) {
-                    int a = -1, b = -1;
-                    for (int i = 0; i < 4; ++i) if (cross[i]) { if (a < 0) a = i; else b = i; }
-                    link(E(a), E(b));
-                } else if (n == 4) {
-                    /* ambiguous face: cut off the corners that are set (depends on the face's signs only,
-                     * so both cubes sharing the face agree) */
-                    const int p = s[0] ? 0 : 1;                                     /* a set corner */
-                    link(E(p + 3), E(p));
-                    link(E(p + 1), E(p + 2));
-                }
-            }
-            bool used[12] = { false };
-            for (int e0 = 0; e0 < 12; ++e0) {
-                if (!((mask[c] >> e0) & 1) || used[e0]) continue;
-                std::vector<int> loop;
-                int prev = -1, cur = e0;
-                while (cur >= 0 && !used[cur]) {
-                    used[cur] = true;
-                    loop.push_back(cur);
-                    const int nxt = nb[cur][0] != prev ? nb[cur][0] : nb[cur][1];
-                    prev = cur;
-                    cur = nxt;
-                }
-                if (loop.size() < 3) continue;
-                /* orient the loop: normal towards the side of the UNSET corners (tsdf <= iso) */
-                double P[12][3], g[3] = { 0, 0, 0 }, nrm[3] = { 0, 0, 0 };
-                for (size_t i = 0; i < loop.size(); ++i) {
-                    const int a = EDGE[loop[i]][0], b = EDGE[loop[i]][1];
-                    const int set = ((c >> a) & 1) ? a : b, unset = set == a ? b : a;
-                    for (int k = 0; k < 3; ++k) {
-                        P[i][k] = 0.5 * (CORNER[a][k] + CORNER[b][k]);
-                        g[k] += CORNER[unset][k] - CORNER[set][k];
-                    }
-                }
-                for (size_t i = 0; i < loop.size(); ++i) {                          /* Newell */
-                    const double* p = P[i];
-                    const double* q = P[(i + 1) % loop.size()];
-                    nrm[0] += (p[1] - q[1]) * (p[2] + q[2]);
-                    nrm[1] += (p[2] - q[2]) * (p[0] + q[0]);
-                    nrm[2] += (p[0] - q[0]) * (p[1] + q[1]);
-                }
-                if (nrm[0] * g[0] + nrm[1] * g[1] + nrm[2] * g[2] < 0) std::reverse(loop.begin(), loop.end());
-                for (size_t i = 1; i + 1 < loop.size(); ++i) {
-                    tri[c].push_back(loop[0]); tri[c].push_back(loop[i]); tri[c].push_back(loop[i + 1]);
-                }
-            }
+            mask[c] = GSDF_MC_EDGE_TABLE[c];
+            for (int k = 0; k < 16 && GSDF_MC_TRI_TABLE[16 * c + k] >= 0; ++k) tri[c].push_back(GSDF_MC_TRI_TABLE[16 * c + k]);
         }
     }
 };
@@ -188,10 +121,7 @@ void MarchingCubes::setTriangles(const float* tris, size_t n_tris) {
 }
 
 void MarchingCubes::fill_table(int8_t out[256 * 16]) {
-    for (int c = 0; c < 256; ++c) {
-        const std::vector<int>& t = triangles(c);
-        for (int k = 0; k < 16; ++k) out[16 * c + k] = k < (int)t.size() && k < 15 ? (int8_t)t[k] : (int8_t)-1;
-    }
+    for (int i = 0; i < 256 * 16; ++i) out[i] = GSDF_MC_TRI_TABLE[i];
 }
 
 bool MarchingCubes::savePly(const std::string& filename) const {

@@ -7,9 +7,8 @@
  * corner has weight 0; vertices by linear interpolation with the 1e-7 guards and clamped double mu
  * (:642-662); no vertex de-duplication, degenerate triangles dropped (:686-712); ASCII PLY (:721-757).
  *
- * The 256-entry triangle table is GENERATED at start-up (iso-contour loops on the cube faces,
- * fan-triangulated) instead of being typed in: every vertex lies on the same cube edge as with the
- * classic table, only the split of a polygon into triangles / of ambiguous faces may differ.
+ * The case tables are the classic edgeTable / triTable the reference embeds (:67-352), kept as constant data in
+ * include/gsdf_mc_tables.h: the triangle list equals the reference's, triangle for triangle, in its order.
  */
 #ifndef GSDF_HOST_MARCHING_CUBES_H_
 #define GSDF_HOST_MARCHING_CUBES_H_
@@ -28,12 +27,12 @@ public:
     bool computeIsoSurface(const std::vector<int32_t>& keys, const std::vector<float>& payload, float isoValue = 0.f);
     /* the same mesh from triangles computed elsewhere (gsdf_extract_mesh: 9 floats per triangle, sweep order) */
     void setTriangles(const float* tris, size_t n_tris);
-    /* the generated table in the layout gsdf_extract_mesh takes: 256 x 16 edge ids, -1 terminated */
+    /* the classic triTable in the layout gsdf_extract_mesh takes: 256 x 16 edge ids, -1 terminated */
     static void fill_table(int8_t out[256 * 16]);
     bool savePly(const std::string& filename) const;
     const std::vector<Vec3f>& vertices() const { return vertices_; }
     const std::vector<std::array<int, 3>>& faces() const { return faces_; }
-    /* generated tables (exposed for tests) */
+    /* the case tables (exposed for tests) */
     static const std::vector<int>& triangles(int cube_index);   /* edge ids, 3 per triangle */
     static int edge_mask(int cube_index);
 

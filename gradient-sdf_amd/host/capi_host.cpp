@@ -12,12 +12,10 @@ extern "C" {
 
 /* returns the number of faces written, or -1 (marching cubes on the device, gsdf_extract_mesh) */
 long gsdf_host_extract_mesh(gsdf_ctx* ctx, float voxel_size, const char* path) {
-    int8_t table[256 * 16];
-    MarchingCubes::fill_table(table);
     int64_t n = 0;
-    if (gsdf_extract_mesh(ctx, 0.f, table, nullptr, 0, &n) != GSDF_OK || n <= 0) return -1;
+    if (gsdf_extract_mesh(ctx, 0.f, nullptr, nullptr, 0, &n) != GSDF_OK || n <= 0) return -1;
     std::vector<float> tris((size_t)n * 9);
-    if (gsdf_extract_mesh(ctx, 0.f, table, tris.data(), n, &n) != GSDF_OK) return -1;
+    if (gsdf_extract_mesh(ctx, 0.f, nullptr, tris.data(), n, &n) != GSDF_OK) return -1;
     MarchingCubes mc(voxel_size);
     mc.setTriangles(tris.data(), (size_t)n);
     if (!mc.savePly(path)) return -1;

@@ -1,5 +1,5 @@
 /* CPU-only self test of the host-side pieces that need no GPU: PNG round trip, pose parsing,
- * SE3 helpers and the generated marching-cubes tables (watertight sphere).  Run by tests/. */
+ * SE3 helpers and the marching-cubes case tables (watertight sphere).  Run by tests/. */
 #include <cmath>
 #include <cstdio>
 #include <fstream>

@@ -175,10 +175,11 @@ int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[
 
 /* Iso-surface of the map on the device -- LayeredMarchingCubesNoColor::computeIsoSurface + computeLutIndex + interpolate +
  * computeTriangles (mesh/LayeredMarchingCubesNoColor.cpp:354-712), called by MapGradPixelSdf::extract_mesh
- * (MapGradPixelSdf.cpp:124-175).  tri_table: the caller's 256 x 16 triangle table (edge ids, 3 per triangle, -1 ends a
- * row; corner / edge numbering of :599-606).  triangles_out: 9 floats per triangle, in the reference's z-y-x sweep
- * order, no vertex de-duplication, degenerate triangles dropped.  *n_tris = triangles found; call with max_tris = 0
- * to size the buffer. */
+ * (MapGradPixelSdf.cpp:124-175).  tri_table: NULL = the reference's triTable (:96-352, the classic marching-cubes
+ * cases, constant data in include/gsdf_mc_tables.h), which gives the reference's mesh triangle for triangle; or a
+ * caller's 256 x 16 table (edge ids, 3 per triangle, -1 ends a row; corner / edge numbering of :599-606, :410-549).
+ * triangles_out: 9 floats per triangle, in the reference's z-y-x sweep order, no vertex de-duplication, degenerate
+ * triangles dropped.  *n_tris = triangles found; call with max_tris = 0 to size the buffer. */
 int gsdf_extract_mesh(gsdf_ctx* c, float iso, const int8_t tri_table[256 * 16], float* triangles_out, int64_t max_tris,
                       int64_t* n_tris);
 

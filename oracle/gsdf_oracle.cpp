@@ -18,6 +18,7 @@
  *     (OpenCV's float boxFilter accumulates in double: sumType CV_64F).
  */
 #include "gsdf_oracle.h"
+#include "../include/gsdf_mc_tables.h"   /* constant data: the classic marching-cubes case tables */
 
 #include <cmath>
 #include <cstring>
@@ -359,6 +360,162 @@ void gsdfo_export_vis(const gsdfo* o, uint32_t* words, int wpv) {
         for (size_t f = 0; f < b.size() && f < (size_t)wpv * 32; ++f)
             if (b[f]) words[i * wpv + f / 32] |= 1u << (f % 32);
     }
+}
+
+/* test plumbing: replace the map by the given (key, SdfVoxel) pairs, so that the export / query / mesh restatements can
+ * be run on exactly the voxel values another implementation produced (payload = dist, gx, gy, gz, weight) */
+void gsdfo_set_map(gsdfo* o, const int32_t* keys, const float* payload, int64_t n) {
+    o->tsdf_.clear();
+    o->vis_.clear();
+    for (int64_t i = 0; i < n; ++i) {
+        SdfVoxel v;
+        v.dist = payload[5 * i];
+        v.grad[0] = payload[5 * i + 1]; v.grad[1] = payload[5 * i + 2]; v.grad[2] = payload[5 * i + 3];
+        v.weight = payload[5 * i + 4];
+        o->tsdf_[Key{ keys[3 * i], keys[3 * i + 1], keys[3 * i + 2] }] = v;
+    }
+}
+
+/* ---- exports: MapGradPixelSdf::extract_pc and LayeredMarchingCubesNoColor -------------------------------- */
+
+/* MapGradPixelSdf::extract_pc -- MapGradPixelSdf.cpp:177-220.  Rows: x y z nx ny nz; voxels are visited in
+ * (z,y,x) order (the reference's phmap order is unknowable).  rows6 == NULL only counts. */
+int64_t gsdfo_extract_pc(const gsdfo* o, float* rows6) {
+    const float voxel_size_2 = (float)(.5 * o->voxel_size_);                        /* :179 */
+    int64_t n = 0;
+    for (const Key& k : sorted_keys(o)) {
+        const SdfVoxel& v = o->tsdf_.at(k);
+        if (v.weight < 5) continue;                                                 /* :184-185 */
+        const V3 gn = normalized3(V3{ v.grad[0], v.grad[1], v.grad[2] });
+        const V3 g = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };                     /* :186 */
+        const V3 d = { v.dist * g.x, v.dist * g.y, v.dist * g.z };                  /* :187 */
+        if (std::fabs(d.x) < voxel_size_2 && std::fabs(d.y) < voxel_size_2 && std::fabs(d.z) < voxel_size_2) {   /* :188 */
+            if (rows6) {
+                const V3 c = o->vox2float(k);
+                float* r = rows6 + 6 * n;
+                r[0] = c.x - d.x; r[1] = c.y - d.y; r[2] = c.z - d.z;               /* :191 */
+                r[3] = -g.x; r[4] = -g.y; r[5] = -g.z;                              /* :192 */
+            }
+            ++n;
+        }
+    }
+    return n;
+}
+
+namespace {
+/* LayeredMarchingCubesNoColor -- mesh/LayeredMarchingCubesNoColor.cpp:354-712, on the oracle's map.
+ * State and method names follow the reference; the case tables are the constant data of
+ * include/gsdf_mc_tables.h (= :67-352). */
+struct LayeredMC {
+    const gsdfo* o;
+    float vs;
+    int min_[3], dim_[3];
+    float origin_[3];
+    size_t areaXY_;
+    std::vector<float> tsdf_, weights_;
+    std::vector<float> tris;                                  /* 9 floats per face, in emission order */
+
+    /* copyLayer -- :565-587: a missing voxel only clears the weight; its tsdf entry stays stale */
+    void copyLayer(int z) {
+        for (int y = 0; y < dim_[1]; ++y)
+            for (int x = 0; x < dim_[0]; ++x) {
+                const size_t off = ((size_t)(z % 2) * dim_[1] + y) * dim_[0] + x;
+                auto it = o->tsdf_.find(Key{ x + min_[0], y + min_[1], z + min_[2] });
+                if (it != o->tsdf_.end()) { weights_[off] = it->second.weight; tsdf_[off] = it->second.dist; }
+                else weights_[off] = 0;
+            }
+    }
+    /* computeLutIndex -- :593-639 */
+    int computeLutIndex(int i, int j, int k, float iso) const {
+        const size_t offZ = (size_t)(k % 2) * areaXY_, offZp = areaXY_ - offZ, offY = (size_t)dim_[0];
+        const size_t off[8] = { offZ + (j + 1) * offY + (i + 1), offZ + j * offY + (i + 1), offZ + j * offY + i, offZ + (j + 1) * offY + i,
+                                offZp + (j + 1) * offY + (i + 1), offZp + j * offY + (i + 1), offZp + j * offY + i, offZp + (j + 1) * offY + i };
+        for (int c = 0; c < 8; ++c) if (weights_[off[c]] == 0.0f) return 0;
+        int cubeIdx = 0;
+        for (int c = 0; c < 8; ++c) if (tsdf_[off[c]] > iso) cubeIdx |= 1 << c;
+        return cubeIdx;
+    }
+    /* voxelToWorld -- :715-719 */
+    V3 voxelToWorld(int i, int j, int k) const {
+        return V3{ (float)i * vs - origin_[0], (float)j * vs - origin_[1], (float)k * vs - origin_[2] };
+    }
+    /* interpolate -- :642-662 (float differences, double comparisons, double mu) */
+    static V3 interpolate(float tsdf0, float tsdf1, V3 val0, V3 val1, float iso) {
+        if (std::fabs(iso - tsdf0) < 1e-7) return val0;
+        if (std::fabs(iso - tsdf1) < 1e-7) return val1;
+        if (std::fabs(tsdf0 - tsdf1) < 1e-7) return val0;
+        double mu = (iso - tsdf0) / (tsdf1 - tsdf0);
+        if (mu > 1.0) mu = 1.0;
+        else if (mu < 0) mu = 0.0;
+        V3 val;
+        val.x = (float)(val0.x + mu * (val1.x - val0.x));
+        val.y = (float)(val0.y + mu * (val1.y - val0.y));
+        val.z = (float)(val0.z + mu * (val1.z - val0.z));
+        return val;
+    }
+    /* getVertex -- :665-672 */
+    V3 getVertex(int i1, int j1, int k1, int i2, int j2, int k2, float iso) const {
+        const float v1 = tsdf_[(size_t)(k1 % 2) * dim_[0] * dim_[1] + (size_t)j1 * dim_[0] + i1];
+        const float v2 = tsdf_[(size_t)(k2 % 2) * dim_[0] * dim_[1] + (size_t)j2 * dim_[0] + i2];
+        return interpolate(v1, v2, voxelToWorld(i1, j1, k1), voxelToWorld(i2, j2, k2), iso);
+    }
+    /* computeTriangles -- :675-704: no vertex sharing; a face with two equal corners is dropped */
+    void computeTriangles(int cubeIndex, const V3 edgePoints[12]) {
+        const int8_t* t = GSDF_MC_TRI_TABLE + 16 * cubeIndex;
+        auto ne = [](V3 a, V3 b) { return a.x != b.x || a.y != b.y || a.z != b.z; };
+        for (int i = 0; t[i] != -1; i += 3) {
+            const V3 p1 = edgePoints[t[i]], p2 = edgePoints[t[i + 1]], p3 = edgePoints[t[i + 2]];
+            if (ne(p1, p2) && ne(p1, p3) && ne(p2, p3)) {
+                const float f[9] = { p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, p3.x, p3.y, p3.z };
+                tris.insert(tris.end(), f, f + 9);
+            }
+        }
+    }
+    /* computeIsoSurface -- :354-561 */
+    bool computeIsoSurface(float iso) {
+        if (o->tsdf_.empty()) return false;
+        int mx[3];
+        for (int a = 0; a < 3; ++a) { min_[a] = std::numeric_limits<int>::max(); mx[a] = std::numeric_limits<int>::min(); }
+        for (const auto& kv : o->tsdf_) {
+            const int c[3] = { kv.first.x, kv.first.y, kv.first.z };
+            for (int a = 0; a < 3; ++a) { min_[a] = std::min(min_[a], c[a]); mx[a] = std::max(mx[a], c[a]); }
+        }
+        for (int a = 0; a < 3; ++a) { origin_[a] = -(float)min_[a] * vs; dim_[a] = mx[a] - min_[a] + 1; }   /* :376-378 */
+        areaXY_ = (size_t)dim_[0] * dim_[1];
+        tsdf_.assign(2 * areaXY_, 0.f);
+        weights_.assign(2 * areaXY_, 0.f);
+        /* edge e joins corner A[e] to corner B[e] (offsets of :410-549, in that order) */
+        static const int C[8][3] = { { 1, 1, 0 }, { 1, 0, 0 }, { 0, 0, 0 }, { 0, 1, 0 }, { 1, 1, 1 }, { 1, 0, 1 }, { 0, 0, 1 }, { 0, 1, 1 } };
+        static const int A[12] = { 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3 }, B[12] = { 1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7 };
+        V3 edgePoints[12] = {};
+        copyLayer(0);
+        for (int z = 0; z < dim_[2] - 1; ++z) {
+            copyLayer(z + 1);
+            for (int y = 0; y < dim_[1] - 1; ++y)
+                for (int x = 0; x < dim_[0] - 1; ++x) {
+                    const int cubeindex = computeLutIndex(x, y, z, iso);
+                    if (cubeindex == 0 || cubeindex == 255) continue;
+                    for (int e = 0; e < 12; ++e)
+                        if (GSDF_MC_EDGE_TABLE[cubeindex] & (1 << e))
+                            edgePoints[e] = getVertex(x + C[A[e]][0], y + C[A[e]][1], z + C[A[e]][2],
+                                                      x + C[B[e]][0], y + C[B[e]][1], z + C[B[e]][2], iso);
+                    computeTriangles(cubeindex, edgePoints);
+                }
+        }
+        return true;
+    }
+};
+} // namespace
+
+/* MapGradPixelSdf::extract_mesh -- MapGradPixelSdf.cpp:124-175 (lmc.computeIsoSurface(&tsdf_), iso 0 by default).
+ * tris9 == NULL (or max_tris too small) only counts; returns the number of faces. */
+int64_t gsdfo_extract_mesh(const gsdfo* o, float iso, float* tris9, int64_t max_tris) {
+    LayeredMC mc;
+    mc.o = o; mc.vs = o->voxel_size_;
+    if (!mc.computeIsoSurface(iso)) return 0;
+    const int64_t n = (int64_t)(mc.tris.size() / 9);
+    if (tris9 && n <= max_tris) std::memcpy(tris9, mc.tris.data(), mc.tris.size() * sizeof(float));
+    return n;
 }
 
 /* MapGradPixelSdf::weights -- MapGradPixelSdf.h:117-125 */

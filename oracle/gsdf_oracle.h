@@ -61,6 +61,17 @@ void   gsdfo_export(const gsdfo* o, int32_t* keys, float* payload);
 /* vis_ bit-vectors (MapGradPixelSdf.cpp:113-115) as ceil(frames/32) uint32 words per voxel, same order as export */
 void   gsdfo_export_vis(const gsdfo* o, uint32_t* words, int words_per_voxel);
 
+/* test plumbing: replace the map by n (key, SdfVoxel) pairs (keys int32[n][3], payload float[n][5] = dist,gx,gy,gz,weight),
+ * so that the restatements below can run on exactly the voxel values another implementation produced */
+void   gsdfo_set_map(gsdfo* o, const int32_t* keys, const float* payload, int64_t n);
+/* MapGradPixelSdf::extract_pc -- MapGradPixelSdf.cpp:177-220: rows x y z nx ny nz of the voxels with weight >= 5 whose
+ * surface point lies inside the voxel, voxels visited in (z,y,x) order.  rows6 == NULL only counts.  Returns the row count. */
+int64_t gsdfo_extract_pc(const gsdfo* o, float* rows6);
+/* MapGradPixelSdf::extract_mesh -> LayeredMarchingCubesNoColor::computeIsoSurface (mesh/LayeredMarchingCubesNoColor.cpp:
+ * 354-712) with the classic case tables (include/gsdf_mc_tables.h = :67-352): 9 floats per face in the z-y-x sweep
+ * order, no vertex sharing.  Returns the face count; tris9 is filled only when max_tris suffices. */
+int64_t gsdfo_extract_mesh(const gsdfo* o, float iso, float* tris9, int64_t max_tris);
+
 /* MapGradPixelSdf::weights / ::tsdf at n points -- MapGradPixelSdf.h:109-125.
  * w[i]=0 when the voxel is absent (then dist/grad are 0; the reference would throw from .at()). */
 void   gsdfo_query(const gsdfo* o, const float* pts, int64_t n, float* dist, float* grad, float* w);

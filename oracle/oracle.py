@@ -50,6 +50,11 @@ def lib():
         L.gsdfo_export.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp]
         L.gsdfo_export_vis.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
         L.gsdfo_query.argtypes = [C.c_void_p, fp, C.c_int64, fp, fp, fp]
+        L.gsdfo_set_map.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp, C.c_int64]
+        L.gsdfo_extract_pc.restype = C.c_int64
+        L.gsdfo_extract_pc.argtypes = [C.c_void_p, fp]
+        L.gsdfo_extract_mesh.restype = C.c_int64
+        L.gsdfo_extract_mesh.argtypes = [C.c_void_p, C.c_float, fp, C.c_int64]
         L.gsdfo_raycast.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]
         L.gsdfo_track.restype = C.c_int
         L.gsdfo_track.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_float, C.c_float, C.c_int,
@@ -148,6 +153,28 @@ class Oracle:
         n = np.zeros((3, H, W), np.float32)
         self.L.gsdfo_raycast(self.h, _fp(K), _fp(R), _fp(t), W, H, np.float32(zmin), np.float32(zmax), _fp(d), _fp(n))
         return d, n
+
+    def set_map(self, keys, payload):
+        """Replace the map by (keys int32[n,3], payload float32[n,5] = dist,gx,gy,gz,weight) -- test plumbing."""
+        k = np.ascontiguousarray(keys, np.int32).reshape(-1, 3)
+        p = _f32(payload).reshape(-1, 5)
+        self.L.gsdfo_set_map(self.h, k.ctypes.data_as(C.POINTER(C.c_int32)), _fp(p), k.shape[0])
+
+    def extract_pc(self):
+        """MapGradPixelSdf::extract_pc rows (x y z nx ny nz), voxels in (z,y,x) order."""
+        n = int(self.L.gsdfo_extract_pc(self.h, None))
+        rows = np.zeros((n, 6), np.float32)
+        if n:
+            self.L.gsdfo_extract_pc(self.h, _fp(rows))
+        return rows
+
+    def extract_mesh(self, iso=0.0):
+        """LayeredMarchingCubesNoColor::computeIsoSurface: faces [n,3,3] in the reference's sweep order."""
+        n = int(self.L.gsdfo_extract_mesh(self.h, np.float32(iso), None, 0))
+        tris = np.zeros((n, 3, 3), np.float32)
+        if n:
+            self.L.gsdfo_extract_mesh(self.h, np.float32(iso), _fp(tris), n)
+        return tris
 
     def track(self, depth, pose7, iters=25, conv=1e-3, damping=1.0, omp=False):
         """Returns (converged, pose7, iters_used, trace[iters_used,36], hits[iters_used])."""

@@ -29,6 +29,18 @@ def test_library_has_no_hip_runtime_dependency_and_no_torch(pkg):
     assert "libamdhip64" not in out and "torch" not in out and "oracle" not in out
 
 
+def test_debug_switches_only_in_the_test_build(pkg):
+    """The path-forcing / measurement hooks live in libgsdf_test.so; the production library has none."""
+    L = pkg.binding.load()
+    assert not hasattr(L, "gsdf_debug_flags") and b"experiments" not in L.gsdf_version()
+    nm = os.popen("nm -D --defined-only %s" % pkg.binding.LIB_PATH).read()
+    assert "gsdf_debug" not in nm
+    T = pkg.binding.load_test_lib()
+    assert b"experiments" in T.gsdf_version() and hasattr(T, "gsdf_debug_flags")
+    for n in _declared():
+        assert hasattr(T, n), "libgsdf_test.so does not export " + n
+
+
 def test_version_and_error_strings(pkg):
     L = pkg.binding.load()
     assert b"gfx950" in L.gsdf_version()

@@ -11,11 +11,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _mk(pkg, O, kind="spheres", W=160, H=120, vs=0.02, trunc=5, cap=18, seed=1, n=4, **kw):
+def _mk(pkg, O, kind="spheres", W=160, H=120, vs=0.02, trunc=5, cap=18, seed=1, n=4, lib=None, **kw):
     seq = pkg.synth.Sequence(kind, W, H, n_frames=n, seed=seed, **kw)
     vs = np.float32(vs)
     T = np.float32(trunc) * vs
-    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=cap)
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=cap, lib=lib)
     o = O.Oracle(vs, T, W, H, seq.K)
     return seq, g, o
 
@@ -66,31 +66,33 @@ def test_fusion_keys_bit_exact(pkg, O, kind, W, H, vs, trunc):
     g.close()
 
 
-@pytest.mark.parametrize("flags,name", [(4, "every tile defers (near-tile path, float atomics in k_fuse_resolve)"),
+@pytest.mark.parametrize("flags,name", [(0, "test build, nothing forced"),
+                                        (4, "every tile defers (near-tile path, float atomics in k_fuse_resolve)"),
                                         (512, "every tile walked as 4 row bands (far-tile path)"),
                                         (256, "single band only (far tiles overflow the LDS table into the deferred list)"),
-                                        (512 + 4, "4 bands, deferred")])
+                                        (512 + 4, "4 bands, deferred"),
+                                        (8192, "every hand-off wait expires at once (timed-out tiles defer)")])
 def test_fusion_forced_paths_match_oracle(pkg, O, flags, name):
     """The flush has a fast path (ordered tiles, plain read-modify-write handed from tile to tile) and
-    fallbacks chosen per tile from its depth; force each of them on the same input."""
-    seq, g, o = _mk(pkg, O, kind="tum", W=320, H=240, vs=0.01, trunc=10, cap=21, n=3)
-    L = pkg.binding.load()
-    L.gsdf_debug_flags(flags)
+    fallbacks chosen per tile from its depth; force each of them on the same input.  The switches exist only
+    in the test build of the library (libgsdf_test.so, -DGSDF_EXPERIMENTS), per context."""
+    seq, g, o = _mk(pkg, O, kind="tum", W=320, H=240, vs=0.01, trunc=10, cap=21, n=3, lib=pkg.binding.load_test_lib())
+    g.debug_flags(flags)
     nu = nv = 0
-    try:
-        for i in range(seq.n):
-            d, R, t = seq.frame(i)
-            g.update(d, R, t)
-            a, b = o.update(d, R, t)
-            nu += a; nv += b
-        g.sync()
-    finally:
-        L.gsdf_debug_flags(0)
+    for i in range(seq.n):
+        d, R, t = seq.frame(i)
+        g.update(d, R, t)
+        a, b = o.update(d, R, t)
+        nu += a; nv += b
+    g.sync()
     assert _cmp_tables(g, o) > 10000
     st = g.stats()
     assert st["n_upd"] == nu and st["n_valid"] == nv                          # every sample and pixel counted exactly once
-    assert st["fuse_timeouts"] == 0
-    assert (st["n_deferred"] > 10000) == bool(flags & 4) or flags == 256      # only the forced-deferred runs defer wholesale
+    if flags == 8192:
+        assert st["fuse_timeouts"] > 100 and st["n_deferred"] > 10000         # the timed-out tiles took the deferred route
+    else:
+        assert st["fuse_timeouts"] == 0
+        assert (st["n_deferred"] > 10000) == bool(flags & 4) or flags == 256  # only the forced-deferred runs defer wholesale
     g.close()
 
 
@@ -102,18 +104,16 @@ def test_fusion_handoff_loses_nothing_at_full_size(pkg):
     W, H, n = 640, 480, 24
     seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=3)
     vs = np.float32(0.01); T = np.float32(10) * vs
-    L = pkg.binding.load()
     out, stats = [], []
     for flags in (0, 4):
-        g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=22)
-        L.gsdf_debug_flags(flags)
-        try:
-            for i in range(n):
-                d, R, t = seq.frame(i)
-                g.update(d, R, t)
-            g.sync()
-        finally:
-            L.gsdf_debug_flags(0)
+        # the production library for the fast path, the test build with every tile deferring for the other
+        g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=22, lib=pkg.binding.load_test_lib() if flags else None)
+        if flags:
+            g.debug_flags(flags)
+        for i in range(n):
+            d, R, t = seq.frame(i)
+            g.update(d, R, t)
+        g.sync()
         out.append(g.export(sorted=True, raw=True))
         stats.append(g.stats())
         g.close()

@@ -10,13 +10,10 @@ W, H = 640, 480
 seq = pkg.synth.Sequence(kind, W, H, n_frames=n, seed=0)
 vs = np.float32(0.01); T = np.float32(10) * vs
 frames = [seq.frame(i) for i in range(n)]
-g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=22)
-L = pkg.binding.load()
+L = pkg.binding.load_test_lib()          # the -DGSDF_EXPERIMENTS build (libgsdf_test.so)
+g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=22, lib=L)
 import ctypes as _ct
 L.gsdf_version.restype = _ct.c_char_p
-if b"experiments" not in L.gsdf_version():
-    print("NOTE: libgsdf.so was built without the measurement switches; rebuild with `make -C gradient-sdf_amd/csrc -B EXPERIMENTS=1`"
-          " (and plain `make -B` afterwards) or every variant below measures the full kernel")
 dev = [g.upload(f[0]) for f in frames]
 names = {0: "full", 1: "no flush", 2: "no LDS accumulate (flush empty)", 3: "compute only", 4: "flush: probe only",
          8: "flush: plain RMW", 17: "no flush, no overflow-to-HBM", 65: "no flush, count overflows", 16: "no overflow-to-HBM",
@@ -26,7 +23,7 @@ names[256] = 'full, single band forced'; names[512] = 'full, 4 bands forced'
 names[1024] = 'band limit 0.9'; names[2048] = 'band limit 1.1'
 names[4096] = 'full, 1 workgroup per CU'; names[4097] = 'no flush, 1 workgroup per CU'; names[4099] = 'compute only, 1 workgroup per CU'
 for flags in (0, 1, 17, 33, 3, 4096, 0):
-    L.gsdf_debug_flags(flags)
+    g.debug_flags(flags)
     g.reset()
     for rep in range(2):
         g.profile(1)
@@ -40,5 +37,4 @@ for flags in (0, 1, 17, 33, 3, 4096, 0):
         g.profile(0)
         print("flags=%d %-34s rep%d fusion %.1f us/frame  normals %.1f us" % (flags, names[flags], rep,
               pr["fusion"]["ms"] / n * 1e3, pr["normals"]["ms"] / n * 1e3))
-L.gsdf_debug_flags(0)
 g.close()

@@ -9,16 +9,10 @@ W, H = 640, 480
 seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=0)
 vs = np.float32(float(sys.argv[1]) if len(sys.argv) > 1 else 0.005); T = np.float32(10) * vs
 frames = [seq.frame(i) for i in range(n)]
-g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=25)
-L = pkg.binding.load()
-import ctypes as _ct
-L.gsdf_version.restype = _ct.c_char_p
-if b"experiments" not in L.gsdf_version():
-    print("NOTE: libgsdf.so was built without the measurement switches; rebuild with `make -C gradient-sdf_amd/csrc -B EXPERIMENTS=1`"
-          " (and plain `make -B` afterwards) or every variant below measures the full kernel")
+g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=25, lib=pkg.binding.load_test_lib())   # -DGSDF_EXPERIMENTS build
 dev = [g.upload(f[0]) for f in frames]
 for flags in (0, 256, 512, 0):
-    L.gsdf_debug_flags(flags)
+    g.debug_flags(flags)
     g.reset()
     for rep in range(2):
         g.profile(1)
@@ -28,5 +22,4 @@ for flags in (0, 256, 512, 0):
         pr = g.profile_read()
         g.profile(0)
         print("vs=%.4f flags=%d rep%d fusion %.1f us/frame voxels %d" % (vs, flags, rep, pr["fusion"]["ms"] / n * 1e3, g.count()))
-L.gsdf_debug_flags(0)
 g.close()

@@ -1,20 +1,15 @@
 import sys, os
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as G
 pkg = G.package()
 n = 12
 seq = pkg.synth.Sequence("tum", 640, 480, n_frames=n, seed=0)
 vs = np.float32(0.01); T = np.float32(10) * vs
 frames = [seq.frame(i) for i in range(n)]
-g = pkg.GradSdf(vs, T, 640, 480, seq.K, capacity_log2=22)
-L = pkg.binding.load()
-import ctypes as _ct
-L.gsdf_version.restype = _ct.c_char_p
-if b"experiments" not in L.gsdf_version():
-    print("NOTE: libgsdf.so was built without the measurement switches; rebuild with `make -C gradient-sdf_amd/csrc -B EXPERIMENTS=1`"
-          " (and plain `make -B` afterwards) or every variant below measures the full kernel")
-L.gsdf_debug_flags(128)
+L = pkg.binding.load_test_lib()          # -DGSDF_EXPERIMENTS build
+g = pkg.GradSdf(vs, T, 640, 480, seq.K, capacity_log2=22, lib=L)
+g.debug_flags(128)
 dev = [g.upload(f[0]) for f in frames]
 import ctypes
 def rd():
@@ -40,5 +35,4 @@ print("wave-level events per frame: bucket full", out[0] / n, "CAS lost", out[1]
 wg = 1200.0 * n
 print("mean per workgroup (us): prologue %.2f  ray walk %.2f  flush %.2f" % (out[4] / wg / 100.0, out[2] / wg / 100.0, out[3] / wg / 100.0))
 print("n_upd/frame", st["n_upd"] / n, "voxels", g.count())
-L.gsdf_debug_flags(0)
 g.close()

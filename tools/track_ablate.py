@@ -9,18 +9,12 @@ n = 12
 seq = pkg.synth.Sequence("tum", 640, 480, n_frames=n, seed=0)
 vs = np.float32(0.01); T = np.float32(10) * vs
 frames = [seq.frame(i) for i in range(n)]
-g = pkg.GradSdf(vs, T, 640, 480, seq.K, capacity_log2=22)
-L = pkg.binding.load()
-import ctypes as _ct
-L.gsdf_version.restype = _ct.c_char_p
-if b"experiments" not in L.gsdf_version():
-    print("NOTE: libgsdf.so was built without the measurement switches; rebuild with `make -C gradient-sdf_amd/csrc -B EXPERIMENTS=1`"
-          " (and plain `make -B` afterwards) or every variant below measures the full kernel")
+g = pkg.GradSdf(vs, T, 640, 480, seq.K, capacity_log2=22, lib=pkg.binding.load_test_lib())   # -DGSDF_EXPERIMENTS build
 for i in range(6):
     g.update(frames[i][0], frames[i][1], frames[i][2])
 q = pkg.synth.R_to_quat_np(frames[6][1]).astype(np.float32)
 pose = np.concatenate([frames[6][2], q]).astype(np.float32)
-L.gsdf_debug_flags(flags << 8)
+g.debug_flags(flags << 16)
 import time
 g.sync()
 t0 = time.perf_counter()
@@ -28,5 +22,4 @@ for r in range(20):
     conv, p, passes = g.track(frames[6][0], pose, iters=25)
 t1 = time.perf_counter()
 print("flags", flags, "conv", conv, "passes", passes, "ms per optimize()", (t1 - t0) / 20 * 1e3, "us per pass", (t1 - t0) / 20 / max(passes, 1) * 1e6)
-L.gsdf_debug_flags(0)
 g.close()
