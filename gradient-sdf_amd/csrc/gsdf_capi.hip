@@ -61,6 +61,7 @@ struct gsdf_ctx {
     int fuse_blocks = 0;
     gsdf_deferred* deferred = nullptr;
     unsigned int* deferred_count = nullptr;
+    unsigned int* fuse_ticket = nullptr;           /* arrivals of finished k_fuse workgroups (reset by the last one) */
     unsigned int deferred_cap = 0;
     unsigned int fuse_tag = 0;                     /* serial of the last fusion launch */
     unsigned int* tile_flags = nullptr;            /* per-tile hand-off flags of k_fuse */
@@ -80,7 +81,8 @@ struct gsdf_ctx {
     unsigned int track_serial = 0;                 /* optimize() call counter */
     volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */
     unsigned int* progress_dev = nullptr;
-    int adaptive = 1;                              /* issue tracker passes only as far as the device needs */
+    int adaptive = 1;                              /* issue tracker passes in batches, following the device (see enqueue_track) */
+    int first_batch = 5, next_batch = 4;           /* launches per batch: 5 cover the usual <= 4 passes + their last head */
     int debug = 0;                                 /* path-forcing / measurement switches (gsdf_debug_flags; test build only) */
     float* frame_log = nullptr;
     long long frame_log_cap = 0;
@@ -158,14 +160,15 @@ int require_frame(gsdf_ctx* c) {
     return GSDF_OK;
 }
 
-int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose) {
+/* normals_done: the frame's normals were computed beside its first tracker pass (enqueue_track) */
+int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done) {
     const size_t N = (size_t)c->W * c->H;
     const gsdf_frame_geom g = c->geom();
     const gsdf_ncache nc = c->ncache();
-    {
+    if (!normals_done) {
         prof_scope ps(c, 0);
         gsdf_launch_normals(c->stream, g, c->win, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N,
-                            use_dev_pose ? c->st : nullptr, c->deferred_count, c->st);
+                            c->deferred_count, c->st);
     }
     {
         prof_scope ps(c, 1);
@@ -177,55 +180,96 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
         gsdf_launch_fuse(c->stream, g, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N, pose,
                          use_dev_pose, c->tab, c->st, c->blk_counters, c->deferred, c->deferred_count,
                          c->deferred_cap, c->fuse_tag, c->tile_flags, c->tile_order, c->frame_log, c->frame_log_cap, c->vis, c->vis_words,
-                         c->debug & 0xFFFF);
+                         c->debug & 0xFFFF, c->fuse_ticket,
+                         /* long deferred lists lately (the note lags by a launch or two: a hint, not a condition) */
+                         c->progress && c->progress[2] > 8192u ? 1 : 0, c->progress ? c->progress_dev + 2 : nullptr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
     return GSDF_OK;
 }
 
-/* RigidPointOptimizer::optimize_sampled as a chain of per-pass launches.  The convergence test,
- * the pose update and the done/converged flags live on the device; launches after `done` return
- * immediately.  To avoid queueing all num_iterations launches (an empty launch still costs ~4 us
- * on the stream), the host follows the device through two pinned words the pass epilogue writes and
- * stays at most GSDF_AHEAD passes ahead; correctness never depends on what the host sees. */
-#define GSDF_AHEAD 3
-int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, float damping) {
+/* RigidPointOptimizer::optimize_sampled as a chain of per-pass launches.  The convergence test, the pose update
+ * and the done/converged flags live on the device; launches after `done` return immediately.  Launch k > 0
+ * first finishes pass k-1 (reduce, solve, update: the "head"), launch `iters` is head-only.
+ *
+ * The host issues the launches in BATCHES and never waits in the common case: the first batch covers the usual
+ * 3-4 passes; behind every batch it queues the frame's fusion (fuse_after: the Scan3D loop body), which is gated
+ * on the device by done && converged, so it runs exactly once -- behind the batch in which optimize() ended.
+ * While that batch (and the fusion) execute, the host follows one pinned word the pass heads write (serial,
+ * done, passes) and only issues a further batch if the optimisation has not ended by the last head of the
+ * previous one.  Correctness never depends on what the host sees: a late or lost observation only costs empty
+ * launches. */
+int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done);
+
+/* 1 = optimize() ended, 0 = the head of launch `last` ran and it has not ended, -1 = gave up waiting */
+int follow_progress(gsdf_ctx* c, unsigned int serial, int last) {
+    for (long spin = 0; spin < 200000000L; ++spin) {
+        const unsigned int w = c->progress[0];
+        if ((w >> 16) == serial) {
+            if (w & 0x8000u) return 1;
+            if ((int)(w & 0x7FFFu) >= last) return 0;
+        }
+        __builtin_ia32_pause();
+    }
+    return -1;
+}
+
+int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, float damping, bool fuse_after) {
     const gsdf_frame_geom g = c->geom();
+    gsdf_pose_arg unused;
+    std::memset(&unused, 0, sizeof(unused));
     if (iters <= 0) {
         gsdf_launch_track_none(c->stream, c->st);
-        return GSDF_OK;
+        return fuse_after ? enqueue_fuse(c, depth_dev, unused, 1, false) : GSDF_OK;
+    }
+    if (iters > 0x7FFF) return fail(GSDF_ERR_INVALID, "num_iterations must be <= 32767");
+    gsdf_normals_job nj;
+    if (fuse_after) {                    /* the frame's normals ride along with its first pass */
+        const size_t N = (size_t)c->W * c->H;
+        nj.nc = c->ncache();
+        nj.nx = c->normals; nj.ny = c->normals + N; nj.nz = c->normals + 2 * N;
+        nj.deferred_count = c->deferred_count;
+        nj.r = c->win / 2; nj.ntx = 0;
     }
     gsdf_track_params tp;
     tp.max_passes = iters;
     tp.conv_sq = conv * conv;                                /* RigidOptimizer.h:72 */
     tp.damping = damping;
-    tp.serial = (++c->track_serial) & 0xFFFFFFu;
-    if (tp.serial == 0) tp.serial = c->track_serial = 1;
+    c->track_serial = (c->track_serial + 1u) & 0xFFFFu;
+    if (c->track_serial == 0) c->track_serial = 1;
+    tp.serial = c->track_serial;
     const bool adaptive = c->adaptive && c->progress;
     tp.progress = adaptive ? c->progress_dev : nullptr;
     tp.debug = c->debug >> 16;
-    /* launches 0..iters-1 gather; launch k>0 first finishes pass k-1 (reduce, solve, update); launch
-     * `iters` is head-only and finishes the last pass */
-    for (int k = 0; k <= iters; ++k) {
-        if (adaptive && c->progress[1] == tp.serial) break;  /* device finished this optimize() */
-        tp.pass_index = k;
-        tp.rot = c->track_rot;
-        c->track_rot = (c->track_rot + 1u) % 3u;              /* kept in [0, 3): no discontinuity at wrap-around */
-        {
+    tp.n_track_blocks = c->track_blocks;
+    int k = 0;
+    int batch = adaptive ? c->first_batch : iters + 1;
+    while (k <= iters) {
+        const int last = std::min(iters, k + batch - 1);
+        for (; k <= last; ++k) {
+            tp.pass_index = k;
+            tp.rot = c->track_rot;
+            c->track_rot = (c->track_rot + 1u) % 3u;          /* kept in [0, 3): no discontinuity at wrap-around */
             prof_scope ps(c, 2);
-            gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks, tp);
+            gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks, tp,
+                                   fuse_after && k == 0 ? &nj : nullptr);
         }
-        if (adaptive && k + 1 >= GSDF_AHEAD) {
-            /* throttle: wait until the device is within GSDF_AHEAD passes (bounded spin) */
-            for (long spin = 0; spin < 20000000L; ++spin) {
-                if (c->progress[1] == tp.serial) break;
-                const unsigned int pr = c->progress[0];
-                const int done_passes = (pr >> 8) == tp.serial ? (int)(pr & 0xFFu) : 0;
-                if (k + 1 - done_passes < GSDF_AHEAD) break;
-                __builtin_ia32_pause();
-            }
+        if (fuse_after) {
+            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true);           /* main_scan_3d.cpp:261-265 */
+            if (rc) return rc;
         }
+        if (last == iters) break;                            /* the head-only launch always ends optimize() */
+        int ended = follow_progress(c, tp.serial, last);
+        if (ended < 0) {                                     /* the device is far behind: wait for it properly */
+            gsdf_dev_state s;
+            if (hipMemcpyAsync(&s, c->st, sizeof(s), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess)
+                return fail(GSDF_ERR_HIP, "tracking: device state read failed");
+            ended = s.done;
+        }
+        if (ended) break;
+        batch = c->next_batch;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("tracking launch: ") + hipGetErrorString(e));
@@ -252,12 +296,12 @@ int gsdf_debug_flags(gsdf_ctx* c, int flags) {
     c->debug = flags;
     return GSDF_OK;
 }
-int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[8]) {
+int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[24]) {
     if (!c || !out) return GSDF_ERR_INVALID;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
     gsdf_dev_state h;
     if (hipMemcpy(&h, c->st, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
-    for (int i = 0; i < 8; ++i) out[i] = h.dbg[i];
+    for (int i = 0; i < 24; ++i) out[i] = h.dbg[i];
     return GSDF_OK;
 }
 const char* gsdf_version(void) { return "gsdf-mi355x 0.2 (gfx950) +experiments"; }
@@ -309,6 +353,8 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         (void)hipGetLastError();
         const char* env = getenv("GSDF_ADAPTIVE");
         if (env) c->adaptive = atoi(env);
+        if ((env = getenv("GSDF_FIRST_BATCH")) && atoi(env) >= 2) c->first_batch = atoi(env);
+        if ((env = getenv("GSDF_NEXT_BATCH")) && atoi(env) >= 1) c->next_batch = atoi(env);
     }
     int rc = gsdf_reset(c);
     if (rc != GSDF_OK) { gsdf_destroy(c); return rc; }
@@ -323,7 +369,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     void* ptrs[] = { c->tab.vox, c->tab.bkeys, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
-                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
+                     c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->progress) (void)hipHostFree((void*)c->progress);
@@ -360,11 +406,11 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     void* old[] = { c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log, c->deferred,
-                    c->deferred_count, c->tile_flags, c->tile_order };
+                    c->deferred_count, c->tile_flags, c->tile_order, c->fuse_ticket };
     for (void* p : old) if (p) (void)hipFree(p);
     c->tile_flags = nullptr; c->tile_order = nullptr;
     c->planes = c->depth_stage = c->normals = nullptr; c->partials = nullptr;
-    c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr;
+    c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr; c->fuse_ticket = nullptr;
     c->W = W; c->H = H; c->win = win;
     std::memcpy(c->K, K, 9 * sizeof(float));
     const size_t N = (size_t)W * H;
@@ -394,6 +440,8 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipMalloc((void**)&c->deferred, (size_t)c->deferred_cap * sizeof(gsdf_deferred)));
     HIP_TRY(hipMalloc((void**)&c->deferred_count, sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(c->deferred_count, 0, sizeof(unsigned int), c->stream));
+    HIP_TRY(hipMalloc((void**)&c->fuse_ticket, sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(c->fuse_ticket, 0, sizeof(unsigned int), c->stream));
     c->frame_log_cap = 1 << 16;
     HIP_TRY(hipMalloc((void**)&c->frame_log, (size_t)c->frame_log_cap * 10 * sizeof(float)));
     gsdf_launch_normals_cache(c->stream, W, H, c->K, win, c->planes);
@@ -418,7 +466,7 @@ int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float*
     const size_t N = (size_t)c->W * c->H;
     HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), c->depth_stage, c->normals, c->normals + N,
-                        c->normals + 2 * N, nullptr, nullptr, nullptr);
+                        c->normals + 2 * N, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(nx, c->normals, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(ny, c->normals + N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -435,7 +483,7 @@ int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const
     gsdf_pose_arg pose;
     std::memcpy(pose.R, R, sizeof(pose.R));
     std::memcpy(pose.t, t, sizeof(pose.t));
-    return enqueue_fuse(c, depth_dev, pose, 0);
+    return enqueue_fuse(c, depth_dev, pose, 0, false);
 }
 
 int gsdf_update(gsdf_ctx* c, const float* depth_host, const float R[9], const float t[3]) {
@@ -477,7 +525,7 @@ int gsdf_track(gsdf_ctx* c, const float* depth_host, const float K[9], float pos
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, (size_t)c->W * c->H * sizeof(float), hipMemcpyHostToDevice, c->stream));
     gsdf_launch_set_pose(c->stream, c->st, nullptr, pose7);
-    rc = enqueue_track(c, c->depth_stage, num_iterations, conv_threshold, damping);
+    rc = enqueue_track(c, c->depth_stage, num_iterations, conv_threshold, damping, false);
     if (rc) return rc;
     gsdf_dev_state s;
     rc = read_state(c, &s);
@@ -496,11 +544,7 @@ int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9
     if (std::memcmp(K, c->K, 9 * sizeof(float)) != 0)
         return fail(GSDF_ERR_INVALID, "K differs from the intrinsics given to gsdf_normals_init");
     HIP_TRY(hipSetDevice(c->device));
-    rc = enqueue_track(c, depth_dev, num_iterations, conv_threshold, damping);    /* main_scan_3d.cpp:258 */
-    if (rc) return rc;
-    gsdf_pose_arg unused;
-    std::memset(&unused, 0, sizeof(unused));
-    rc = enqueue_fuse(c, depth_dev, unused, 1);                                   /* :261-265 */
+    rc = enqueue_track(c, depth_dev, num_iterations, conv_threshold, damping, true);   /* main_scan_3d.cpp:258-265 */
     if (rc) return rc;
     HIP_TRY(hipGetLastError());                                                   /* log row: written by k_fuse_resolve */
     return GSDF_OK;

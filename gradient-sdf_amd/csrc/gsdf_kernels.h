@@ -37,23 +37,23 @@ struct gsdf_trk_buf {
 struct gsdf_dev_state {
     float pose7[7];               /* tx ty tz qx qy qz qw */
     float R[9];                   /* rotationMatrix() of pose7, kept in step by whoever writes pose7 */
-    int done;                     /* pass kernels return immediately once set */
+    int done;                     /* the running / last optimize() has ended (published with `converged` by the pass heads) */
     int converged;
     int passes;
     int max_passes;
     unsigned int fuse_timeouts;   /* fusion tiles whose bounded wait for a neighbour expired (they deferred instead) */
+    unsigned int last_deferred;   /* length of the deferred list of the last fusion launch */
     float last_hits;
     float conv_sq;
     float damping;
     int status;                   /* GSDF_STATUS_* bits, sticky */
-    int pad0;
     unsigned long long n_upd, n_valid, n_hit, n_occupied;
     unsigned long long n_deferred; /* contributions added by k_fuse_resolve so far */
     long long frames;             /* Sdf::counter_ */
     long long log_rows;
     long long frame_cur;          /* counter_ snapshot for the running update (k_normals -> k_fuse) */
     gsdf_trk_buf trk[2];
-    unsigned long long dbg[8];    /* experiment counters (gsdf_debug_flags & 128), see tools/go_count.py */
+    unsigned long long dbg[24];   /* experiment counters (gsdf_debug_flags & 128), see tools/go_count.py */
 };
 
 struct gsdf_frame_geom {
@@ -81,7 +81,6 @@ void gsdf_launch_table_clear(hipStream_t s, gsdf_table tab, size_t n_slots);
 void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int win, float* planes11);
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
                          const float* depth, float* nx, float* ny, float* nz,
-                         const gsdf_dev_state* gate /* nullable: skip unless converged */,
                          unsigned int* deferred_count /* nullable: cleared for the k_fuse that follows */,
                          gsdf_dev_state* st_rw /* nullable: snapshot of the frame counter for k_fuse */);
 /* use_dev_pose: take R,t from st->R / st->pose7 and skip the launch unless st->converged */
@@ -95,7 +94,10 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       const uint32_t* tile_order /* [gsdf_fuse_grid_blocks] from gsdf_fuse_tile_order, on the device */,
                       float* log_rows /* nullable: frame log, written when use_dev_pose */, long long max_rows,
                       uint32_t* vis /* nullable: per-voxel frame bit-vectors */, int vis_words,
-                      int debug /* path-forcing / measurement switches, honoured by -DGSDF_EXPERIMENTS builds only */);
+                      int debug /* path-forcing / measurement switches, honoured by -DGSDF_EXPERIMENTS builds only */,
+                      unsigned int* ticket /* device word, zeroed once: arrivals of finished workgroups */,
+                      int resolve_follows /* also queue k_fuse_resolve (long deferred lists) */,
+                      unsigned int* host_note /* nullable pinned host word: receives the length of the deferred list */);
 int  gsdf_fuse_grid_blocks(int W, int H);
 void gsdf_fuse_tile_order(int W, int H, uint32_t* order_host /* [gsdf_fuse_grid_blocks] */);
 /* per-launch parameters of one Gauss-Newton pass (RigidOptimizer.h:57-62) */
@@ -103,14 +105,22 @@ struct gsdf_track_params {
     int pass_index, max_passes;
     float conv_sq, damping;
     unsigned int serial;          /* optimize() call number, for the host progress words */
-    unsigned int* progress;       /* pinned host memory: [0] = serial<<8 | passes, [1] = serial when done; nullable */
+    unsigned int* progress;       /* pinned host word: serial << 16 | done << 15 | passes, written by every pass head; nullable */
     int debug;                    /* experiment switches (gsdf_debug_flags >> 8); 0 in production */
     unsigned int rot;             /* tracker launches issued on this context so far, mod 3: selects the sum buffers */
+    int n_track_blocks;           /* workgroups of the pass itself (set by the launcher); further ones compute normals tiles */
+};
+/* NormalEstimator::compute of the frame being tracked, run by extra workgroups of its first pass (Scan3D loop) */
+struct gsdf_normals_job {
+    gsdf_ncache nc;
+    float *nx, *ny, *nz;
+    unsigned int* deferred_count; /* cleared for the k_fuse of this frame */
+    int r, ntx;                   /* window radius; tiles per image row (set by the launcher) */
 };
 void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st);
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
                             gsdf_dev_state* st, double* partials /* 3 * GSDF_TRACK_ROWSET, zeroed */, int n_blocks,
-                            const gsdf_track_params& tp);
+                            const gsdf_track_params& tp, const gsdf_normals_job* normals /* nullable */);
 void gsdf_launch_set_pose(hipStream_t s, gsdf_dev_state* st, const float* pose7_dev_or_null,
                           const float pose7_host[7]);
 void gsdf_launch_export(hipStream_t s, gsdf_table tab, size_t n_slots, unsigned long long* keys_out,

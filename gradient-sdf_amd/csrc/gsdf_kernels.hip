@@ -25,6 +25,7 @@
 #include "gsdf_math.h"
 
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <vector>
 
 #define FULL_MASK 0xFFFFFFFFFFFFFFFFull
@@ -143,49 +144,47 @@ void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int 
 }
 
 /* ------------------------------------------------------------------------------------------------
- * NormalEstimator::compute.  32x8 output tile per workgroup; the depth tile + halo is staged
+ * NormalEstimator::compute.  32x16 output tile per 512-thread workgroup; the depth tile + halo is staged
  * through LDS as the three products {x0,y0,1}/n^2 * 1/z, row sums in double in LDS, then the
- * column sums, Q*b and the normalisation in registers.
+ * column sums, Q*b and the normalisation in registers.  One tile function, two callers: k_normals
+ * (GT-pose fusion, gsdf_normals_compute) and the extra workgroups of the first tracker pass of a frame
+ * (k_track_pass: the normals depend on the depth only, so they are computed beside the latency-bound
+ * pose iteration instead of after it).
  * ---------------------------------------------------------------------------------------------- */
 #define NRM_TX 32
-#define NRM_TY 8
+#define NRM_TY 16
+#define NRM_THREADS 512
 #define NRM_RMAX 7
-__global__ __launch_bounds__(256) void k_normals(gsdf_frame_geom g, int r, gsdf_ncache nc,
-                                                 const float* __restrict__ depth, float* __restrict__ nx,
-                                                 float* __restrict__ ny, float* __restrict__ nz,
-                                                 const gsdf_dev_state* gate, unsigned int* deferred_count,
-                                                 gsdf_dev_state* st_rw) {
-    if (gate && !gate->converged) return;
-    if (deferred_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        *deferred_count = 0u;                                  /* fresh list for k_fuse */
-        if (st_rw) st_rw->frame_cur = st_rw->frames;           /* counter_ seen by every workgroup of k_fuse */
-    }
-    __shared__ float prod[3][NRM_TY + 2 * NRM_RMAX][NRM_TX + 2 * NRM_RMAX + 1];
-    __shared__ double rows[3][NRM_TY + 2 * NRM_RMAX][NRM_TX];
-    const int W = g.W, H = g.H;
-    const int tx0 = blockIdx.x * NRM_TX, ty0 = blockIdx.y * NRM_TY;
+struct nrm_lds {
+    float prod[3][NRM_TY + 2 * NRM_RMAX][NRM_TX + 2 * NRM_RMAX + 1];
+    double rows[3][NRM_TY + 2 * NRM_RMAX][NRM_TX];
+};
+__device__ __forceinline__ void normals_tile(nrm_lds& S, int tile_x, int tile_y, int W, int H, int r, const gsdf_ncache& nc,
+                                             const float* __restrict__ depth, float* __restrict__ nx, float* __restrict__ ny,
+                                             float* __restrict__ nz) {
+    const int tx0 = tile_x * NRM_TX, ty0 = tile_y * NRM_TY;
     const int PW = NRM_TX + 2 * r, PH = NRM_TY + 2 * r;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < PW * PH; idx += 256) {
+    for (int idx = tid; idx < PW * PH; idx += NRM_THREADS) {
         const int ly = idx / PW, lx = idx - ly * PW;
         const int gy = reflect101(ty0 + ly - r, H), gx = reflect101(tx0 + lx - r, W);
         const size_t i = (size_t)gy * W + gx;
         const float z = depth[i];
         const float zi = z != 0.f ? 1.f / z : 0.f;          /* NormalEstimator.h:183-187 */
-        prod[0][ly][lx] = nc.x0n[i] * zi;                   /* :191-193 */
-        prod[1][ly][lx] = nc.y0n[i] * zi;
-        prod[2][ly][lx] = nc.ninv[i] * zi;
+        S.prod[0][ly][lx] = nc.x0n[i] * zi;                 /* :191-193 */
+        S.prod[1][ly][lx] = nc.y0n[i] * zi;
+        S.prod[2][ly][lx] = nc.ninv[i] * zi;
     }
     __syncthreads();
-    for (int idx = tid; idx < PH * NRM_TX; idx += 256) {
+    for (int idx = tid; idx < PH * NRM_TX; idx += NRM_THREADS) {
         const int ly = idx / NRM_TX, x = idx - ly * NRM_TX;
         double s0 = 0, s1 = 0, s2 = 0;
         for (int dx = 0; dx <= 2 * r; ++dx) {
-            s0 += (double)prod[0][ly][x + dx];
-            s1 += (double)prod[1][ly][x + dx];
-            s2 += (double)prod[2][ly][x + dx];
+            s0 += (double)S.prod[0][ly][x + dx];
+            s1 += (double)S.prod[1][ly][x + dx];
+            s2 += (double)S.prod[2][ly][x + dx];
         }
-        rows[0][ly][x] = s0; rows[1][ly][x] = s1; rows[2][ly][x] = s2;
+        S.rows[0][ly][x] = s0; S.rows[1][ly][x] = s1; S.rows[2][ly][x] = s2;
     }
     __syncthreads();
     const int x = tid & (NRM_TX - 1), y = tid / NRM_TX;
@@ -193,9 +192,9 @@ __global__ __launch_bounds__(256) void k_normals(gsdf_frame_geom g, int r, gsdf_
     if (px >= W || py >= H) return;
     double b1 = 0, b2 = 0, b3 = 0;
     for (int dy = 0; dy <= 2 * r; ++dy) {
-        b1 += rows[0][y + dy][x];
-        b2 += rows[1][y + dy][x];
-        b3 += rows[2][y + dy][x];
+        b1 += S.rows[0][y + dy][x];
+        b2 += S.rows[1][y + dy][x];
+        b3 += S.rows[2][y + dy][x];
     }
     const size_t i = (size_t)py * W + px;
     const float c1 = (float)b1, c2 = (float)b2, c3 = (float)b3;
@@ -206,11 +205,23 @@ __global__ __launch_bounds__(256) void k_normals(gsdf_frame_geom g, int r, gsdf_
     const float n = sqrtf((vx * vx + vy * vy) + vz * vz);   /* :199 */
     nx[i] = vx / n; ny[i] = vy / n; nz[i] = vz / n;         /* :201-203 */
 }
+
+__global__ __launch_bounds__(NRM_THREADS) void k_normals(gsdf_frame_geom g, int r, gsdf_ncache nc,
+                                                         const float* __restrict__ depth, float* __restrict__ nx,
+                                                         float* __restrict__ ny, float* __restrict__ nz,
+                                                         unsigned int* deferred_count, gsdf_dev_state* st_rw) {
+    if (deferred_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        *deferred_count = 0u;                                  /* fresh list for k_fuse */
+        if (st_rw) st_rw->frame_cur = st_rw->frames;           /* counter_ seen by every workgroup of k_fuse */
+    }
+    __shared__ nrm_lds S;
+    normals_tile(S, blockIdx.x, blockIdx.y, g.W, g.H, r, nc, depth, nx, ny, nz);
+}
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
-                         const float* depth, float* nx, float* ny, float* nz, const gsdf_dev_state* gate,
+                         const float* depth, float* nx, float* ny, float* nz,
                          unsigned int* deferred_count, gsdf_dev_state* st_rw) {
     dim3 grid((g.W + NRM_TX - 1) / NRM_TX, (g.H + NRM_TY - 1) / NRM_TY);
-    hipLaunchKernelGGL(k_normals, grid, dim3(256), 0, s, g, win / 2, nc, depth, nx, ny, nz, gate, deferred_count, st_rw);
+    hipLaunchKernelGGL(k_normals, grid, dim3(NRM_THREADS), 0, s, g, win / 2, nc, depth, nx, ny, nz, deferred_count, st_rw);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -265,6 +276,10 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
  *    to 2^-21 (2.4e-7 absolute; the gradient bar is 1e-4 relative to max(1, weight)). */
 #define FUSE_FIX_ONE 2097152.0f          /* 2^21 */
 #define FUSE_FIX_INV 4.76837158203125e-07f
+#ifndef FUSE_SPREAD
+#define FUSE_SPREAD 1                    /* spread lane -> (pixel, slice) mapping, see k_fuse */
+#endif
+#define FUSE_NSTAT (FUSE_SPREAD ? 8 : 4) /* waves of a workgroup that hold distinct pixels */
 typedef uint32_t gsdf_u32x4 __attribute__((ext_vector_type(4)));
 
 struct fuse_args {
@@ -288,7 +303,13 @@ struct fuse_args {
     uint32_t* vis;                      /* optional per-voxel frame bit-vectors (vis_, MapGradPixelSdf.h:70); nullable */
     int vis_words;
     int debug;                          /* path-forcing / measurement switches: only read by builds with -DGSDF_EXPERIMENTS */
+    unsigned int* ticket;               /* arrivals of finished workgroups; the last one resolves the deferred list and resets it */
+    float* log_rows;                    /* nullable: per-frame log of the Scan3D loop (use_dev_pose) */
+    long long max_rows;
+    int resolve_follows;                /* a k_fuse_resolve launch is queued behind this one: leave long lists to it */
+    unsigned int* host_note;            /* nullable, pinned host word: length of this launch's deferred list */
 };
+#define FUSE_RESOLVE_INLINE 8192u       /* deferred entries the last workgroup adds itself even when a resolve launch follows */
 
 struct fuse_lds {
     uint32_t key[FUSE_LCAP] __attribute__((aligned(16)));
@@ -297,9 +318,10 @@ struct fuse_lds {
                                                                             scattered entries spread over the banks */
     unsigned int cnt[2][4 * FUSE_ZSPLIT];   /* per wave: samples with w > 0, valid pixels */
     unsigned int n_defer, defer_base;
-    unsigned int st_min[4], st_max[4];  /* per wave: smallest / largest valid depth (float bits) */
-    float st_cnt[4];                    /* per wave: valid pixels */
+    unsigned int st_min[FUSE_NSTAT], st_max[FUSE_NSTAT];  /* per wave: smallest / largest valid depth (float bits) */
+    float st_cnt[FUSE_NSTAT];                             /* per wave: valid pixels */
     unsigned int ordered;               /* flush with plain read-modify-write (1) or through the deferred list (0) */
+    unsigned int any_defer, is_last;    /* this workgroup appended to the deferred list / is the last one to finish */
     const float* plane[7];              /* depth, x0, y0, 1/n2, nx, ny, nz: read from here by the band reloads, so the
                                            seven pointers do not stay in scalar registers across the ray walk */
 };
@@ -353,10 +375,32 @@ __device__ __forceinline__ void fuse_lds_clear(fuse_lds& L, int tid) {
     for (int i = tid; i < FUSE_LCAP * 3 / 4; i += FUSE_THREADS) g4[i] = gsdf_u32x4{ 0u, 0u, 0u, 0u };
 }
 
+/* per-frame log row of the Scan3D loop: pose7, converged, passes, hits of the last pass (main_scan_3d.cpp:268-280) */
+__device__ __forceinline__ void fuse_log_row(const fuse_args& a) {
+    if (!a.log_rows) return;
+    gsdf_dev_state* st = a.st;
+    const long long r = st->log_rows;
+    if (r < a.max_rows) {
+        float* o = a.log_rows + 10 * r;
+        for (int i = 0; i < 7; ++i) o[i] = st->pose7[i];
+        o[7] = (float)st->converged; o[8] = (float)st->passes; o[9] = st->last_hits;
+    }
+    st->log_rows = r + 1;
+}
+
 __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
     __shared__ fuse_lds L;
-    if (a.use_dev_pose && !a.st->converged) return;        /* main_scan_3d.cpp:261: if (conv) update */
     const int tid = threadIdx.x;
+    /* main_scan_3d.cpp:261: if (conv) update.  The launch may have been queued before optimize() ended (the host
+     * issues it behind every batch of passes): it runs only once the pose iteration is done AND converged; the
+     * launch that finds it done but NOT converged only writes the frame's log row. */
+    if (a.use_dev_pose) {
+        const int done = a.st->done, conv = a.st->converged;
+        if (!(done && conv)) {
+            if (done && blockIdx.x == 0 && tid == 0) fuse_log_row(a);
+            return;
+        }
+    }
     const unsigned long long T0 = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
     float R[9], t[3];
     if (a.use_dev_pose) {
@@ -403,24 +447,38 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
         }
     };
     /* the common case is one band: load its pixels now, the loads overlap the table clear */
+#if FUSE_SPREAD
+    /* Lanes of a wave are spread out, because lanes that hit the same voxel in one instruction serialise in the LDS
+     * atomics: a wave takes 32 pixels (every 2nd in x, every (4 / bands)-th in y: wave w has phase (w & 1, w >> 1)) and
+     * BOTH slices of their ray walk (lanes 0-31 / 32-63), so neighbouring lanes are >= 2 pixels or half a ray apart. */
+    static_assert(FUSE_ZSPLIT == 2, "the spread mapping splits a ray between the two halves of a wave");
+    load_pixel(tile_x * FUSE_T + 2 * lx + (wave & 1), tile_y * FUSE_T + 4 * (ly & 3) + (wave >> 1),
+               a.depth, a.nc.x0, a.nc.y0, a.nc.ninv, a.nx, a.ny, a.nz);
+#else
     load_pixel(tile_x * FUSE_T + (wave & 1) * 8 + lx, tile_y * FUSE_T + ((wave >> 1) & 1) * 8 + ly,
                a.depth, a.nc.x0, a.nc.y0, a.nc.ninv, a.nx, a.ny, a.nz);
+#endif
     /* meanwhile: empty table */
     fuse_lds_clear(L, tid);
+    if (GSDF_EXPERIMENT(a.debug, 128)) {                    /* phase timer: all seven pixel loads have arrived */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) atomicAdd(&a.st->dbg[5], wall_clock64() - T0);
+    }
     if (tid == 0) {
-        L.n_defer = 0u; L.defer_base = 0u;
+        L.n_defer = 0u; L.defer_base = 0u; L.any_defer = 0u;
         L.plane[0] = a.depth; L.plane[1] = a.nc.x0; L.plane[2] = a.nc.y0; L.plane[3] = a.nc.ninv;
         L.plane[4] = a.nx; L.plane[5] = a.ny; L.plane[6] = a.nz;
     }
-    /* depth range of the tile and the number of valid pixels: one entry per wave of the first half */
-    if (zslice == 0) {
+    /* depth range of the tile and the number of valid pixels: one entry per wave that holds distinct pixels */
+    if (FUSE_SPREAD || zslice == 0) {
         unsigned int zb = valid ? __float_as_uint(z) : 0x7F800000u, zt = valid ? __float_as_uint(z) : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned int o1 = __shfl_xor(zb, o), o2 = __shfl_xor(zt, o);
             zb = o1 < zb ? o1 : zb; zt = o2 > zt ? o2 : zt;
         }
-        const float cnt = (float)__popcll(__ballot(valid));
+        /* spread mapping: both halves of a wave hold the same 32 pixels */
+        const float cnt = (float)__popcll(FUSE_SPREAD ? (__ballot(valid) & 0xFFFFFFFFull) : __ballot(valid));
         if (lane == 0) { L.st_min[wave] = zb; L.st_max[wave] = zt; L.st_cnt[wave] = cnt; }
     }
     __syncthreads();
@@ -432,9 +490,13 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
     int ox, oy, oz;
     bool range_ok;
     {
-        const unsigned int zmin_bits = min(min(L.st_min[0], L.st_min[1]), min(L.st_min[2], L.st_min[3]));
-        const unsigned int zmax_bits = max(max(L.st_max[0], L.st_max[1]), max(L.st_max[2], L.st_max[3]));
-        const float n_valid = (L.st_cnt[0] + L.st_cnt[1]) + (L.st_cnt[2] + L.st_cnt[3]);
+        unsigned int zmin_bits = L.st_min[0], zmax_bits = L.st_max[0];
+        float n_valid = L.st_cnt[0];
+#pragma unroll
+        for (int i = 1; i < FUSE_NSTAT; ++i) {
+            zmin_bits = min(zmin_bits, L.st_min[i]); zmax_bits = max(zmax_bits, L.st_max[i]);
+            n_valid += L.st_cnt[i];                                   /* small integers: exact in any order */
+        }
         /* (1) of the flush comment below: may this tile write its voxels itself? */
         const float D = 1.7421f * g.vs;
         const float s_min = __uint_as_float(zmin_bits) - (float)g.factor * g.vs - 2.f * D;
@@ -493,19 +555,32 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
     for (int pass = 0; pass < n_pass; ++pass) {
     /* lanes -> (pixel of the band, slice of the ray walk).  One band: as loaded above, FUSE_ZSPLIT slices.  Two bands
      * of 16x8 pixels: 2 waves (8x8 each) per slice, twice the slices.  Four bands of 16x4: 1 wave per slice. */
+#if FUSE_SPREAD
+    /* a band of 256 / n_pass pixels = G groups of 32 (one per wave % G), walked in 2 * n_pass slices: the two halves
+     * of a wave take slices 2 (wave / G) and 2 (wave / G) + 1 */
+    const int G = 8 / n_pass, grp = wave % G;
+    const int zs = (lane >> 5) + 2 * (wave / G);
+    const int bx = 2 * lx + (grp & 1), by = (G / 2) * (ly & 3) + (grp >> 1);
+#else
     const int per = FUSE_THREADS / (FUSE_ZSPLIT * n_pass);
     const int q = tid % per, zs = tid / per;
     const int bx = n_pass == 4 ? (q & 15) : ((q >> 6) & 1) * 8 + (q & 7);
     const int by = n_pass == 4 ? (q >> 4) : (q >> 7) * 8 + ((q >> 3) & 7);
+#endif
     if (n_pass > 1)
         load_pixel(tile_x * FUSE_T + bx, tile_y * FUSE_T + pass * (FUSE_T / n_pass) + by,
                    L.plane[0], L.plane[1], L.plane[2], L.plane[3], L.plane[4], L.plane[5], L.plane[6]);
-    if (zs == 0) n_val_w += (unsigned int)__popcll(__ballot(valid));  /* zs is the same for a whole wave */
+    n_val_w += (unsigned int)__popcll(__ballot(valid && zs == 0));    /* every pixel is held by one lane per slice */
     /* this slice's share of the ray walk k = -factor..factor (:101); the order is free (sums) */
     const int k_lo = -g.factor + (zs * nk_all) / (FUSE_ZSPLIT * n_pass);
     const int k_hi = -g.factor + ((zs + 1) * nk_all) / (FUSE_ZSPLIT * n_pass) - 1;
-    const int nk = __builtin_amdgcn_readfirstlane(k_hi - k_lo + 1);       /* the same for the whole wave */
-    if (nk > 0 && __any(valid)) {                    /* ~18 % of the 8x8 sub-tiles have no valid pixel at all */
+    const int nk_lane = k_hi - k_lo + 1;
+    int nk = nk_lane;                                                  /* loop count of the wave: its longest slice */
+#if FUSE_SPREAD
+    nk = max(nk, __shfl_xor(nk, 32));
+#endif
+    nk = __builtin_amdgcn_readfirstlane(nk);
+    if (nk > 0 && __any(valid)) {                    /* waves without any valid pixel skip the walk */
         for (int c0 = 0; c0 < nk; c0 += FUSE_BATCH) {
             uint32_t key[FUSE_BATCH], bk[FUSE_BATCH];
             unsigned long long qw[FUSE_BATCH], qs[FUSE_BATCH];
@@ -518,7 +593,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 act[j] = false; local[j] = false; key[j] = 0u; bk[j] = 0u;
                 vox[j][0] = vox[j][1] = vox[j][2] = 0;
                 if (c0 + j >= nk) continue;
-                const int kk = k_lo + c0 + j;                          /* wave-uniform */
+                const int kk = k_lo + c0 + j;
                 const float s = z + (float)kk * g.vs;
                 const float pxw = s * Rxy.x + t[0], pyw = s * Rxy.y + t[1], pzw = s * Rxy.z + t[2];   /* :103 */
                 /* float2vox (:104): std::round; the rounded value is kept as a float too -- (float)vi == the rounded
@@ -529,7 +604,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 const float pc_z = gsdf_sum3(R[2] * dx, R[5] * dy, R[8] * dz);   /* :105  (Rt row 2) */
                 const float sdf = pc_z - z;                                /* :106 */
                 const float w = gsdf_weight(sdf, g.T, g.inv_T);            /* :107 */
-                act[j] = valid && w > 0.f;
+                act[j] = valid && w > 0.f && c0 + j < nk_lane;
                 n_upd_w += (unsigned int)__popcll(__ballot(act[j]));
                 vox[j][0] = vx; vox[j][1] = vy; vox[j][2] = vz;
                 /* tile-local key: 10 bits per axis relative to the tile origin */
@@ -544,8 +619,9 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                  * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
                  * overflow, and the distinct voxels of one wave instruction never compete for a bucket.
                  * (The HBM table keeps the full 64-bit finaliser.) */
-                static_assert(FUSE_NB == 512, "lattice constants are for 512 buckets");
-                bk[j] = (lx3 + 98u * ly3 + 143u * lz3) & (uint32_t)(FUSE_NB - 1);
+                static_assert(FUSE_NB == 512 || FUSE_NB == 384, "lattice constants exist for 512 and 384 buckets");
+                if (FUSE_NB == 512) bk[j] = (lx3 + 98u * ly3 + 143u * lz3) & 511u;
+                else bk[j] = (lx3 + 65u * ly3 + 138u * lz3) % 384u;            /* 3 workgroups per CU: min distance 7.9 */
             }
             /* 2.-4. look the voxels up in the LDS table.  All pending samples of the batch advance
              *    together: bucket (4 keys) = one ds_read_b128, match / first-empty by selects, at most
@@ -585,7 +661,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                     emp = kk4[j].z == FUSE_LKEY_EMPTY ? 2 : emp; emp = kk4[j].y == FUSE_LKEY_EMPTY ? 1 : emp; emp = kk4[j].x == FUSE_LKEY_EMPTY ? 0 : emp;
                     if (pend[j] && hit >= 0) { slot[j] = (int)(4 * bk[j]) + hit; pend[j] = false; }
                     cas_at[j] = (pend[j] && emp >= 0) ? (int)(4 * bk[j]) + emp : -1;
-                    if (pend[j] && emp < 0) bk[j] = (bk[j] + 1u) & (uint32_t)(FUSE_NB - 1);   /* bucket full of others */
+                    if (pend[j] && emp < 0) bk[j] = bk[j] + 1u == (uint32_t)FUSE_NB ? 0u : bk[j] + 1u;   /* bucket full of others */
                     if (GSDF_EXPERIMENT(a.debug, 128) && __any(pend[j] && emp < 0)) ++dbg_full;
                 }
                 uint32_t old[FUSE_BATCH];
@@ -620,6 +696,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                     if (!p) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
                     else {
                         defer_append(a, p, fix2f(qw[j]), fix2f(qs[j]), fix2f((uint32_t)qg[j][0]), fix2f((uint32_t)qg[j][1]), fix2f((uint32_t)qg[j][2]));
+                        L.any_defer = 1u;
                         vis_mark(a, p, frame_cur);
                     }
                 }
@@ -672,6 +749,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
 #pragma unroll
         for (int e = 0; e < NE; ++e)
             if (ekey[e] != GSDF_KEY_EMPTY) k0[e] = a.tab.bkeys[home[e]];         /* 512 KB of block keys: L2 hits */
+        unsigned long long TF = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
         /* meanwhile one wave waits for the adjacent tiles of lower colour (lane j watches neighbour j) */
         if (wave == 0 && L.ordered && pass == 0) {
             bool need = false;
@@ -706,6 +784,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             else P[e] = a.tab.vox + ((size_t)b * GSDF_BLOCK_VOX + gsdf_block_local(ekey[e]));
         }
         __syncthreads();                                              /* the wait above is over (or timed out) */
+        if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 0], T - TF); TF = T; }
         const bool ordered = L.ordered != 0u;
         if (ordered) {
             /* a record is 32 bytes, 32-byte aligned: two 16-byte agent-scope (sc1) accesses each way -- narrower
@@ -719,13 +798,12 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ra[e]) : "v"(P[e]) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=v"(rb[e]) : "v"(P[e]) : "memory");
             }
-            static_assert(NE == 4 || NE == 2, "the wait statement names NE x 2 destination registers");
-            if constexpr (NE == 4)
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[NE - 2]), "+v"(rb[NE - 2]), "+v"(ra[NE - 1]), "+v"(rb[NE - 1])
-                             :: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[NE - 1]), "+v"(rb[NE - 1]) :: "memory");
+            static_assert(NE >= 2 && NE <= 4, "the wait statement names NE x 2 destination registers");
+            /* (the middle operands repeat earlier ones when NE < 4) */
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[NE - 2]), "+v"(rb[NE - 2]), "+v"(ra[NE - 1]), "+v"(rb[NE - 1])
+                         :: "memory");
+            if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 1], T - TF); TF = T; }
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 if (ekey[e] == GSDF_KEY_EMPTY) continue;
@@ -742,14 +820,14 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(P[e]), "v"(ob) : "memory");
                 vis_mark(a, P[e], frame_cur);
             }
-            /* hand the voxels on: every storing wave drains its stores, then ONE lane publishes the flag.  Nobody
-             * waits for a tile of the highest colour: after its last band it just ends (the kernel boundary
-             * completes its stores); between bands the drain orders this workgroup's own re-reads. */
-            if (colour < 3 || pass + 1 < n_pass) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            /* hand the voxels on: every storing wave drains its stores, then ONE lane publishes the flag.  (Tiles of
+             * the highest colour drain too although nobody waits for their flag: the deferred contributions are
+             * added by the last workgroup of this launch, after every tile's stores.) */
+            if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 2], T - TF); TF = T; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 3], T - TF); TF = T; }
         } else {
             /* near tile (or timed-out wait): everything goes through the deferred list */
             unsigned int my_defer = 0u;
@@ -763,7 +841,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             if (my_defer) atomicAdd(&L.n_defer, my_defer);
             __syncthreads();
             if (L.n_defer) {
-                if (tid == 0) L.defer_base = atomicAdd(a.deferred_count, L.n_defer);   /* one global atomic per workgroup */
+                if (tid == 0) { L.defer_base = atomicAdd(a.deferred_count, L.n_defer); L.any_defer = 1u; }   /* one global atomic per workgroup */
                 __syncthreads();
                 if (tid == 0) L.n_defer = 0u;
                 __syncthreads();
@@ -805,28 +883,50 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
         unsigned long long* c = a.blk_counters + 4 * ((size_t)tile_y * a.ntx + tile_x);
         c[0] = nu; c[1] = nv; c[2] += nu; c[3] += nv;
         if (tile_x == 0 && tile_y == 0) a.st->frames += 1;            /* :120 increase_counter() */
+        /* Arrival.  The deferred contributions (near tiles, LDS overflow, timed-out waits: normally a handful) are added
+         * by whichever workgroup finishes last, so the common case needs no second launch.  A workgroup that appended to
+         * the list releases its entries first (cdna_hip_programming.md G16: stores -> barrier -> one agent-scope release
+         * -> drained -> atomic); every workgroup has drained its record stores above. */
+        if (L.any_defer) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        L.is_last = atomicAdd(a.ticket, 1u) + 1u == gridDim.x ? 1u : 0u;
+        if (L.is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!L.is_last) return;
+    unsigned int n = __hip_atomic_load(a.deferred_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    n = n < a.deferred_cap ? n : a.deferred_cap;
+    const bool mine = !(a.resolve_follows && n > FUSE_RESOLVE_INLINE);
+    if (mine)
+        for (unsigned int i = tid; i < n; i += FUSE_THREADS) {
+            const gsdf_deferred d = a.deferred[i];
+            unsafeAtomicAdd(&d.p->w, d.w);
+            unsafeAtomicAdd(&d.p->s, d.s);
+            unsafeAtomicAdd(&d.p->gx, d.gx);
+            unsafeAtomicAdd(&d.p->gy, d.gy);
+            unsafeAtomicAdd(&d.p->gz, d.gz);
+        }
+    if (tid == 0) {
+        if (mine) { a.st->n_deferred += n; __hip_atomic_store(a.deferred_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        a.st->last_deferred = n;
+        /* the host decides by it, without waiting, whether the next launches get a k_fuse_resolve behind them */
+        if (a.host_note) __hip_atomic_store(a.host_note, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.use_dev_pose) fuse_log_row(a);
     }
 }
 
-/* adds the deferred contributions (voxels shared by several tiles, LDS overflow) after k_fuse.
- * The list counter is cleared by the k_normals launch that precedes every k_fuse. */
-__global__ __launch_bounds__(256) void k_fuse_resolve(const gsdf_deferred* list, const unsigned int* count, unsigned int cap,
-                                                       gsdf_dev_state* gate, gsdf_dev_state* st, float* log_rows,
-                                                       long long max_rows) {
-    /* per-frame log row: pose7, converged, passes, hits of the last pass (main_scan_3d.cpp:268-280) */
-    if (log_rows && blockIdx.x == 0 && threadIdx.x == 0) {
-        const long long r = gate->log_rows;
-        if (r < max_rows) {
-            float* o = log_rows + 10 * r;
-            for (int i = 0; i < 7; ++i) o[i] = gate->pose7[i];
-            o[7] = (float)gate->converged; o[8] = (float)gate->passes; o[9] = gate->last_hits;
-        }
-        gate->log_rows = r + 1;
-    }
-    if (gate && !gate->converged) return;
+/* Adds a LONG deferred list after k_fuse (scenes with many near tiles: every contribution of such a tile is deferred).
+ * Queued only while the previous launches reported long lists (gsdf_dev_state::last_deferred, read by the host without
+ * waiting); short lists are added by the last workgroup of k_fuse itself, which leaves count = 0 here. */
+__global__ __launch_bounds__(256) void k_fuse_resolve(const gsdf_deferred* list, unsigned int* count, unsigned int cap,
+                                                       const gsdf_dev_state* gate, gsdf_dev_state* st) {
+    if (gate && !(gate->done && gate->converged)) return;
     unsigned int n = *count;
     n = n < cap ? n : cap;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_deferred += n;
+    if (n == 0u) return;
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const gsdf_deferred d = list[i];
         unsafeAtomicAdd(&d.p->w, d.w);
@@ -835,6 +935,7 @@ __global__ __launch_bounds__(256) void k_fuse_resolve(const gsdf_deferred* list,
         unsafeAtomicAdd(&d.p->gy, d.gy);
         unsafeAtomicAdd(&d.p->gz, d.gz);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_deferred += n;    /* the count itself is cleared by the next normals stage */
 }
 
 void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
@@ -842,8 +943,11 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       int use_dev_pose, gsdf_table tab, gsdf_dev_state* st, unsigned long long* blk_counters,
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
                       unsigned int tag, unsigned int* tile_flags, const uint32_t* tile_order, float* log_rows,
-                      long long max_rows, uint32_t* vis, int vis_words, int debug) {
+                      long long max_rows, uint32_t* vis, int vis_words, int debug, unsigned int* ticket, int resolve_follows,
+                      unsigned int* host_note) {
     fuse_args a;
+    a.host_note = host_note;
+    a.ticket = ticket; a.log_rows = use_dev_pose ? log_rows : nullptr; a.max_rows = max_rows; a.resolve_follows = resolve_follows;
     a.vis = vis; a.vis_words = vis_words;
     a.debug = debug;
     a.g = g; a.nc = nc; a.depth = depth; a.nx = nx; a.ny = ny; a.nz = nz; a.pose = pose;
@@ -854,9 +958,8 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     a.tile_flags = tile_flags; a.ntx = ntx; a.nty = nty; a.tile_order = tile_order;
     const int n = ntx * nty;
     hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(debug, 4096) ? 81920 : 0, s, a);   /* experiment: 1 workgroup per CU */
-    /* the deferred list is normally (almost) empty: a small grid keeps the launch cheap, the stride loop covers long lists */
-    hipLaunchKernelGGL(k_fuse_resolve, dim3(64), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st,
-                       use_dev_pose ? log_rows : nullptr, max_rows);
+    if (resolve_follows)
+        hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st);
 }
 int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T); }
 /* Launch order of the fusion tiles.  Colour-major (colour = parity of tile x, y): a tile only ever waits for tiles
@@ -1034,9 +1137,24 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
     }
 }
 
+static_assert(GSDF_TRACK_BLOCK == NRM_THREADS, "the normals tiles of the first pass run in tracker-sized workgroups");
 __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
                                                                  gsdf_table tab, gsdf_dev_state* st,
-                                                                 double* rows, gsdf_track_params tp) {
+                                                                 double* rows, gsdf_track_params tp, gsdf_normals_job nj) {
+    /* Workgroups beyond the tracker's own (first pass of a frame in the Scan3D loop only): one normals tile each
+     * (NormalEstimator::compute of THIS depth frame for the update() that follows a converged optimize(),
+     * main_scan_3d.cpp:258-263).  They need the depth only, fill the chip beside the latency-bound pass, and use
+     * dynamic LDS so that the later passes of the frame stay small. */
+    if ((int)blockIdx.x >= tp.n_track_blocks) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+        const int t = (int)blockIdx.x - tp.n_track_blocks;
+        if (t == 0 && threadIdx.x == 0) {
+            *nj.deferred_count = 0u;                            /* fresh list for the k_fuse of this frame */
+            st->frame_cur = st->frames;                         /* counter_ seen by every workgroup of k_fuse */
+        }
+        normals_tile(*reinterpret_cast<nrm_lds*>(dyn_lds), t % nj.ntx, t / nj.ntx, g.W, g.H, nj.r, nj.nc, depth, nj.nx, nj.ny, nj.nz);
+        return;
+    }
     __shared__ float wsum[GSDF_TRACK_BLOCK / 64][32];
     __shared__ double gsum[GSDF_TRACK_BLOCK / 32][32];
     __shared__ float tot[32];
@@ -1067,6 +1185,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
             for (int i = 0; i < 7; ++i) o.pose7[i] = pose[i];
             o.done = 0; o.converged = 0; o.passes = 0;
+            st->done = 0; st->converged = 0;                               /* what the gated fusion launches of this frame read */
         }
     } else {
         /* ---- head: every workgroup reduces the rows of pass k-1 in the same fixed order, solves the
@@ -1109,14 +1228,14 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
                 if (done) st->trk[(k - 1) & 1].done = 1;
                 gsdf_quat_to_R(pose + 3, st->R);
                 st->converged = converged;
+                st->done = done;
                 st->passes = passes;
                 st->last_hits = tot[28];
                 st->n_hit += (unsigned long long)tot[28];
                 /* progress for the host's adaptive pass issue (pinned host memory, system scope) */
-                if (tp.progress) {
-                    __hip_atomic_store(&tp.progress[0], (tp.serial << 8) | (unsigned int)passes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (done) __hip_atomic_store(&tp.progress[1], tp.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
+                if (tp.progress)                 /* one word, so the host reads a consistent (passes, done) pair */
+                    __hip_atomic_store(&tp.progress[0], (tp.serial << 16) | (done ? 0x8000u : 0u) | (unsigned int)(passes & 0x7FFF),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         __syncthreads();
@@ -1130,7 +1249,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
     float acc[GSDF_TRACK_NSUM];
 #pragma unroll
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
-    trk_gather(g, tab, depth, nullptr, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, gridDim.x * GSDF_TRACK_BLOCK, acc);
+    trk_gather(g, tab, depth, nullptr, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, tp.n_track_blocks * GSDF_TRACK_BLOCK, acc);
     __syncthreads();                                                      /* wsum is reused */
     wave_sum_to_lane63(acc);
     if (lane == 63) {
@@ -1151,8 +1270,21 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
     }
 }
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
-                            gsdf_dev_state* st, double* partials, int n_blocks, const gsdf_track_params& tp) {
-    hipLaunchKernelGGL(k_track_pass, dim3(n_blocks), dim3(GSDF_TRACK_BLOCK), 0, s, g, depth, tab, st, partials, tp);
+                            gsdf_dev_state* st, double* partials, int n_blocks, const gsdf_track_params& tp_in,
+                            const gsdf_normals_job* normals) {
+    gsdf_track_params tp = tp_in;
+    tp.n_track_blocks = n_blocks;
+    gsdf_normals_job nj;
+    memset(&nj, 0, sizeof(nj));
+    int extra = 0;
+    size_t dyn = 0;
+    if (normals) {
+        nj = *normals;
+        nj.ntx = (g.W + NRM_TX - 1) / NRM_TX;
+        extra = nj.ntx * ((g.H + NRM_TY - 1) / NRM_TY);
+        dyn = sizeof(nrm_lds);
+    }
+    hipLaunchKernelGGL(k_track_pass, dim3(n_blocks + extra), dim3(GSDF_TRACK_BLOCK), dyn, s, g, depth, tab, st, partials, tp, nj);
 }
 
 struct pose7_arg { float p[7]; };

@@ -13,7 +13,7 @@ g.debug_flags(128)
 dev = [g.upload(f[0]) for f in frames]
 import ctypes
 def rd():
-    o = (ctypes.c_ulonglong * 8)()
+    o = (ctypes.c_ulonglong * 24)()
     L.gsdf_debug_read(g.h, o)
     return np.array(list(o), dtype=np.float64)
 for i in range(n // 2):
@@ -29,10 +29,14 @@ print("frames %d..%d, mean per workgroup (clock ticks): prologue %.0f  ray walk 
 st = g.stats()
 print("go per frame", st["n_hit"] / n, "wave-samples per frame", 1200 * 8 * 10.5, "ratio", st["n_hit"] / n / (1200 * 8 * 10.5))
 import ctypes
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 24)()
 L.gsdf_debug_read(g.h, out)
 print("wave-level events per frame: bucket full", out[0] / n, "CAS lost", out[1] / n)
 wg = 1200.0 * n
 print("mean per workgroup (us): prologue %.2f  ray walk %.2f  flush %.2f" % (out[4] / wg / 100.0, out[2] / wg / 100.0, out[3] / wg / 100.0))
+print("pixel loads arrived after %.2f us (mean per workgroup)" % (out[5] / wg / 100.0))
+for c in range(4):
+    f = [out[8 + 4 * c + k] / (wg / 4) / 100.0 for k in range(4)]
+    print("flush, colour %d tiles (us per workgroup): keys+probe+wait %.2f  record loads %.2f  adds+stores issued %.2f  drain+flag %.2f" % (c, *f))
 print("n_upd/frame", st["n_upd"] / n, "voxels", g.count())
 g.close()
