@@ -119,6 +119,7 @@ def load(path=None):
         "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
         "gsdf_query": (C.c_int, [vp, fp, C.c_int64, fp, fp, fp]),
+        "gsdf_get_voxels": (C.c_int, [vp, i32p, C.c_int64, fp, i32p]),
         "gsdf_block_keys_dev": (C.c_int, [vp, vp, C.c_int64, C.POINTER(C.c_int64)]),
         "gsdf_pack_blocks_dev": (C.c_int, [vp, vp, C.c_int64, vp]),
         "gsdf_unpack_blocks_dev": (C.c_int, [vp, vp, C.c_int64, vp]),
@@ -149,7 +150,7 @@ ABI_SYMBOLS = [
     "gsdf_ba_setup", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
-    "gsdf_query", "gsdf_raycast", "gsdf_extract_mesh",
+    "gsdf_query", "gsdf_get_voxels", "gsdf_raycast", "gsdf_extract_mesh",
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_dev_download", "gsdf_timer_start", "gsdf_timer_stop_ms",
     "gsdf_profile", "gsdf_profile_read",
 ]
@@ -376,6 +377,16 @@ class GradSdf:
         w = np.empty(n, np.float32)
         self._chk(self.L.gsdf_query(self.h, _fp(p), n, _fp(dist), _fp(grad), _fp(w)))
         return dist, grad, w
+
+    def get_voxels(self, keys):
+        """tsdf_.at(idx) for int32 keys [n,3]: (payload [n,5] = dist, raw gx gy gz, weight; found [n] bool)."""
+        k = np.ascontiguousarray(keys, np.int32).reshape(-1, 3)
+        n = k.shape[0]
+        pay = np.zeros((n, 5), np.float32)
+        found = np.zeros(n, np.int32)
+        self._chk(self.L.gsdf_get_voxels(self.h, k.ctypes.data_as(C.POINTER(C.c_int32)), n, _fp(pay),
+                                         found.ctypes.data_as(C.POINTER(C.c_int32))))
+        return pay, found.astype(bool)
 
     def raycast(self, R, t, zmin=0.5, zmax=3.5, W=None, H=None, K=None, normals=True):
         """Voxel-hash raycaster: (depth[H,W] camera z, 0 = no hit; normals[3,H,W] camera frame or None)."""

@@ -899,6 +899,27 @@ int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float
     return GSDF_OK;
 }
 
+int gsdf_get_voxels(gsdf_ctx* c, const int32_t* keys_host, int64_t n, float* payload, int32_t* found) {
+    if (!c || (n > 0 && (!keys_host || !payload || !found))) return fail(GSDF_ERR_INVALID, "null argument");
+    if (n <= 0) return GSDF_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    char* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)n * (3 * sizeof(int32_t) + 5 * sizeof(float) + sizeof(int32_t))));
+    int32_t* dk = (int32_t*)d;
+    float* dp = (float*)(d + (size_t)n * 3 * sizeof(int32_t));
+    int32_t* df = (int32_t*)(d + (size_t)n * (3 * sizeof(int32_t) + 5 * sizeof(float)));
+    hipError_t e = hipMemcpyAsync(dk, keys_host, (size_t)n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        gsdf_launch_get_voxels(c->stream, c->tab, dk, n, dp, df);
+        e = hipMemcpyAsync(payload, dp, (size_t)n * 5 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(found, df, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
+    return GSDF_OK;
+}
+
 int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
                  float* depth_out, float* normals_out) {
     if (!c || !K || !R || !t || !depth_out) return fail(GSDF_ERR_INVALID, "null argument");

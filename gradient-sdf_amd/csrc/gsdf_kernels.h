@@ -132,6 +132,7 @@ void gsdf_launch_merge_raw(hipStream_t s, gsdf_table tab, const int32_t* keys, c
                            long long n, gsdf_dev_state* st);
 void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, const float* pts, long long n,
                        float* dist, float* grad, float* w);
+void gsdf_launch_get_voxels(hipStream_t s, gsdf_table tab, const int32_t* keys, long long n, float* payload, int32_t* found);
 
 void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, int factor /* band half-width in voxels */, int W, int H, const float K[9],
                          const gsdf_pose_arg& pose, float zmin, float zmax, float* depth_dev, float* normals_dev_or_null);

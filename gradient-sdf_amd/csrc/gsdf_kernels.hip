@@ -1407,6 +1407,28 @@ void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, co
     hipLaunchKernelGGL(k_query, dim3(blocks), dim3(256), 0, s, tab, vs, inv_vs, pts, n, dist, grad, w);
 }
 
+/* tsdf_.at(idx) for n voxel indices -- MapGradPixelSdf.h:127-129 (getSdf): the stored SdfVoxel (dist, raw gradient sum, weight) */
+__global__ __launch_bounds__(256) void k_get_voxels(gsdf_table tab, const int32_t* keys, long long n, float* payload, int32_t* found) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int x = keys[3 * i], y = keys[3 * i + 1], z = keys[3 * i + 2];
+        float o[5] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+        int32_t f = 0;
+        if (gsdf_key_in_range(x, y, z)) {
+            const gsdf_payload* sl = gsdf_find(tab, gsdf_key_pack(x, y, z));
+            if (sl && sl->w > 0.f) { f = 1; o[0] = sl->s / sl->w; o[1] = sl->gx; o[2] = sl->gy; o[3] = sl->gz; o[4] = sl->w; }
+        }
+        for (int k = 0; k < 5; ++k) payload[5 * i + k] = o[k];
+        found[i] = f;
+    }
+}
+void gsdf_launch_get_voxels(hipStream_t s, gsdf_table tab, const int32_t* keys, long long n, float* payload, int32_t* found) {
+    if (n <= 0) return;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_get_voxels, dim3(blocks), dim3(256), 0, s, tab, keys, n, payload, found);
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Voxel-hash raycaster (BASELINE.json north_star; absent from the reference): defined
  * on top of weights()/tsdf() -- MapGradPixelSdf.h:109-125 -- and the tracker's back-projection

@@ -7,19 +7,23 @@
 
 #include "../../include/gsdf.h"
 #include "MarchingCubes.h"
+#include "exports.h"
 
 extern "C" {
 
 /* returns the number of faces written, or -1 (marching cubes on the device, gsdf_extract_mesh) */
 long gsdf_host_extract_mesh(gsdf_ctx* ctx, float voxel_size, const char* path) {
-    int64_t n = 0;
-    if (gsdf_extract_mesh(ctx, 0.f, nullptr, nullptr, 0, &n) != GSDF_OK || n <= 0) return -1;
-    std::vector<float> tris((size_t)n * 9);
-    if (gsdf_extract_mesh(ctx, 0.f, nullptr, tris.data(), n, &n) != GSDF_OK) return -1;
-    MarchingCubes mc(voxel_size);
-    mc.setTriangles(tris.data(), (size_t)n);
-    if (!mc.savePly(path)) return -1;
-    return (long)mc.faces().size();
+    long n = 0;
+    return gsdf_exports::write_mesh_ply(ctx, voxel_size, path, &n) ? n : -1;
+}
+/* MapGradPixelSdf::extract_pc: returns the number of points written, or -1 */
+long gsdf_host_extract_pc(gsdf_ctx* ctx, float voxel_size, const char* path) {
+    long n = 0;
+    return gsdf_exports::write_cloud_ply(ctx, voxel_size, path, &n) ? n : -1;
+}
+/* MapGradPixelSdf::save_sdf: 0 on success */
+int gsdf_host_save_sdf(gsdf_ctx* ctx, float voxel_size, const char* path_prefix) {
+    return gsdf_exports::write_sdf_txt(ctx, voxel_size, path_prefix) ? 0 : -1;
 }
 
 /* test hook: the device mesh against the host sweep over the exported map (MarchingCubes::computeIsoSurface).

@@ -43,10 +43,10 @@ extern "C" {
 
 typedef struct gsdf_ctx gsdf_ctx;
 
-/* per-call counters of the last fusion / tracking launches (for algorithmic-bytes accounting) */
+/* counters of the fusion / tracking launches (for algorithmic-bytes accounting: callers take differences) */
 typedef struct gsdf_stats {
-    int64_t n_upd;        /* (pixel,k) samples with w>0 in the last update()            */
-    int64_t n_valid;      /* pixels that passed the z-range and both normal gates       */
+    int64_t n_upd;        /* (pixel,k) samples with w>0, summed over every update() since create/reset   */
+    int64_t n_valid;      /* pixels that passed the z-range and both normal gates, summed likewise       */
     int64_t n_hit;        /* sum over executed tracker passes of pixels with w0>0       */
     int32_t track_passes; /* tracker reduction passes executed in the last optimize()   */
     int32_t converged;    /* result of the last optimize()                              */
@@ -165,6 +165,11 @@ int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t 
 /* Sdf::weights(point) and Sdf::tsdf(point, &grad) at n points -- MapGradPixelSdf.h:109-125.
  * w[i]==0 marks a missing voxel (dist/grad are then 0; the reference's .at() would throw). */
 int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w);
+
+/* MapGradPixelSdf::getSdf(idx) = tsdf_.at(idx) -- MapGradPixelSdf.h:127-129, for n voxel indices at once: the STORED voxel,
+ * payload = dist, gx, gy, gz (the raw weighted gradient sum, not the normalised one gsdf_query returns), weight.
+ * found[i] == 0 marks a missing voxel (payload zeros; the reference's .at() would throw). */
+int gsdf_get_voxels(gsdf_ctx* c, const int32_t* keys_host, int64_t n, float* payload, int32_t* found);
 
 /* Voxel-hash raycaster: depth (camera z, 0 = no hit) and camera-frame normals (3 planes, nullable) of the
  * fused map seen from pose (R, t) through K.  Named in BASELINE.json's north_star but ABSENT from the

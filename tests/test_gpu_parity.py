@@ -454,3 +454,195 @@ def test_argument_errors_of_the_newer_entries(pkg):
     st = g.stats()
     assert st["n_deferred"] == 0 and st["fuse_timeouts"] == 0
     g.close()
+
+
+# ---- round-2 additions: the bench workload, the stress config and the exports under test ---------------------------
+
+def test_tracked_bench_stream_matches_oracle_frame_by_frame(pkg, O):
+    """The bench workload itself (BASELINE configs[1]: S-tum 640x480, 1 cm voxels, trunc 10, 2^22), tracked, 64 frames,
+    through gsdf_track_and_fuse_dev against the oracle's main_scan_3d.cpp:255-266 loop: per frame the same `converged`
+    flag and the same number of Gauss-Newton passes, frame-1 pose within 1e-4.
+
+    Frames that do NOT converge are part of the reference's behaviour on this stream and are asserted here: the
+    nearest-voxel lookup with the 1.2 gradient scale (MapGradPixelSdf.h:113) makes phi discontinuous at voxel
+    borders, and on some frames Gauss-Newton settles into a cycle with |xi|^2 of 5e-6 .. 5e-5, above the 1e-6
+    threshold: optimize() runs all 25 passes, returns false, the frame is not fused (main_scan_3d.cpp:261) and the
+    last iterate stays the start pose of the next frame (RigidOptimizer.h:64).
+
+    What can and cannot be equal.  GPU and oracle differ in the last bits of their sums.  A frame whose iteration is
+    DETERMINISTIC -- it converges in a few passes with every |xi|^2 at least 10 % away from the threshold, or it settles
+    into a stable cycle (the last six |xi|^2 within 5 % of each other, all above the threshold) -- must agree exactly.
+    On the other frames Gauss-Newton wanders chaotically with |xi|^2 between 1e-6 and 1e-4: whether it dips below the
+    threshold within 25 passes is decided by last-bit noise (the same holds between the reference's own serial and OMP
+    builds, whose reductions differ), and after such a frame the two runs hold different maps.  So: strict equality on
+    every frame up to the first one that differs -- which must be a non-deterministic one and must come late, behind
+    converging AND non-converging frames -- and agreement in the aggregate over the whole stream."""
+    W, H, n = 640, 480, 64
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=0)
+    vs = np.float32(0.01); T = np.float32(10) * vs
+    frames = [seq.frame(i) for i in range(n)]
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=22)
+    o = O.Oracle(vs, T, W, H, seq.K, threads=1)
+    d0, R0, t0 = frames[0]
+    p0 = pose7_from(O, R0, t0)
+    R0q = O.quat_to_R(p0[3:])
+    g.update(d0, R0q, t0); o.update(d0, R0q, t0)
+    g.set_pose(p0)
+    dev = [g.upload(f[0]) for f in frames]
+    for i in range(1, n):
+        g.track_and_fuse_dev(dev[i])
+    g.sync()
+    log = g.frame_log()
+    assert log.shape == (n - 1, 10)
+    po = p0.copy()
+    strict = True
+    n_strict = strict_not_conv = 0
+    conv_o, err_o, err_g = [], [], []
+    for i in range(1, n):
+        co, po, used, trace, _ = o.track(frames[i][0], po)
+        if co:
+            o.update(frames[i][0], O.quat_to_R(po[3:]), po[:3])
+        xi2 = trace[:used, 35]
+        clean = co and used <= 6 and bool((np.abs(xi2 / 1e-6 - 1.0) >= 0.1).all())
+        cycle = (not co) and used == 25 and xi2[-6:].min() > 2e-6 and xi2[-6:].max() <= 1.05 * xi2[-6:].min()
+        if strict:
+            same = bool(log[i - 1, 7]) == co and int(log[i - 1, 8]) == used
+            if same:
+                assert np.abs(log[i - 1, :7] - po).max() <= TOL * i, "frame %d pose" % i
+                n_strict += 1
+                strict_not_conv += int(not co)
+            else:
+                # the first frame that differs must be a sensitive one; from here on only the aggregate is compared
+                assert not (clean or cycle), "frame %d: converged %d / %d passes vs oracle %d / %d, |xi|^2 %s" % (
+                    i, log[i - 1, 7], log[i - 1, 8], co, used, xi2)
+                strict = False
+        conv_o.append(co)
+        gt = frames[i][2]
+        if co:
+            err_o.append(np.abs(po[:3] - gt).max())
+        if log[i - 1, 7]:
+            err_g.append(np.abs(log[i - 1, :3] - gt).max())
+    conv_o = np.array(conv_o)
+    conv_g = log[:, 7] > 0
+    assert n_strict >= 30, n_strict                       # frames 1..33 on this stream
+    assert strict_not_conv >= 2                           # among them frames that run all 25 passes and are not fused
+    assert not bool(log[0, 7]) and int(log[0, 8]) == 25   # frame 1: one fused frame in the map, 25 passes, not fused
+    # the whole stream in the aggregate
+    assert (conv_g == conv_o).mean() >= 0.85
+    assert abs(int(conv_g.sum()) - int(conv_o.sum())) <= 6
+    assert (~conv_g).sum() >= 5 and (~conv_o).sum() >= 5  # both runs hit the non-converging stretch of the stream
+    assert max(err_g) < 0.012 and max(err_o) < 0.012      # every fused frame within ~1 voxel of the ground truth
+    st = g.stats()
+    assert st["frames"] == 1 + int(log[:, 7].sum())       # Sdf::counter_ counts the setup frame + the converged ones
+    g.close()
+
+
+def test_stress_config_c3_full_capacity(pkg, O):
+    """BASELINE configs[2] as configured: 1280x960, 5 mm voxels, trunc 10, hash capacity 2^25 (1 GiB of voxel records,
+    beyond the Infinity Cache): 3 frames fused (counters exact, map against the oracle) and one optimize() at 1280x960."""
+    W, H, n = 1280, 960, 4
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=0)
+    vs = np.float32(0.005); T = np.float32(10) * vs
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=25)
+    o = O.Oracle(vs, T, W, H, seq.K, threads=1)
+    nu = nv = 0
+    for i in range(3):
+        d, R, t = seq.frame(i)
+        g.update(d, R, t)
+        a, b = o.update(d, R, t)
+        nu += a; nv += b
+    st = g.stats()
+    assert st["n_upd"] == nu and st["n_valid"] == nv and st["frames"] == 3
+    assert st["fuse_timeouts"] == 0
+    assert _cmp_tables(g, o) > 3000000
+    d3, R3, t3 = seq.frame(3)
+    p = pose7_from(O, seq.frame(2)[1], seq.frame(2)[2])
+    cg, pg, passes = g.track(d3, p, iters=6)
+    co, po, used, _, _ = o.track(d3, p, iters=6)
+    assert cg == co and passes == used
+    assert np.abs(pg - po).max() <= TOL
+    g.close()
+
+
+def _mc_case_tables():
+    """include/gsdf_mc_tables.h parsed as data."""
+    import os, re
+    from conftest import ROOT
+    txt = open(os.path.join(ROOT, "include", "gsdf_mc_tables.h")).read()
+    e = re.search(r"GSDF_MC_EDGE_TABLE\[256\] = \{(.*?)\};", txt, re.S).group(1)
+    t = re.search(r"GSDF_MC_TRI_TABLE\[256 \* 16\] = \{(.*?)\};", txt, re.S).group(1)
+    edge = np.array([int(v, 16) for v in re.findall(r"0x[0-9a-f]+", e)])
+    tri = np.array([int(v) for v in re.findall(r"-?\d+", t)]).reshape(256, 16)
+    return edge, tri
+
+
+def test_device_marching_cubes_is_the_reference_sweep(pkg, O):
+    """gsdf_extract_mesh (one lane per voxel through the block map) against the ORACLE's restatement of
+    LayeredMarchingCubesNoColor::computeIsoSurface (two-layer sweep, classic edgeTable / triTable) on exactly the same
+    voxel values (the GPU's exported map loaded into the oracle): bit-identical triangle list, same order."""
+    for kind, W, H, vs in (("spheres", 160, 120, 0.02), ("tum", 320, 240, 0.01)):
+        seq = pkg.synth.Sequence(kind, W, H, n_frames=4, seed=2)
+        vsf = np.float32(vs)
+        g = pkg.GradSdf(vsf, np.float32(5) * vsf, W, H, seq.K, capacity_log2=21)
+        for i in range(seq.n):
+            g.update(*seq.frame(i))
+        keys, pay = g.export(sorted=True)
+        o = O.Oracle(vsf, np.float32(5) * vsf, W, H, seq.K)
+        o.set_map(keys, pay)
+        tg = g.extract_mesh()
+        to = o.extract_mesh()
+        assert tg.shape == to.shape and tg.shape[0] > 1000
+        assert np.array_equal(tg.view(np.uint32), to.view(np.uint32))
+        # the oracle-fused map gives (nearly) the same surface: same face count within 1 %
+        o2 = O.Oracle(vsf, np.float32(5) * vsf, W, H, seq.K)
+        for i in range(seq.n):
+            o2.update(*seq.frame(i))
+        assert abs(o2.extract_mesh().shape[0] - tg.shape[0]) <= 0.01 * tg.shape[0]
+        g.close()
+
+
+def test_extract_pc_rows_match_oracle(pkg, O, tmp_path):
+    """MapGradPixelSdf::extract_pc (MapGradPixelSdf.cpp:177-220) of the facade -- through the C wrapper the C4 runner
+    uses -- against the oracle's restatement on the same voxel values: same rows, same order."""
+    import ctypes, os, subprocess
+    from conftest import ROOT
+    host = os.path.join(ROOT, "gradient-sdf_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    seq = pkg.synth.Sequence("spheres", 160, 120, n_frames=16, seed=5, step_deg=0.5)
+    vs = np.float32(0.02)
+    g = pkg.GradSdf(vs, np.float32(5) * vs, 160, 120, seq.K, capacity_log2=19)
+    for i in range(seq.n):
+        g.update(*seq.frame(i))
+    hl = ctypes.CDLL(os.path.join(host, "libgsdf_host.so"))
+    hl.gsdf_host_extract_pc.restype = ctypes.c_long
+    hl.gsdf_host_extract_pc.argtypes = [ctypes.c_void_p, ctypes.c_float, ctypes.c_char_p]
+    path = str(tmp_path / "cloud.ply")
+    n = hl.gsdf_host_extract_pc(g.h, ctypes.c_float(vs), path.encode())
+    keys, pay = g.export(sorted=True)
+    o = O.Oracle(vs, np.float32(5) * vs, 160, 120, seq.K)
+    o.set_map(keys, pay)
+    rows = o.extract_pc()
+    assert n == rows.shape[0] and n > 50
+    lines = open(path).read().split("\n")
+    assert lines[0] == "ply" and lines[2] == "element vertex %d" % n
+    got = np.array([[float(v) for v in ln.split()] for ln in lines[10:10 + n]], np.float64)
+    # the file holds 6 significant digits (operator<< of float, as in the reference)
+    assert np.allclose(got, rows, rtol=6e-6, atol=1e-9)
+    g.close()
+
+
+def test_get_voxels_returns_the_stored_record(pkg, O):
+    """gsdf_get_voxels = tsdf_.at(idx) (getSdf, MapGradPixelSdf.h:127-129): dist, RAW gradient sum, weight of a voxel,
+    exactly the row of the export; missing voxels are flagged."""
+    seq, g, o = _mk(pkg, O, n=3)
+    for i in range(seq.n):
+        g.update(*seq.frame(i))
+    keys, pay = g.export(sorted=True)
+    rng = np.random.default_rng(3)
+    sel = rng.integers(0, len(keys), 500)
+    probe = np.concatenate([keys[sel], np.array([[10000, 10000, 10000], [-(1 << 21), 0, 0]], np.int32)])
+    got, found = g.get_voxels(probe)
+    assert found[:500].all() and not found[500:].any()
+    assert np.array_equal(got[:500].view(np.uint32), pay[sel].view(np.uint32))
+    assert (got[500:] == 0).all()
+    g.close()
