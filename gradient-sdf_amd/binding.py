@@ -123,12 +123,23 @@ def load(path=None):
         "gsdf_block_keys_dev": (C.c_int, [vp, vp, C.c_int64, C.POINTER(C.c_int64)]),
         "gsdf_pack_blocks_dev": (C.c_int, [vp, vp, C.c_int64, vp]),
         "gsdf_unpack_blocks_dev": (C.c_int, [vp, vp, C.c_int64, vp]),
+        "gsdf_merge_allreduce": (C.c_int, [vp, vp, i64p, i64p]),
+        "gsdf_merge_allreduce_with": (C.c_int, [vp, vp, i64p, i64p]),
+        "gsdf_rccl_unique_id": (C.c_int, [C.c_char_p]),
+        "gsdf_rccl_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.c_int, C.c_int]),
+        "gsdf_rccl_comm_destroy": (C.c_int, [vp]),
         "gsdf_raycast": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]),
         "gsdf_extract_mesh": (C.c_int, [vp, C.c_float, C.POINTER(C.c_int8), fp, C.c_int64, C.POINTER(C.c_int64)]),
         "gsdf_dev_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_int64]),
         "gsdf_dev_free": (C.c_int, [vp, vp]),
         "gsdf_dev_upload": (C.c_int, [vp, vp, vp, C.c_int64]),
         "gsdf_dev_download": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "gsdf_host_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_int64]),
+        "gsdf_host_free": (C.c_int, [vp, vp]),
+        "gsdf_dev_upload_async": (C.c_int, [vp, vp, vp, C.c_int64]),
+        "gsdf_mark": (C.c_int, [vp, i64p]),
+        "gsdf_mark_wait": (C.c_int, [vp, C.c_int64]),
+        "gsdf_mark_reached": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int)]),
         "gsdf_timer_start": (C.c_int, [vp]),
         "gsdf_timer_stop_ms": (C.c_int, [vp, fp]),
         "gsdf_profile": (C.c_int, [vp, C.c_int]),
@@ -150,10 +161,35 @@ ABI_SYMBOLS = [
     "gsdf_ba_setup", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
+    "gsdf_merge_allreduce", "gsdf_merge_allreduce_with", "gsdf_rccl_unique_id", "gsdf_rccl_comm_init", "gsdf_rccl_comm_destroy",
     "gsdf_query", "gsdf_get_voxels", "gsdf_raycast", "gsdf_extract_mesh",
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_dev_download", "gsdf_timer_start", "gsdf_timer_stop_ms",
+    "gsdf_host_alloc", "gsdf_host_free", "gsdf_dev_upload_async", "gsdf_mark", "gsdf_mark_wait", "gsdf_mark_reached",
     "gsdf_profile", "gsdf_profile_read",
 ]
+
+
+def rccl_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it and hands it to the other ranks)."""
+    L = load()
+    buf = C.create_string_buffer(128)
+    rc = L.gsdf_rccl_unique_id(buf)
+    if rc != GSDF_OK:
+        raise GsdfError(rc, L.gsdf_last_error().decode())
+    return buf.raw
+
+
+def rccl_comm_init(nranks, unique_id, rank, device):
+    L = load()
+    comm = C.c_void_p()
+    rc = L.gsdf_rccl_comm_init(C.byref(comm), int(nranks), unique_id, int(rank), int(device))
+    if rc != GSDF_OK:
+        raise GsdfError(rc, L.gsdf_last_error().decode())
+    return comm
+
+
+def rccl_comm_destroy(comm):
+    load().gsdf_rccl_comm_destroy(comm)
 
 
 def _f32(a):
@@ -368,6 +404,46 @@ class GradSdf:
 
     def unpack_blocks_dev(self, keys_ptr, n, dense_ptr):
         self._chk(self.L.gsdf_unpack_blocks_dev(self.h, C.c_void_p(keys_ptr), int(n), C.c_void_p(dense_ptr)))
+
+    # -- the exchange as one C call ---------------------------------------------------------------------
+    def merge_allreduce_rccl(self, comm):
+        """gsdf_merge_allreduce over an ncclComm_t (c_void_p from rccl_comm_init): (blocks in the union, bytes all-reduced)."""
+        nb, by = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.gsdf_merge_allreduce(self.h, comm, C.byref(nb), C.byref(by)))
+        return nb.value, by.value
+
+    def merge_allreduce_with(self, allgather, allreduce_sum, nranks):
+        """gsdf_merge_allreduce_with: the exchange over caller-provided collectives on host buffers.
+        allgather(send: np.uint8[bytes]) -> np.uint8[nranks * bytes];  allreduce_sum(buf: np.float32[n]) -> reduced copy."""
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
+        def ag(_user, send, recv, nbytes):
+            try:
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                out = np.ascontiguousarray(allgather(src.copy()), np.uint8).reshape(-1)
+                assert out.size == nbytes * nranks
+                C.memmove(recv, out.ctypes.data, out.size)
+                return 0
+            except Exception:            # noqa: BLE001 -- an exception must not cross the C boundary
+                return 1
+
+        def ar(_user, buf, n):
+            try:
+                a = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_float)), shape=(n,))
+                out = np.ascontiguousarray(allreduce_sum(a.copy()), np.float32).reshape(-1)
+                assert out.size == n
+                C.memmove(buf, out.ctypes.data, out.size * 4)
+                return 0
+            except Exception:            # noqa: BLE001
+                return 1
+
+        class Ops(C.Structure):
+            _fields_ = [("allgather", AG), ("allreduce_sum_f32", AR), ("user", C.c_void_p), ("nranks", C.c_int)]
+        ops = Ops(AG(ag), AR(ar), None, int(nranks))
+        nb, by = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.gsdf_merge_allreduce_with(self.h, C.byref(ops), C.byref(nb), C.byref(by)))
+        return nb.value, by.value
 
     def query(self, pts):
         p = _f32(pts).reshape(-1, 3)

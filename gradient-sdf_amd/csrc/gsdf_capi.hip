@@ -8,6 +8,7 @@
  */
 #include "../../include/gsdf.h"
 #include "../../include/gsdf_mc_tables.h"
+#include "gsdf_ctx.h"
 #include "gsdf_kernels.h"
 #include "gsdf_math.h"
 
@@ -22,96 +23,7 @@
 #include <string>
 #include <vector>
 
-static thread_local std::string g_err;
-
-static int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
-#define HIP_TRY(expr)                                                                            \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
-    } while (0)
-
-struct gsdf_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    /* MapGradPixelSdf / Sdf members */
-    float voxel_size = 0, voxel_size_inv = 0, T = 0, inv_T = 0;
-    float zmin = 0.5f, zmax = 3.5f;                /* Sdf.h:67-68 */
-    int factor = 0;
-    /* table */
-    int capacity_log2 = 0;
-    size_t n_slots = 0;
-    gsdf_table tab{ nullptr, 0 };
-    /* normal estimator + frame scratch */
-    int W = 0, H = 0, win = 0;
-    float K[9] = { 0 };
-    float* planes = nullptr;                       /* 11 planes */
-    float* depth_stage = nullptr;                  /* H2D staging for host-pointer entry points */
-    float* normals = nullptr;                      /* 3 planes */
-    /* tracker */
-    gsdf_dev_state* st = nullptr;
-    double* partials = nullptr;                    /* 3 rotating buffers of tracker partial sums */
-    unsigned int track_rot = 0;                    /* tracker launches issued so far, mod 3 (selects the sum buffers) */
-    int track_blocks = 0;
-    unsigned long long* blk_counters = nullptr;
-    int fuse_blocks = 0;
-    gsdf_deferred* deferred = nullptr;
-    unsigned int* deferred_count = nullptr;
-    unsigned int* fuse_ticket = nullptr;           /* arrivals of finished k_fuse workgroups (reset by the last one) */
-    unsigned int deferred_cap = 0;
-    unsigned int fuse_tag = 0;                     /* serial of the last fusion launch */
-    unsigned int* tile_flags = nullptr;            /* per-tile hand-off flags of k_fuse */
-    uint32_t* tile_order = nullptr;                /* launch order of the fusion tiles (gsdf_fuse_tile_order) */
-    uint32_t* vis = nullptr;                       /* optional vis_ bit-vectors, n_slots x vis_words */
-    int vis_words = 0;
-    /* PhotoBA (PhotometricOptimizer) */
-    int ba_n = 0;
-    float ba_reg = 10.f;
-    float* ba_images = nullptr;
-    float* ba_Rt = nullptr;                        /* device: n x 9 rotations then n x 3 translations */
-    int* ba_frame_idx = nullptr;
-    double* ba_block_E = nullptr;
-    float* ba_block_part = nullptr;
-    float* ba_Hb = nullptr;
-    std::vector<float> ba_R, ba_t;                 /* host copies of the keyframe poses being optimised */
-    unsigned int track_serial = 0;                 /* optimize() call counter */
-    volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */
-    unsigned int* progress_dev = nullptr;
-    int adaptive = 1;                              /* issue tracker passes in batches, following the device (see enqueue_track) */
-    int first_batch = 5, next_batch = 4;           /* launches per batch: 5 cover the usual <= 4 passes + their last head */
-    int debug = 0;                                 /* path-forcing / measurement switches (gsdf_debug_flags; test build only) */
-    float* frame_log = nullptr;
-    long long frame_log_cap = 0;
-    /* misc */
-    unsigned long long* counter = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[3];
-    std::vector<hipEvent_t> event_pool;
-    double prof_ms[3] = { 0, 0, 0 };
-    long long prof_n[3] = { 0, 0, 0 };
-
-    gsdf_frame_geom geom() const {
-        gsdf_frame_geom g;
-        g.W = W; g.H = H;
-        g.fx = K[0]; g.fy = K[4]; g.cx = K[2]; g.cy = K[5];
-        g.vs = voxel_size; g.inv_vs = voxel_size_inv; g.T = T; g.inv_T = inv_T;
-        g.zmin = zmin; g.zmax = zmax; g.factor = factor;
-        return g;
-    }
-    gsdf_ncache ncache() const {
-        const size_t N = (size_t)W * H;
-        gsdf_ncache nc;
-        nc.x0 = planes; nc.y0 = planes + N; nc.x0n = planes + 2 * N; nc.y0n = planes + 3 * N;
-        nc.ninv = planes + 4 * N; nc.q11 = planes + 5 * N; nc.q12 = planes + 6 * N; nc.q13 = planes + 7 * N;
-        nc.q22 = planes + 8 * N; nc.q23 = planes + 9 * N; nc.q33 = planes + 10 * N;
-        return nc;
-    }
-};
+static int fail(int code, const std::string& msg) { return gsdf_fail(code, msg); }
 
 namespace {
 
@@ -286,7 +198,7 @@ int read_state(gsdf_ctx* c, gsdf_dev_state* out) {
 
 extern "C" {
 
-const char* gsdf_last_error(void) { return g_err.c_str(); }
+const char* gsdf_last_error(void) { return g_gsdf_err.c_str(); }
 #ifdef GSDF_EXPERIMENTS
 /* Test / measurement build only (libgsdf_test.so, make EXPERIMENTS=1); not part of include/gsdf.h and absent from the
  * production library.  Per context.  Bits 0-15 go to k_fuse: 4 every tile defers, 256 single band, 512 four bands,
@@ -368,6 +280,8 @@ void gsdf_destroy(gsdf_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->mark_pool) (void)hipEventDestroy(e);
+    for (auto& m : c->marks) (void)hipEventDestroy(m.second);
     void* ptrs[] = { c->tab.vox, c->tab.bkeys, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
@@ -1038,6 +952,61 @@ int gsdf_dev_upload(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t by
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GSDF_OK;
+}
+
+/* ---- asynchronous frame staging (Scan3D: decode on host threads -> pinned buffer -> HBM, overlapped with the GPU) ---- */
+int gsdf_host_alloc(gsdf_ctx* c, void** host_ptr, int64_t bytes) {
+    if (!c || !host_ptr || bytes <= 0) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostMalloc(host_ptr, (size_t)bytes, hipHostMallocDefault));
+    return GSDF_OK;
+}
+int gsdf_host_free(gsdf_ctx* c, void* host_ptr) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostFree(host_ptr));
+    return GSDF_OK;
+}
+int gsdf_dev_upload_async(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes) {
+    if (!c || !dev_dst || !host_src || bytes < 0) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    return GSDF_OK;
+}
+int gsdf_mark(gsdf_ctx* c, int64_t* mark) {
+    if (!c || !mark) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t e = nullptr;
+    if (!c->mark_pool.empty()) { e = c->mark_pool.back(); c->mark_pool.pop_back(); }
+    else HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e, c->stream));
+    c->marks.push_back({ ++c->mark_serial, e });
+    *mark = c->mark_serial;
+    return GSDF_OK;
+}
+/* retire the marks up to `mark` (they complete in stream order); wait != 0 blocks until then */
+static int marks_reached(gsdf_ctx* c, int64_t mark, int wait, int* reached) {
+    *reached = 1;
+    while (!c->marks.empty() && c->marks.front().first <= mark) {
+        hipEvent_t e = c->marks.front().second;
+        hipError_t q = wait ? hipEventSynchronize(e) : hipEventQuery(e);
+        if (q == hipErrorNotReady) { *reached = 0; return GSDF_OK; }
+        if (q != hipSuccess) return fail(GSDF_ERR_HIP, std::string("gsdf mark: ") + hipGetErrorString(q));
+        c->mark_pool.push_back(e);
+        c->marks.pop_front();
+    }
+    return GSDF_OK;
+}
+int gsdf_mark_wait(gsdf_ctx* c, int64_t mark) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int r = 0;
+    return marks_reached(c, mark, 1, &r);
+}
+int gsdf_mark_reached(gsdf_ctx* c, int64_t mark, int* reached) {
+    if (!c || !reached) return fail(GSDF_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return marks_reached(c, mark, 0, reached);
 }
 
 int gsdf_timer_start(gsdf_ctx* c) {

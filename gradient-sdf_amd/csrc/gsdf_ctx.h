@@ -1,0 +1,112 @@
+/*
+ * gsdf_ctx.h -- the context behind the C-ABI handle (private to libgsdf.so: gsdf_capi.hip, gsdf_merge.hip).
+ */
+#ifndef GSDF_CTX_H_
+#define GSDF_CTX_H_
+
+#include "../../include/gsdf.h"
+#include "gsdf_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <deque>
+#include <string>
+#include <utility>
+#include <vector>
+
+inline thread_local std::string g_gsdf_err;
+
+inline int gsdf_fail(int code, const std::string& msg) {
+    g_gsdf_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return gsdf_fail(GSDF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+struct gsdf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    /* MapGradPixelSdf / Sdf members */
+    float voxel_size = 0, voxel_size_inv = 0, T = 0, inv_T = 0;
+    float zmin = 0.5f, zmax = 3.5f;                /* Sdf.h:67-68 */
+    int factor = 0;
+    /* table */
+    int capacity_log2 = 0;
+    size_t n_slots = 0;
+    gsdf_table tab{ nullptr, 0 };
+    /* normal estimator + frame scratch */
+    int W = 0, H = 0, win = 0;
+    float K[9] = { 0 };
+    float* planes = nullptr;                       /* 11 planes */
+    float* depth_stage = nullptr;                  /* H2D staging for host-pointer entry points */
+    float* normals = nullptr;                      /* 3 planes */
+    /* tracker */
+    gsdf_dev_state* st = nullptr;
+    double* partials = nullptr;                    /* 3 rotating buffers of tracker partial sums */
+    unsigned int track_rot = 0;                    /* tracker launches issued so far, mod 3 (selects the sum buffers) */
+    int track_blocks = 0;
+    unsigned long long* blk_counters = nullptr;
+    int fuse_blocks = 0;
+    gsdf_deferred* deferred = nullptr;
+    unsigned int* deferred_count = nullptr;
+    unsigned int* fuse_ticket = nullptr;           /* arrivals of finished k_fuse workgroups (reset by the last one) */
+    unsigned int deferred_cap = 0;
+    unsigned int fuse_tag = 0;                     /* serial of the last fusion launch */
+    unsigned int* tile_flags = nullptr;            /* per-tile hand-off flags of k_fuse */
+    uint32_t* tile_order = nullptr;                /* launch order of the fusion tiles (gsdf_fuse_tile_order) */
+    uint32_t* vis = nullptr;                       /* optional vis_ bit-vectors, n_slots x vis_words */
+    int vis_words = 0;
+    /* PhotoBA (PhotometricOptimizer) */
+    int ba_n = 0;
+    float ba_reg = 10.f;
+    float* ba_images = nullptr;
+    float* ba_Rt = nullptr;                        /* device: n x 9 rotations then n x 3 translations */
+    int* ba_frame_idx = nullptr;
+    double* ba_block_E = nullptr;
+    float* ba_block_part = nullptr;
+    float* ba_Hb = nullptr;
+    std::vector<float> ba_R, ba_t;                 /* host copies of the keyframe poses being optimised */
+    unsigned int track_serial = 0;                 /* optimize() call counter */
+    volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */
+    unsigned int* progress_dev = nullptr;
+    int adaptive = 1;                              /* issue tracker passes in batches, following the device (see enqueue_track) */
+    int first_batch = 5, next_batch = 4;           /* launches per batch: 5 cover the usual <= 4 passes + their last head */
+    int debug = 0;                                 /* path-forcing / measurement switches (gsdf_debug_flags; test build only) */
+    float* frame_log = nullptr;
+    long long frame_log_cap = 0;
+    /* misc */
+    unsigned long long* counter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[3];
+    std::vector<hipEvent_t> event_pool;
+    /* gsdf_mark: events recorded on the stream, retired in order */
+    std::deque<std::pair<long long, hipEvent_t>> marks;
+    std::vector<hipEvent_t> mark_pool;
+    long long mark_serial = 0;
+    double prof_ms[3] = { 0, 0, 0 };
+    long long prof_n[3] = { 0, 0, 0 };
+
+    gsdf_frame_geom geom() const {
+        gsdf_frame_geom g;
+        g.W = W; g.H = H;
+        g.fx = K[0]; g.fy = K[4]; g.cx = K[2]; g.cy = K[5];
+        g.vs = voxel_size; g.inv_vs = voxel_size_inv; g.T = T; g.inv_T = inv_T;
+        g.zmin = zmin; g.zmax = zmax; g.factor = factor;
+        return g;
+    }
+    gsdf_ncache ncache() const {
+        const size_t N = (size_t)W * H;
+        gsdf_ncache nc;
+        nc.x0 = planes; nc.y0 = planes + N; nc.x0n = planes + 2 * N; nc.y0n = planes + 3 * N;
+        nc.ninv = planes + 4 * N; nc.q11 = planes + 5 * N; nc.q12 = planes + 6 * N; nc.q13 = planes + 7 * N;
+        nc.q22 = planes + 8 * N; nc.q23 = planes + 9 * N; nc.q33 = planes + 10 * N;
+        return nc;
+    }
+};
+
+#endif /* GSDF_CTX_H_ */

@@ -27,6 +27,12 @@ void MapGradPixelSdf::ensure_frame(const DepthImage& depth, const Mat3f& K, Norm
     frame_w_ = depth.cols; frame_h_ = depth.rows;
 }
 
+void MapGradPixelSdf::prepare(int W, int H, const Mat3f& K, NormalEstimator* NEst) {
+    if (frame_w_ == W && frame_h_ == H) return;
+    check(gsdf_normals_init(ctx_, W, H, NEst ? NEst->K.data() : K.data(), NEst ? NEst->window : 11), "gsdf_normals_init");
+    frame_w_ = W; frame_h_ = H;
+}
+
 void MapGradPixelSdf::update(const ColorImage&, const DepthImage& depth, const Mat3f K, const SE3& pose,
                              NormalEstimator* NEst) {
     if (!NEst) {   /* MapGradPixelSdf.cpp:55-58 */

@@ -55,6 +55,9 @@ public:
     bool save_sdf(std::string filename) override;                      /* MapGradPixelSdf.cpp:222-296 */
     bool extract_mesh(std::string filename) override;                  /* MapGradPixelSdf.cpp:124-175 */
 
+    /* fix the frame size / intrinsics / normal-estimator window before driving the *_dev entries directly (update() does
+     * it on the first frame) */
+    void prepare(int W, int H, const Mat3f& K, NormalEstimator* NEst);
     gsdf_ctx* handle() const { return ctx_; }
     float voxel_size() const { return voxel_size_; }
 

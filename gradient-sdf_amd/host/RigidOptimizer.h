@@ -20,6 +20,9 @@ public:
     void set_num_iterations(int n) { num_iterations_ = n; }            /* :85-97 */
     void set_conv_threshold(float c) { conv_threshold_ = c; }
     void set_damping(float d) { damping_ = d; }
+    int num_iterations() const { return num_iterations_; }
+    float conv_threshold() const { return conv_threshold_; }
+    float damping() const { return damping_; }
     void set_pose(SE3 pose) { pose_ = pose; }                          /* :99 */
     SE3 pose() { return pose_; }                                       /* :101-103 */
     virtual bool optimize(const DepthImage& depth, const Mat3f K) = 0; /* :106 */

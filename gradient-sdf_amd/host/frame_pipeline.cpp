@@ -1,0 +1,126 @@
+#include "frame_pipeline.h"
+
+#include <algorithm>
+
+FramePipeline::FramePipeline(gsdf_ctx* ctx, const ImageLoader* loader, std::vector<FrameEntry> entries, int W, int H, int threads,
+                             int slots)
+    : ctx_(ctx), loader_(loader), entries_(std::move(entries)), W_(W), H_(H) {
+    if (threads <= 0) threads = (int)std::min<unsigned>(16u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    if (slots <= 0) slots = 2 * threads + 4;
+    slots = (int)std::min<size_t>((size_t)slots, std::max<size_t>(entries_.size(), 1));
+    slots_.resize((size_t)slots);
+    const int64_t bytes = (int64_t)W_ * H_ * (int64_t)sizeof(float);
+    for (Slot& s : slots_) {
+        void *h = nullptr, *d = nullptr;
+        if (gsdf_host_alloc(ctx_, &h, bytes) != GSDF_OK || gsdf_dev_alloc(ctx_, &d, bytes) != GSDF_OK) {
+            error_ = std::string("frame staging buffers: ") + gsdf_last_error();
+            if (h) gsdf_host_free(ctx_, h);
+            break;
+        }
+        s.host = (float*)h; s.dev = (float*)d;
+    }
+    if (error_.empty())
+        for (int t = 0; t < threads; ++t) threads_.emplace_back(&FramePipeline::worker, this);
+}
+
+FramePipeline::~FramePipeline() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    for (std::thread& t : threads_) t.join();
+    gsdf_sync(ctx_);                                   /* nothing on the stream reads the buffers any more */
+    for (Slot& s : slots_) {
+        if (s.host) gsdf_host_free(ctx_, s.host);
+        if (s.dev) gsdf_dev_free(ctx_, s.dev);
+    }
+}
+
+/* decoder: claim the next frame whose slot (frame % slots) is free, decode into the slot's pinned buffer */
+void FramePipeline::worker() {
+    for (;;) {
+        size_t f;
+        Slot* s;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || next_decode_ >= entries_.size() || slots_[next_decode_ % slots_.size()].state == FREE; });
+            if (stop_ || next_decode_ >= entries_.size()) return;
+            f = next_decode_++;
+            s = &slots_[f % slots_.size()];
+            s->state = DECODING;
+            s->frame = f;
+        }
+        std::string err;
+        const bool ok = loader_->decode_depth(entries_[f].depth_file, s->host, W_, H_, &err);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            s->state = ok ? FILLED : FAILED;
+            if (!ok && error_.empty()) error_ = err;
+        }
+        cv_.notify_all();
+    }
+}
+
+/* slots whose frame the stream has finished with go back to the decoders (called with mu_ NOT held) */
+void FramePipeline::reclaim(bool block_oldest) {
+    bool freed = false;
+    for (;;) {
+        Slot* oldest = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (Slot& s : slots_)
+                if (s.state == INFLIGHT && (!oldest || s.mark < oldest->mark)) oldest = &s;
+        }
+        if (!oldest) break;
+        int reached = 0;
+        if (block_oldest) { if (gsdf_mark_wait(ctx_, oldest->mark) != GSDF_OK) break; reached = 1; block_oldest = false; }
+        else if (gsdf_mark_reached(ctx_, oldest->mark, &reached) != GSDF_OK || !reached) break;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            oldest->state = FREE;
+        }
+        freed = true;
+    }
+    if (freed) cv_.notify_all();
+}
+
+const float* FramePipeline::next(size_t* index) {
+    if (!error_.empty() || next_deliver_ >= entries_.size()) return nullptr;
+    const size_t f = next_deliver_;
+    Slot& s = slots_[f % slots_.size()];
+    for (;;) {
+        reclaim(false);
+        std::unique_lock<std::mutex> lk(mu_);
+        if ((s.state == FILLED || s.state == FAILED) && s.frame == f) break;
+        if (s.state == INFLIGHT) {                     /* the ring is full of frames the GPU still owns: wait for the oldest */
+            lk.unlock();
+            reclaim(true);
+            continue;
+        }
+        cv_.wait_for(lk, std::chrono::milliseconds(2));
+    }
+    if (s.state == FAILED) { next_deliver_ = entries_.size(); return nullptr; }
+    if (gsdf_dev_upload_async(ctx_, s.dev, s.host, (int64_t)W_ * H_ * (int64_t)sizeof(float)) != GSDF_OK) {
+        error_ = std::string("upload: ") + gsdf_last_error();
+        return nullptr;
+    }
+    last_slot_ = (long)(f % slots_.size());
+    ++next_deliver_;
+    if (index) *index = f;
+    return s.dev;
+}
+
+bool FramePipeline::submitted() {
+    if (last_slot_ < 0) return false;
+    Slot& s = slots_[(size_t)last_slot_];
+    int64_t m = 0;
+    if (gsdf_mark(ctx_, &m) != GSDF_OK) { error_ = std::string("mark: ") + gsdf_last_error(); return false; }
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        s.mark = m;
+        s.state = INFLIGHT;
+    }
+    last_slot_ = -1;
+    return true;
+}

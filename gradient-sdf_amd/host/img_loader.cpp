@@ -28,6 +28,21 @@ bool ImageLoader::load_depth(const std::string& filename, DepthImage& depth) {
     return true;
 }
 
+bool ImageLoader::decode_depth(const std::string& filename, float* dst, int W, int H, std::string* err) const {
+    PngImage img;
+    std::string e;
+    if (filename.empty() || !png_read(path_ + filename, img, &e)) {
+        if (err) *err = "empty depth image " + path_ + filename + " (" + e + ")";
+        return false;
+    }
+    if (img.width != W || img.height != H) {
+        if (err) *err = "frame size of " + filename + " differs from --width/--height";
+        return false;
+    }
+    for (size_t i = 0; i < img.first_channel.size(); ++i) dst[i] = (float)img.first_channel[i] * unit_;   /* convertTo(CV_32FC1, unit_) */
+    return true;
+}
+
 bool ImageLoader::load_pose(const std::string& filename, std::vector<Mat4f>& poses) {
     std::ifstream file(filename.c_str());
     if (!file.is_open()) { std::cout << "can't load poses!" << std::endl; return false; }
@@ -56,6 +71,29 @@ bool SynthLoader::load_next(ColorImage&, DepthImage& depth) {
     if (!load_depth("depth/" + timestamp_rgb_ + ".png", depth)) return false;
     ++counter_;
     return true;
+}
+
+bool SynthLoader::next_entry(std::string& depth_file, std::string& timestamp) {
+    std::stringstream ss;
+    ss << std::setfill('0') << std::setw(3) << counter_;
+    timestamp_rgb_ = ss.str();
+    timestamp_depth_ = timestamp_rgb_;
+    depth_file = "depth/" + timestamp_rgb_ + ".png";
+    timestamp = timestamp_depth_;
+    std::ifstream probe(path_ + depth_file);
+    if (!probe.is_open()) return false;
+    ++counter_;
+    return true;
+}
+
+bool TumrgbdLoader::next_entry(std::string& depth_file, std::string& timestamp) {
+    std::string line = "#", rgb_file;
+    while (line.empty() || line.at(0) == '#')
+        if (!std::getline(assoc_, line)) return false;
+    std::istringstream ss(line);
+    ss >> timestamp_rgb_ >> rgb_file >> timestamp_depth_ >> depth_file;
+    timestamp = timestamp_depth_;
+    return !depth_file.empty();
 }
 
 bool TumrgbdLoader::load_next(ColorImage&, DepthImage& depth) {

@@ -25,6 +25,10 @@ public:
     std::string rgb_timestamp() const { return timestamp_rgb_; }
     bool load_intrinsics(const std::string& filename = "intrinsics.txt");
     bool load_depth(const std::string& filename, DepthImage& depth);
+    /* the same decode into a caller's buffer of W x H floats; no member is modified: callable from several threads */
+    bool decode_depth(const std::string& filename, float* dst, int W, int H, std::string* err) const;
+    /* advance to the next frame WITHOUT decoding it: its depth file (relative to the directory) and depth timestamp */
+    virtual bool next_entry(std::string& depth_file, std::string& timestamp) = 0;
     static bool load_pose(const std::string& filename, std::vector<Mat4f>& poses);
     virtual bool load_next(ColorImage& color, DepthImage& depth) = 0;
     virtual void reset() = 0;
@@ -35,6 +39,7 @@ class SynthLoader : public ImageLoader {       /* unit 1/1000, files depth/001.p
 public:
     explicit SynthLoader(const std::string& path) : ImageLoader(1.f / 1000, path) {}
     bool load_next(ColorImage& color, DepthImage& depth) override;
+    bool next_entry(std::string& depth_file, std::string& timestamp) override;
     void reset() override { counter_ = 1; }
 };
 
@@ -43,6 +48,7 @@ class TumrgbdLoader : public ImageLoader {     /* unit 1/5000, associated.txt */
 public:
     explicit TumrgbdLoader(const std::string& path) : ImageLoader(1.f / 5000, path) { assoc_.open(path_ + "associated.txt"); }
     bool load_next(ColorImage& color, DepthImage& depth) override;
+    bool next_entry(std::string& depth_file, std::string& timestamp) override;
     void reset() override { assoc_.close(); assoc_.open(path_ + "associated.txt"); }
 };
 

@@ -1,32 +1,53 @@
 /*
  * Scan3D -- the depth-scanning CLI of the reference (cpp/depth_scanning/src/main_scan_3d.cpp) on
  * top of the MI355X engine.  Same flags (--input --results --pose-file --first --last --scan-type
- * --data-type --voxel-size --trunc --save-sdf), same frame loop (GT-pose fusion or track+fuse,
+ * --data-type --voxel-size --trunc --save-sdf), same frame loop semantics (GT-pose fusion or track+fuse,
  * :208-281), same outputs (<results>_poses.txt in TUM format, <results>gradient_sdf_mesh_final.ply,
  * _cloud_final.ply, optional sdf text files, :285-311) and the Timer labels.  New flags:
- * --width/--height (the reference hard-codes 640x480, :183), --hash-capacity (log2 slots), --device.
+ *   --width/--height (the reference hard-codes 640x480, :183), --hash-capacity (log2 slots), --device,
+ *   --sync            the reference's call structure literally: one blocking optimize() / update() per frame through the
+ *                     facade classes (host-pointer entries; every call copies the frame and waits for the GPU);
+ *   (default)         the device-resident loop: PNG decode on host threads into page-locked buffers, asynchronous copy
+ *                     to HBM, gsdf_track_and_fuse_dev / gsdf_update_dev enqueued per frame, poses read back once at
+ *                     the end (frame_pipeline.h) -- same poses and map as --sync;
+ *   --decode-threads  host threads of the PNG decode (default: half the cores, at most 16);
+ *   --gpus N          GT-pose fusion sharded over N ranks, one process per GPU (main_scan_3d.cpp:250-254 has no frame-to-
+ *                     frame dependence): contiguous frame ranges, ONE exchange (gsdf_merge_allreduce: RCCL all-reduce of
+ *                     the per-voxel sums over the union of blocks), then rank 0 writes the outputs.  Tracked mode does
+ *                     not shard (frame i needs the map of all frames < i);
+ *   --transport shm   the exchange through host shared memory instead of RCCL: N ranks on ONE device (test boxes).
  * Only --scan-type grad-sdf exists here: base-sdf is the comparison method, out of scope.
  */
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <limits>
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 
 #include "MapGradPixelSdf.h"
 #include "RigidOptimizer.h"
 #include "Timer.h"
+#include "frame_pipeline.h"
 #include "img_loader.h"
+#include "shm_collective.h"
 
 namespace {
 struct Options {
     std::string input, output = "../results/", pose_file = "pose.txt", stype = "map-gp", dtype;
     size_t first = 0, last = std::numeric_limits<size_t>::max();
     float voxel_size = 0.01f, trunc = 5.f;
-    bool save_sdf = false;
+    bool save_sdf = false, sync = false;
     int width = 640, height = 480, capacity_log2 = 22, device = 0;
+    int gpus = 1, rank = -1, decode_threads = 0;
+    std::string transport = "rccl", rendezvous;
 };
 
 bool parse(int argc, char** argv, Options& o) {
@@ -35,9 +56,11 @@ bool parse(int argc, char** argv, Options& o) {
         auto val = [&](std::string& dst) { if (i + 1 >= argc) return false; dst = argv[++i]; return true; };
         std::string v;
         if (a == "--save-sdf") { o.save_sdf = true; continue; }
+        if (a == "--sync") { o.sync = true; continue; }
         if (a == "-h" || a == "--help") {
             std::cout << "Hash Table-Based 3D Scanning (MI355X)\n  --input --results --pose-file --first --last --scan-type"
-                         " --data-type --voxel-size --trunc --save-sdf --width --height --hash-capacity --device\n";
+                         " --data-type --voxel-size --trunc --save-sdf --width --height --hash-capacity --device"
+                         " --sync --decode-threads --gpus --transport rccl|shm\n";
             std::exit(0);
         }
         if (!val(v)) { std::cerr << "missing value for " << a << std::endl; return false; }
@@ -54,8 +77,101 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "--height") o.height = std::stoi(v);
         else if (a == "--hash-capacity") o.capacity_log2 = std::stoi(v);
         else if (a == "--device") o.device = std::stoi(v);
+        else if (a == "--gpus") o.gpus = std::stoi(v);
+        else if (a == "--rank") o.rank = std::stoi(v);                 /* set by the launcher */
+        else if (a == "--rendezvous") o.rendezvous = v;                /* set by the launcher */
+        else if (a == "--transport") o.transport = v;
+        else if (a == "--decode-threads") o.decode_threads = std::stoi(v);
         else { std::cerr << "unknown option " << a << std::endl; return false; }
     }
+    return true;
+}
+
+/* --gpus N: one process per rank (started before anything touches the GPU); the ranks meet in a /dev/shm segment */
+int launch_ranks(int argc, char** argv, const Options& opt) {
+    const std::string name = "gsdf_scan3d_" + std::to_string((long)getpid());
+    if (!ShmCollective::create(name, opt.gpus)) { std::cerr << "cannot create the rendezvous segment" << std::endl; return 1; }
+    std::remove(("/dev/shm/" + name + ".id").c_str());
+    std::vector<pid_t> kids;
+    for (int r = 0; r < opt.gpus; ++r) {
+        const pid_t pid = fork();
+        if (pid == 0) {
+            std::vector<std::string> args(argv, argv + argc);
+            args.push_back("--rank"); args.push_back(std::to_string(r));
+            args.push_back("--rendezvous"); args.push_back(name);
+            std::vector<char*> av;
+            for (std::string& a : args) av.push_back(&a[0]);
+            av.push_back(nullptr);
+            execv("/proc/self/exe", av.data());
+            std::perror("execv");
+            _exit(127);
+        }
+        if (pid < 0) { std::perror("fork"); return 1; }
+        kids.push_back(pid);
+    }
+    int worst = 0;
+    for (pid_t pid : kids) {
+        int st = 0;
+        waitpid(pid, &st, 0);
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
+        if (code > worst) worst = code;
+    }
+    ShmCollective::destroy(name);
+    std::remove(("/dev/shm/" + name + ".id").c_str());
+    return worst;
+}
+
+/* [lo, hi) of `rank` among `world` contiguous shards of n items */
+void shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi) {
+    const size_t base = n / (size_t)world, rem = n % (size_t)world;
+    *lo = (size_t)rank * base + std::min<size_t>((size_t)rank, rem);
+    *hi = *lo + base + ((size_t)rank < rem ? 1 : 0);
+}
+
+void write_pose_line(std::ofstream& f, const std::string& ts, const Mat4f& p) {
+    /* timestamp tx ty tz qx qy qz qw (main_scan_3d.cpp:268-280); the quaternion is Eigen::Quaternion(R) of the pose matrix */
+    float R[9], q[4];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = p(r, c);
+    gsdf_R_to_quat(R, q);
+    f << ts << " " << p(0, 3) << " " << p(1, 3) << " " << p(2, 3) << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
+}
+
+/* the exchange step of --gpus N */
+bool exchange(gsdf_ctx* ctx, const Options& opt, int device) {
+    int64_t n_blocks = 0, bytes = 0;
+    if (opt.transport == "shm") {
+        ShmCollective sc(opt.rendezvous, opt.gpus, opt.rank);
+        if (!sc.ok()) { std::cerr << "rank " << opt.rank << ": rendezvous segment missing" << std::endl; return false; }
+        gsdf_collective ops = sc.ops();
+        if (gsdf_merge_allreduce_with(ctx, &ops, &n_blocks, &bytes) != GSDF_OK) { std::cerr << "exchange: " << gsdf_last_error() << std::endl; return false; }
+    } else {
+        /* rank 0 creates the RCCL id and publishes it as a file next to the rendezvous segment */
+        const std::string idf = "/dev/shm/" + opt.rendezvous + ".id";
+        char id[128];
+        if (opt.rank == 0) {
+            if (gsdf_rccl_unique_id(id) != GSDF_OK) { std::cerr << "RCCL: " << gsdf_last_error() << std::endl; return false; }
+            { std::ofstream f(idf + ".tmp", std::ios::binary); f.write(id, 128); }
+            std::rename((idf + ".tmp").c_str(), idf.c_str());
+        } else {
+            bool got = false;
+            for (int t = 0; t < 60000 && !got; ++t) {
+                std::ifstream f(idf, std::ios::binary);
+                got = (bool)f.read(id, 128);
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+            if (!got) { std::cerr << "rank " << opt.rank << ": no RCCL id from rank 0" << std::endl; return false; }
+        }
+        void* comm = nullptr;
+        if (gsdf_rccl_comm_init(&comm, opt.gpus, id, opt.rank, device) != GSDF_OK) { std::cerr << "RCCL: " << gsdf_last_error() << std::endl; return false; }
+        Timer T;
+        T.tic();
+        const int rc = gsdf_merge_allreduce(ctx, comm, &n_blocks, &bytes);
+        if (opt.rank == 0) T.toc("Exchange without communicator set-up");
+        gsdf_rccl_comm_destroy(comm);
+        if (rc != GSDF_OK) { std::cerr << "exchange: " << gsdf_last_error() << std::endl; return false; }
+    }
+    if (opt.rank == 0)
+        std::cout << "Exchanged " << n_blocks << " voxel blocks (" << bytes / 1048576.0 << " MiB all-reduced) among " << opt.gpus << " ranks" << std::endl;
     return true;
 }
 } // namespace
@@ -64,6 +180,10 @@ int main(int argc, char* argv[]) {
     Timer T;
     Options opt;
     if (!parse(argc, argv, opt)) return 1;
+    if (opt.gpus > 1 && opt.rank < 0) return launch_ranks(argc, argv, opt);      /* the launcher itself never touches the GPU */
+    const bool sharded = opt.gpus > 1;
+    const bool lead = !sharded || opt.rank == 0;                                  /* writes the outputs */
+    if (sharded && opt.transport != "shm") opt.device = opt.rank;                 /* one GPU per rank */
 
     if (opt.stype != "grad-sdf") {           /* the default "map-gp" is rejected like in the reference (:105-114) */
         std::cerr << "Your specified scan type is not supported (yet)." << std::endl;
@@ -81,74 +201,158 @@ int main(int argc, char* argv[]) {
         return 1;
     }
     const Mat3f K = loader->K();
-    std::cout << "K: " << std::endl;
-    for (int r = 0; r < 3; ++r) std::cout << K(r, 0) << " " << K(r, 1) << " " << K(r, 2) << std::endl;
+    if (lead) {
+        std::cout << "K: " << std::endl;
+        for (int r = 0; r < 3; ++r) std::cout << K(r, 0) << " " << K(r, 1) << " " << K(r, 2) << std::endl;
+    }
 
     std::vector<Mat4f> poses;
     bool GT_pose = false;
     if (!ImageLoader::load_pose(opt.input + opt.pose_file, poses)) std::cerr << "No GT poses are avaible!" << std::endl;
-    else { std::cout << poses.size() << " GT poses are loaded!" << std::endl; GT_pose = true; }
+    else { if (lead) std::cout << poses.size() << " GT poses are loaded!" << std::endl; GT_pose = true; }
+    if (sharded && !GT_pose) {
+        std::cerr << "--gpus needs GT poses: tracked frames depend on the map of all earlier frames and cannot be sharded" << std::endl;
+        return 1;
+    }
 
     T.tic();
     NormalEstimator NEst(opt.width, opt.height, K, 2 * 5 + 1);                         /* :183 */
-    T.toc("Init normal estimation");
+    if (lead) T.toc("Init normal estimation");
 
     const float truncation = opt.trunc * opt.voxel_size;                              /* :191 */
     std::unique_ptr<MapGradPixelSdf> tSDF;
     std::unique_ptr<RigidPointOptimizer> pOpt;
-    std::ofstream pose_file(opt.output + "_poses.txt");
 
-    ColorImage color;
-    DepthImage depth;
-    for (size_t i = 0; i < opt.first; ++i) loader->load_next(color, depth);           /* :203-205 */
-
-    for (size_t i = opt.first; i <= opt.last; ++i) {
-        std::cout << "Working on frame: " << i << std::endl;
-        T.tic();
-        const bool loaded = loader->load_next(color, depth);
-        if (!loaded) std::cerr << " -> Frame " << i << " could not be loaded!" << std::endl;
-        T.toc("Load data");
-        if (!loaded) break;
-        if (depth.cols != opt.width || depth.rows != opt.height) {
-            std::cerr << "frame size " << depth.cols << "x" << depth.rows << " differs from --width/--height" << std::endl;
-            return 1;
-        }
-        if (i == opt.first) {
+    if (opt.sync && !sharded) {
+        /* ---- the reference's call structure: blocking optimize() / update() per frame through the facade ---- */
+        std::ofstream pose_file(opt.output + "_poses.txt");
+        ColorImage color;
+        DepthImage depth;
+        for (size_t i = 0; i < opt.first; ++i) loader->load_next(color, depth);           /* :203-205 */
+        for (size_t i = opt.first; i <= opt.last; ++i) {
+            std::cout << "Working on frame: " << i << std::endl;
             T.tic();
-            tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device));
-            T.toc("Create Sdf");
-            T.tic();
-            if (GT_pose) tSDF->update(color, depth, K, SE3(poses[0]), &NEst);          /* poses[0] even if --first > 0 (:242) */
-            else tSDF->setup(color, depth, K, &NEst);
-            T.toc("Integrate depth data into Sdf");
-            T.tic();
-            pOpt.reset(new RigidPointOptimizer(tSDF.get()));
-            T.toc("Create RigidOptimizer");
-        } else if (GT_pose) {
-            if (i >= poses.size()) break;
-            T.tic();
-            tSDF->update(color, depth, K, SE3(poses[i]), &NEst);
-            T.toc("Integrate depth data into Sdf");
-        } else {
-            T.tic();
-            const bool conv = pOpt->optimize(depth, K);
-            T.toc("Point optimization");
-            if (conv) {                                                                /* :261-265 */
+            const bool loaded = loader->load_next(color, depth);
+            if (!loaded) std::cerr << " -> Frame " << i << " could not be loaded!" << std::endl;
+            T.toc("Load data");
+            if (!loaded) break;
+            if (depth.cols != opt.width || depth.rows != opt.height) {
+                std::cerr << "frame size " << depth.cols << "x" << depth.rows << " differs from --width/--height" << std::endl;
+                return 1;
+            }
+            if (i == opt.first) {
                 T.tic();
-                tSDF->update(color, depth, K, pOpt->pose(), &NEst);
+                tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device));
+                T.toc("Create Sdf");
+                T.tic();
+                if (GT_pose) tSDF->update(color, depth, K, SE3(poses[0]), &NEst);          /* poses[0] even if --first > 0 (:242) */
+                else tSDF->setup(color, depth, K, &NEst);
                 T.toc("Integrate depth data into Sdf");
+                T.tic();
+                pOpt.reset(new RigidPointOptimizer(tSDF.get()));
+                T.toc("Create RigidOptimizer");
+            } else if (GT_pose) {
+                if (i >= poses.size()) break;
+                T.tic();
+                tSDF->update(color, depth, K, SE3(poses[i]), &NEst);
+                T.toc("Integrate depth data into Sdf");
+            } else {
+                T.tic();
+                const bool conv = pOpt->optimize(depth, K);
+                T.toc("Point optimization");
+                if (conv) {                                                                /* :261-265 */
+                    T.tic();
+                    tSDF->update(color, depth, K, pOpt->pose(), &NEst);
+                    T.toc("Integrate depth data into Sdf");
+                }
+            }
+            write_pose_line(pose_file, loader->depth_timestamp(), (GT_pose && i < poses.size()) ? poses[i] : pOpt->pose().matrix());
+        }
+        pose_file.close();
+        if (!tSDF) { std::cerr << "no frame was processed" << std::endl; return 1; }
+    } else {
+        /* ---- the device-resident loop ------------------------------------------------------------------------
+         * The frame list first (the loaders advance through their index files without decoding), then: decode on host
+         * threads -> page-locked buffer -> asynchronous copy to HBM -> the frame's kernels, all enqueued; the host
+         * never waits for a frame.  Poses of tracked frames come back in ONE read of the device's frame log. */
+        std::vector<FrameEntry> all;
+        {
+            std::string f, ts;
+            for (size_t i = 0; i < opt.first; ++i) if (!loader->next_entry(f, ts)) break;  /* :203-205 */
+            for (size_t i = opt.first; i <= opt.last; ++i) {
+                if (GT_pose && i > opt.first && i >= poses.size()) break;                  /* :251 */
+                if (!loader->next_entry(f, ts)) break;
+                all.push_back(FrameEntry{ f, ts });
             }
         }
-        /* timestamp tx ty tz qx qy qz qw (:268-280); the quaternion is Eigen::Quaternion(R) of the pose matrix */
-        const Mat4f p = (GT_pose && i < poses.size()) ? poses[i] : pOpt->pose().matrix();
-        float R[9], q[4];
-        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[3 * r + c] = p(r, c);
-        gsdf_R_to_quat(R, q);
-        pose_file << loader->depth_timestamp() << " " << p(0, 3) << " " << p(1, 3) << " " << p(2, 3) << " "
-                  << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
+        if (all.empty()) { std::cerr << " -> Frame " << opt.first << " could not be loaded!" << std::endl << "no frame was processed" << std::endl; return 1; }
+        size_t lo = 0, hi = all.size();
+        if (sharded) shard_range(all.size(), opt.rank, opt.gpus, &lo, &hi);
+        T.tic();
+        tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device));
+        if (lead) T.toc("Create Sdf");
+        tSDF->prepare(opt.width, opt.height, K, &NEst);
+        gsdf_ctx* ctx = tSDF->handle();
+        T.tic();
+        pOpt.reset(new RigidPointOptimizer(tSDF.get()));
+        if (lead) T.toc("Create RigidOptimizer");
+        const auto t_loop = std::chrono::steady_clock::now();
+        {
+            FramePipeline pipe(ctx, loader.get(), std::vector<FrameEntry>(all.begin() + (long)lo, all.begin() + (long)hi), opt.width,
+                               opt.height, opt.decode_threads);
+            for (size_t j = lo; j < hi; ++j) {
+                const size_t i = opt.first + j;                       /* frame number as in the reference's loop */
+                if (lead) std::cout << "Working on frame: " << i << std::endl;
+                T.tic();
+                size_t got = 0;
+                const float* d = pipe.next(&got);
+                if (lead) T.toc("Load data");
+                if (!d) { std::cerr << " -> Frame " << i << " could not be loaded! " << pipe.error() << std::endl; break; }
+                T.tic();
+                int rc;
+                if (j == 0 || GT_pose) {
+                    /* first frame: poses[0] (even if --first > 0, :242) or setup() at the identity (Sdf.h:119-121) */
+                    const SE3 p = GT_pose ? SE3(poses[j == 0 ? 0 : i]) : SE3();
+                    const Mat3f R = p.rotationMatrix();
+                    const Vec3f t = p.translation();
+                    rc = gsdf_update_dev(ctx, d, R.data(), t.data());                                  /* :242-243, :252 */
+                    if (lead) T.toc("Integrate depth data into Sdf");
+                } else {
+                    rc = gsdf_track_and_fuse_dev(ctx, d, K.data(), pOpt->num_iterations(), pOpt->conv_threshold(), pOpt->damping());   /* :258-265 */
+                    if (lead) T.toc("Point optimization + integration (enqueued)");
+                }
+                if (rc != GSDF_OK || !pipe.submitted()) { std::cerr << "frame " << i << ": " << gsdf_last_error() << std::endl; return 1; }
+            }
+            if (gsdf_sync(ctx) != GSDF_OK) { std::cerr << "engine: " << gsdf_last_error() << std::endl; return 1; }
+        }
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+        if (lead) {
+            std::cout << "Current frame counter: " << tSDF->frame_counter() << std::endl;
+            std::cout << "---------- " << (hi - lo) << " frames loaded + " << (GT_pose ? "fused" : "tracked + fused") << ": " << el << "s ("
+                      << (double)(hi - lo) / el << " frames per second" << (sharded ? ", this rank" : "") << ")." << std::endl;
+        }
+        if (sharded) {
+            T.tic();
+            if (!exchange(ctx, opt, opt.device)) return 1;
+            if (lead) T.toc("Exchange voxel sums between the ranks");
+        }
+        if (lead) {
+            std::ofstream pose_file(opt.output + "_poses.txt");
+            if (GT_pose) {
+                for (size_t j = 0; j < all.size(); ++j) write_pose_line(pose_file, all[j].timestamp, poses[opt.first + j < poses.size() ? opt.first + j : poses.size() - 1]);
+            } else {
+                std::vector<float> log(all.size() * 10);
+                int64_t n = 0;
+                if (gsdf_read_frame_log(ctx, log.data(), (int64_t)all.size(), &n) != GSDF_OK) { std::cerr << gsdf_last_error() << std::endl; return 1; }
+                write_pose_line(pose_file, all[0].timestamp, SE3().matrix());                          /* pOpt->pose() before the first optimize() */
+                for (int64_t r = 0; r < n && (size_t)(r + 1) < all.size(); ++r) {
+                    write_pose_line(pose_file, all[(size_t)r + 1].timestamp, SE3::from_pose7(&log[(size_t)r * 10]).matrix());
+                    if (log[(size_t)r * 10 + 7] > 0.f) std::cout << "frame " << opt.first + (size_t)r + 1 << " ... Convergence after " << (int)log[(size_t)r * 10 + 8] - 1 << " iterations!" << std::endl;
+                }
+            }
+        }
     }
-    pose_file.close();
-    if (!tSDF) { std::cerr << "no frame was processed" << std::endl; return 1; }
+    if (!lead) return 0;
 
     const std::string prefix = "gradient_sdf";
     T.tic();

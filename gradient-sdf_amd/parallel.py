@@ -15,9 +15,23 @@ The tracked path cannot be sharded (frame i needs the map of all frames < i): re
 
 All functions work on CPU tensors under gloo (used by the world-size-2 tests) and on device tensors
 under nccl (= RCCL on ROCm).  This module contains no hot-path arithmetic: the GPU work goes through the
-C-ABI (gsdf_export_raw_dev / gsdf_merge_raw_dev).
+C-ABI (gsdf_export_raw_dev / gsdf_merge_raw_dev).  The C++ form of the same exchange is gsdf_merge_allreduce
+(include/gsdf.h: pack -> ncclAllReduce -> unpack on the context's own stream); this module is the torch.distributed
+harness around the same device kernels.
+
+Stream ordering: libgsdf works on its own non-blocking HIP stream, torch (and the nccl backend, whose collectives return
+before they finish) on torch's current stream.  Every hand-over between the two is therefore fenced with
+`_torch_done()` (torch -> libgsdf) -- the libgsdf entries used here synchronise their stream before they return.
 """
 import numpy as np
+
+
+def _torch_done(device):
+    """Wait until everything torch has queued on its current stream (fills, copies, RCCL collectives) is complete, so that
+    libgsdf -- which runs on its own stream -- may read or overwrite the buffers."""
+    if str(device) != "cpu":
+        import torch
+        torch.cuda.current_stream().synchronize()
 
 
 def shard_range(n_frames, rank, world):
@@ -74,11 +88,11 @@ def exchange_and_merge(g, dist):
     pay = torch.empty((max(n, 1), 5), dtype=torch.float32, device="cuda")
     got = g.export_raw_dev(keys.data_ptr(), pay.data_ptr(), n) if n else 0
     lists = allgather_lists(keys[:got], pay[:got], dist, device="cuda")
+    lists = [(k.contiguous(), p.contiguous()) for k, p in lists]
+    _torch_done("cuda")                        # the all-gathers (and the copies above) have landed
     for r, (k, p) in enumerate(lists):
         if r == rank or k.shape[0] == 0:
             continue
-        k = k.contiguous()
-        p = p.contiguous()
         g.merge_raw_dev(k.data_ptr(), p.data_ptr(), k.shape[0])
     torch.cuda.synchronize()
     return sum(k.shape[0] for k, _ in lists)
@@ -110,9 +124,11 @@ def allreduce_merge(ops, dist, device="cpu"):
     """One all-reduce of per-voxel (weight, weighted distance, weighted gradient) over the union of the ranks' blocks.
     `ops` provides block_keys() -> int64 tensor, pack(union) -> float32 tensor [n, 64, 5], unpack(union, dense)
     (GpuBlockOps below for a binding.GradSdf; NumpyBlockOps for the CPU tests).  Returns the number of blocks."""
-    union = union_block_keys(ops.block_keys(), dist, device=device)
-    dense = ops.pack(union)
+    union = union_block_keys(ops.block_keys(), dist, device=device).contiguous()
+    _torch_done(device)                          # the union is complete before libgsdf reads it
+    dense = ops.pack(union)                      # libgsdf's stream is synchronised when pack returns
     dist.all_reduce(dense)                       # sum; RCCL over xGMI under the nccl backend
+    _torch_done(device)                          # the reduction has finished before the sums are stored
     ops.unpack(union, dense)
     return int(union.shape[0])
 
@@ -133,7 +149,9 @@ class GpuBlockOps:
     def pack(self, union):
         import torch
         union = union.contiguous()
-        dense = torch.zeros((union.shape[0], BLOCK_VOX, 5), dtype=torch.float32, device="cuda")
+        # empty, not zeros: the pack kernel writes every element, and a fill queued on torch's stream could land after it
+        dense = torch.empty((union.shape[0], BLOCK_VOX, 5), dtype=torch.float32, device="cuda")
+        _torch_done("cuda")
         self.g.pack_blocks_dev(union.data_ptr(), union.shape[0], dense.data_ptr())
         return dense
 

@@ -219,6 +219,20 @@ def _png_gray16(path, img16):
                 + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
 
 
+def layout_unit(layout):
+    """Depth unit of a dataset layout's loader: SynthLoader 1/1000 (SynthLoader.h:58), TumrgbdLoader 1/5000 (TumrgbdLoader.h:62)."""
+    return UNIT_TUM if layout == "tum" else UNIT_SYNTH
+
+
+def layout_depth_u16(seq, i, layout):
+    """The uint16 depth image write_dataset stores for frame i: the sequence's own quantisation when its unit is the
+    layout's, else the frame re-quantised to the layout's unit (so that the loader reads metres back)."""
+    d16 = seq.depth_u16(i)
+    if np.float32(seq.unit) == np.float32(layout_unit(layout)):
+        return d16
+    return quantize_u16(u16_to_metres(d16, seq.unit).astype(np.float64), layout_unit(layout))
+
+
 def write_dataset(seq, out_dir, layout="synth", with_poses=True, pose_file="pose.txt"):
     """Write `seq` as a dataset directory: intrinsics.txt, depth PNGs (u16), optional TUM pose file.
     layout "synth": depth/%03d.png 1-based (SynthLoader.h:64-83); "tum": associated.txt + depth/<ts>.png
@@ -233,7 +247,7 @@ def write_dataset(seq, out_dir, layout="synth", with_poses=True, pose_file="pose
     for i in range(seq.n):
         ts = "%03d" % (i + 1) if layout == "synth" else "%.6f" % (1305031102.0 + i / 30.0)
         name = "depth/%s.png" % ts
-        _png_gray16(out_dir + name, seq.depth_u16(i))
+        _png_gray16(out_dir + name, layout_depth_u16(seq, i, layout))
         assoc.append("%s rgb/%s.png %s %s" % (ts, ts, ts, name))
         R, t = seq.pose(i)
         q = R_to_quat_np(R)

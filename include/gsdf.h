@@ -162,6 +162,32 @@ int gsdf_block_keys_dev(gsdf_ctx* c, uint64_t* block_keys_dev, int64_t max_n, in
 int gsdf_pack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t n, float* dense_dev);
 int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t n, const float* dense_dev);
 
+/* The exchange step as ONE call, for C++ hosts (BASELINE.json north_star: "frames shard naturally across the
+ * 8 GPUs of one node with a RCCL-over-xGMI all-reduce of per-voxel (weight, weighted-distance, weighted-gradient) before
+ * mesh extraction").  Collective: every rank of the communicator calls it with the map it fused from its own frames (the
+ * GT-pose branch, main_scan_3d.cpp:250-254); on return every rank's map is the sum of all maps.  Steps: all-gather of the
+ * block ids, sorted union, gsdf pack, ONE ncclAllReduce (sum, float32, 1280 B per block of the union) on the context's own
+ * stream, gsdf unpack.  nccl_comm: an ncclComm_t of the RCCL already in the process (RCCL is resolved at run time, it is
+ * not a link dependency of libgsdf.so).  n_blocks / bytes (nullable): size of the union / of the all-reduced buffer. */
+int gsdf_merge_allreduce(gsdf_ctx* c, void* nccl_comm, int64_t* n_blocks, int64_t* bytes);
+/* communicator plumbing for hosts that do not link RCCL themselves (the Scan3D CLI): ncclGetUniqueId / ncclCommInitRank
+ * (on `device`) / ncclCommDestroy.  Create the communicator once, outside any timed region. */
+int gsdf_rccl_unique_id(char id128[128]);
+int gsdf_rccl_comm_init(void** nccl_comm, int nranks, const char id128[128], int rank, int device);
+int gsdf_rccl_comm_destroy(void* nccl_comm);
+/* The same exchange over a caller-provided transport: two collectives on HOST buffers (libgsdf stages the device data).
+ * Used where RCCL cannot run (two ranks on one GPU in the tests) or where the host has its own communication layer.
+ * Both callbacks return 0 on success. */
+typedef struct gsdf_collective {
+    /* recv[r * bytes .. (r + 1) * bytes) := rank r's `send` (bytes per rank are equal on all ranks) */
+    int (*allgather)(void* user, const void* send, void* recv, int64_t bytes);
+    /* buf[i] := sum over the ranks of buf[i], i < n */
+    int (*allreduce_sum_f32)(void* user, float* buf, int64_t n);
+    void* user;
+    int nranks;
+} gsdf_collective;
+int gsdf_merge_allreduce_with(gsdf_ctx* c, const gsdf_collective* ops, int64_t* n_blocks, int64_t* bytes);
+
 /* Sdf::weights(point) and Sdf::tsdf(point, &grad) at n points -- MapGradPixelSdf.h:109-125.
  * w[i]==0 marks a missing voxel (dist/grad are then 0; the reference's .at() would throw). */
 int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w);
@@ -193,6 +219,16 @@ int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes);
 int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr);
 int gsdf_dev_upload(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes);
 int gsdf_dev_download(gsdf_ctx* c, void* host_dst, const void* dev_src, int64_t bytes);
+/* Asynchronous frame staging for a host loop that keeps the GPU fed (the Scan3D CLI): page-locked host
+ * buffers, an upload that is only ENQUEUED on the context's stream (host_src must stay untouched until a later mark is
+ * reached), and marks: gsdf_mark records a point in the stream, gsdf_mark_wait blocks until the stream has passed it,
+ * gsdf_mark_reached polls.  Marks complete in the order they were recorded. */
+int gsdf_host_alloc(gsdf_ctx* c, void** host_ptr, int64_t bytes);
+int gsdf_host_free(gsdf_ctx* c, void* host_ptr);
+int gsdf_dev_upload_async(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes);
+int gsdf_mark(gsdf_ctx* c, int64_t* mark);
+int gsdf_mark_wait(gsdf_ctx* c, int64_t mark);
+int gsdf_mark_reached(gsdf_ctx* c, int64_t mark, int* reached);
 /* HIP-event timing on the context's stream: t0/t1 bracket whatever is enqueued between them */
 int gsdf_timer_start(gsdf_ctx* c);
 int gsdf_timer_stop_ms(gsdf_ctx* c, float* ms);          /* synchronises */

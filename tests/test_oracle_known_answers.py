@@ -283,3 +283,98 @@ def test_raycast_thin_band(O, pkg):
         z, _ = o.raycast(np.eye(3), np.zeros(3), zmin=zmin)
         assert (z > 0).mean() > 0.94                                 # a few border rays leave the fused columns
         assert np.abs(z - z0)[z > 0].max() < 1.0 * float(vs)         # one sample spacing: phi = dist + 1.2 g.(c - p) is not metric
+
+
+# ---- exports: marching cubes (classic case tables as data) and the point cloud -------------------------------------
+
+def _mc_tables():
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "include", "gsdf_mc_tables.h")).read()
+    e = re.search(r"GSDF_MC_EDGE_TABLE\[256\] = \{(.*?)\};", txt, re.S).group(1)
+    t = re.search(r"GSDF_MC_TRI_TABLE\[256 \* 16\] = \{(.*?)\};", txt, re.S).group(1)
+    edge = np.array([int(v, 16) for v in re.findall(r"0x[0-9a-f]+", e)])
+    tri = np.array([int(v) for v in re.findall(r"-?\d+", t)]).reshape(256, 16)
+    return edge, tri
+
+
+def test_mc_case_tables_are_consistent():
+    """The embedded edgeTable / triTable (include/gsdf_mc_tables.h = LayeredMarchingCubesNoColor.cpp:67-352): for every
+    corner pattern the flagged edges are exactly the edges whose two corners differ in sign (edge e joins corners A[e], B[e]
+    of :410-549), the triangles use exactly the flagged edges, and complementary patterns cross the same edges."""
+    edge, tri = _mc_tables()
+    A = [0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3]
+    B = [1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7]
+    assert edge.shape == (256,) and tri.shape == (256, 16)
+    for c in range(256):
+        mask = 0
+        for e in range(12):
+            if ((c >> A[e]) & 1) != ((c >> B[e]) & 1):
+                mask |= 1 << e
+        assert edge[c] == mask, c
+        row = tri[c]
+        used = row[row >= 0]
+        assert len(used) % 3 == 0 and len(used) <= 15
+        assert (row[len(used):] == -1).all()
+        m2 = 0
+        for e in used:
+            m2 |= 1 << int(e)
+        assert m2 == mask, c
+        assert edge[255 - c] == edge[c]
+    assert (tri[0] == -1).all() and (tri[255] == -1).all()
+
+
+def test_oracle_marching_cubes_sphere_is_watertight(O):
+    """The oracle's LayeredMarchingCubesNoColor restatement on an analytic sphere (map loaded with set_map): every mesh edge
+    is shared by exactly two faces, vertices lie on the sphere within interpolation error, faces come in z-y-x sweep order."""
+    N, vs, r = 20, np.float32(0.05), 0.8
+    ax = np.arange(-N, N + 1, dtype=np.int32)
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    keys = np.stack([x.ravel(), y.ravel(), z.ravel()], 1).astype(np.int32)
+    d = (np.sqrt((keys.astype(np.float64) ** 2).sum(1)) * float(vs) - r).astype(np.float32)
+    pay = np.zeros((len(keys), 5), np.float32)
+    pay[:, 0] = d; pay[:, 3] = 1.0; pay[:, 4] = 1.0
+    K = np.array([100, 0, 32, 0, 100, 24, 0, 0, 1], np.float32)
+    o = O.Oracle(vs, np.float32(5) * vs, 64, 48, K)
+    o.set_map(keys, pay)
+    tris = o.extract_mesh()
+    assert tris.shape[0] > 2000
+    rad = np.linalg.norm(tris.reshape(-1, 3), axis=1)
+    assert rad.min() > r - 0.01 and rad.max() < r + 0.01
+    q = np.round(tris.astype(np.float64) * 1e5).astype(np.int64)
+    edges = {}
+    for f in q:
+        for a in range(3):
+            u, v = tuple(f[a]), tuple(f[(a + 1) % 3])
+            k = (u, v) if u < v else (v, u)
+            edges[k] = edges.get(k, 0) + 1
+    assert all(c == 2 for c in edges.values())
+    # sweep order: the lowest corner of the cube a face came from never decreases in (z, y, x)
+    base = np.floor(tris.min(axis=1) / float(vs) + 1e-4).astype(np.int64)
+    code = (base[:, 2] * 4096 + base[:, 1]) * 4096 + base[:, 0]
+    assert (np.diff(code) >= 0).all()
+    # a voxel with weight 0 at a cube corner suppresses the cube (computeLutIndex :611-618)
+    pay2 = pay.copy()
+    pay2[:, 4] = np.where((keys == 0).all(1) | (np.abs(keys).sum(1) % 7 == 0), 0.0, 1.0)
+    o.set_map(keys[pay2[:, 4] > 0], pay2[pay2[:, 4] > 0])
+    assert 0 < o.extract_mesh().shape[0] < tris.shape[0]
+
+
+def test_oracle_extract_pc_plane_known_answer(O):
+    """extract_pc (MapGradPixelSdf.cpp:177-220) on hand-made voxels: weight gate (>= 5), the half-voxel box test on
+    dist * 1.2 g^, point = centre - dist * 1.2 g^, normal = -1.2 g^."""
+    vs = np.float32(0.02)
+    K = np.array([100, 0, 32, 0, 100, 24, 0, 0, 1], np.float32)
+    o = O.Oracle(vs, np.float32(5) * vs, 64, 48, K)
+    keys = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0]], np.int32)
+    pay = np.array([[0.004, 0, 0, 3.0, 6.0],      # in: |0.004 * 1.2| < 0.01
+                    [0.004, 0, 0, 3.0, 4.9],      # weight < 5: out
+                    [0.009, 0, 0, -2.0, 9.0],     # |0.009 * 1.2| = 0.0108 >= 0.01: out
+                    [-0.008, 0, 5.0, 0, 5.0]],    # in (weight == 5 passes `< 5`), gradient along +y
+                   np.float32)
+    o.set_map(keys, pay)
+    rows = o.extract_pc()
+    assert rows.shape == (2, 6)
+    g = np.float32(1.2)
+    assert np.allclose(rows[0], [0, 0, 0 - np.float32(0.004) * g, 0, 0, -g], atol=1e-7)
+    assert np.allclose(rows[1], [np.float32(0.06), 0 + np.float32(0.008) * g, 0, 0, -g, 0], atol=1e-7)

@@ -99,3 +99,97 @@ def test_frame_sharded_fusion_world2_gloo(pkg, O, tmp_path):
     assert np.abs(w - pay[:, 4]).max() <= 1e-4 * max(1.0, pay[:, 4].max())
     assert np.abs(a["pay"][:, 0] / w - pay[:, 0]).max() <= 1e-4
     assert np.abs(a["pay"][:, 1:4] - pay[:, 1:4]).max() <= 1e-4 * max(1.0, pay[:, 4].max())
+
+
+# ---- the exchange as ONE C-ABI call (gsdf_merge_allreduce / gsdf_merge_allreduce_with) on real hardware ---------------
+
+def _gpu_worker(rank, world, port, out_dir):
+    """One rank of the frame-sharded GT-pose fusion on the GPU: fuse the own frame range through the C-ABI, then the C++
+    exchange entry with gloo as its transport (two ranks share the one GPU of the test box, which RCCL does not allow)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.package()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H, n = 320, 240, 8
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=9, step_deg=3.0)
+    vs = np.float32(0.02)
+    g = pkg.GradSdf(vs, np.float32(5) * vs, W, H, seq.K, capacity_log2=20, device=0)
+    lo, hi = pkg.parallel.shard_range(n, rank, world)
+    for i in range(lo, hi):
+        g.update(*seq.frame(i))
+
+    def allgather(send):
+        t = torch.from_numpy(send)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return torch.cat(out).numpy()
+
+    def allreduce(buf):
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t)
+        return t.numpy()
+
+    own = g.count()
+    n_blocks, nbytes = g.merge_allreduce_with(allgather, allreduce, world)
+    keys, pay = g.export(sorted=True, raw=True)
+    np.savez(os.path.join(out_dir, "gpu_rank%d.npz" % rank), keys=keys, pay=pay, own=own, n_blocks=n_blocks, nbytes=nbytes)
+    g.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_merge_allreduce_c_entry_world2_on_one_gpu(pkg, O, tmp_path):
+    """gsdf_merge_allreduce_with from two processes (one context each): afterwards both hold the map of ALL frames --
+    key set bit-exact against the oracle's single-process fusion, sums within float noise."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / "gpu_rank0.npz")
+    b = np.load(tmp_path / "gpu_rank1.npz")
+    assert np.array_equal(a["keys"], b["keys"]) and np.array_equal(a["pay"], b["pay"])   # every rank holds the same sums
+    assert int(a["n_blocks"]) == int(b["n_blocks"]) > 100 and int(a["nbytes"]) == int(a["n_blocks"]) * 64 * 5 * 4
+    assert int(a["own"]) < len(a["keys"]) and int(b["own"]) < len(a["keys"])             # the shards really differed
+    W, H, n = 320, 240, 8
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=9, step_deg=3.0)
+    vs = np.float32(0.02)
+    o = O.Oracle(vs, np.float32(5) * vs, W, H, seq.K)
+    for i in range(n):
+        o.update(*seq.frame(i))
+    keys, pay = o.export()
+    assert np.array_equal(a["keys"], keys)
+    w = a["pay"][:, 4]
+    scale = np.maximum(1.0, pay[:, 4])
+    assert (np.abs(w - pay[:, 4]) / scale).max() <= 1e-4
+    assert np.abs(a["pay"][:, 0] / w - pay[:, 0]).max() <= 1e-4
+    assert (np.abs(a["pay"][:, 1:4] - pay[:, 1:4]).max(axis=1) / scale).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_merge_allreduce_over_rccl_one_rank(pkg):
+    """gsdf_merge_allreduce over a real RCCL communicator (gsdf_rccl_comm_init; one rank -- the box has one GPU): block ids,
+    pack, ncclAllGather / ncclAllReduce on the context's stream, unpack.  With one rank the map must come back unchanged,
+    bit for bit; a second call finds the same union."""
+    W, H = 320, 240
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=4, seed=1)
+    vs = np.float32(0.01)
+    g = pkg.GradSdf(vs, np.float32(10) * vs, W, H, seq.K, capacity_log2=21)
+    for i in range(seq.n):
+        g.update(*seq.frame(i))
+    k0, p0 = g.export(sorted=True, raw=True)
+    comm = pkg.binding.rccl_comm_init(1, pkg.binding.rccl_unique_id(), 0, 0)
+    try:
+        nb, nbytes = g.merge_allreduce_rccl(comm)
+        assert nb > 100 and nbytes == nb * 64 * 5 * 4
+        k1, p1 = g.export(sorted=True, raw=True)
+        assert np.array_equal(k0, k1) and np.array_equal(p0.view(np.uint32), p1.view(np.uint32))
+        nb2, _ = g.merge_allreduce_rccl(comm)
+        assert nb2 == nb
+        g.update(*seq.frame(0))                           # the map stays usable: fusing after the exchange works
+        assert g.count() == len(k0)
+    finally:
+        pkg.binding.rccl_comm_destroy(comm)
+    g.close()
