@@ -1432,11 +1432,11 @@ void gsdf_launch_get_voxels(hipStream_t s, gsdf_table tab, const int32_t* keys, 
 /* ------------------------------------------------------------------------------------------------
  * Voxel-hash raycaster (BASELINE.json north_star; absent from the reference): defined
  * on top of weights()/tsdf() -- MapGradPixelSdf.h:109-125 -- and the tracker's back-projection
- * (RigidPointOptimizer.cpp:46-47,67-70): p(s) = s R (x0, y0, 1) + t; min(4, factor - 1)-voxel steps (at least 1) while the voxel
- * under p(s) is missing, 1-voxel steps inside the band; hit = first sign change phi_prev < 0 <= phi of two
- * consecutive in-band samples (the SDF is negative in front of a surface); depth by linear interpolation,
- * normal = R^T grad/|grad| of the sample behind the surface.  The test suite holds a CPU statement of the same
- * definition.
+ * (RigidPointOptimizer.cpp:46-47,67-70): p(s) = s R (x0, y0, 1) + t; coarse steps of min(4, factor - 1) voxels of depth
+ * (at least 1) while the voxel under p(s) is missing -- re-walked in fine steps when they end on an existing voxel -- and
+ * 1-voxel steps inside the band; hit = first sign change phi_prev < 0 <= phi of two consecutive existing samples (the SDF
+ * is negative in front of a surface); depth by linear interpolation, normal = R^T grad/|grad| of the sample behind the
+ * surface.  The test infrastructure holds the CPU statement of the same definition.
  * One lane per pixel, 16x16-pixel workgroups (neighbouring rays walk the same blocks: the block keys
  * are L2 hits, records share lines).  The walk is a chain of dependent lookups per ray: 4-voxel steps
  * through empty space (one key probe each), 1-voxel steps inside the band.
@@ -1450,11 +1450,15 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
     const float fx_inv = 1.f / fx, fy_inv = 1.f / fy;
     const float x0 = ((float)u - cx) * fx_inv, y0 = ((float)v - cy) * fy_inv;
     const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ x0, y0, 1.f });
-    const float fine = vs, coarse = (float)(factor < 2 ? 1 : (factor > 5 ? 4 : factor - 1)) * vs;   /* narrower than the band in front of a surface */
+    /* coarse steps of min(4, factor - 1) voxels of depth across missing voxels; the first existing voxel found after
+     * one sends the walk back to the start of that step, which is then walked in fine steps (the step may have jumped the
+     * front of the band); one missing sample between two existing ones is bridged -- definition: DESIGN.md (f4) */
+    const float fine = vs, coarse = (float)(factor < 2 ? 1 : (factor > 5 ? 4 : factor - 1)) * vs;
     float out_z = 0.f;
     gsdf_v3 out_n = { 0.f, 0.f, 0.f };
     bool prev_ok = false;
     float phi_prev = 0.f, s_prev = 0.f;
+    float fine_until = zmin, s_coarse_from = -1.f;
     for (float s = zmin; s < zmax;) {
         const gsdf_v3 p = { s * d.x + pose.t[0], s * d.y + pose.t[1], s * d.z + pose.t[2] };
         const int vx = gsdf_float2vox1(inv_vs, p.x), vy = gsdf_float2vox1(inv_vs, p.y), vz = gsdf_float2vox1(inv_vs, p.z);
@@ -1465,6 +1469,13 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
             const float2* q = reinterpret_cast<const float2*>(sl);
             ws = q[0]; gxy = q[1]; gz_ = q[2];
             w0 = ws.x;
+        }
+        if (w0 > 0.f && s_coarse_from >= 0.f) {
+            fine_until = s;
+            s = s_coarse_from + fine;
+            s_coarse_from = -1.f;
+            prev_ok = false;
+            continue;
         }
         if (w0 > 0.f) {
             const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ gxy.x, gxy.y, gz_.x });
@@ -1479,9 +1490,12 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
             }
             prev_ok = true; phi_prev = phi; s_prev = s;
             s += fine;
+        } else if (prev_ok && s - s_prev < 1.5f * fine) {
+            s += fine;                                          /* one missing sample inside the band is bridged */
         } else {
             prev_ok = false;
-            s += coarse;
+            if (s < fine_until) s += fine;
+            else { s_coarse_from = s; s += coarse; }
         }
     }
     const size_t i = (size_t)v * W + u;

@@ -376,6 +376,20 @@ void gsdfo_set_map(gsdfo* o, const int32_t* keys, const float* payload, int64_t 
     }
 }
 
+/* test plumbing: overwrite the SdfVoxel of EXISTING voxels (vis_ and the key set stay): lets the PhotoBA restatement run on
+ * exactly the voxel values another implementation fused.  Returns the number of keys that were not in the map. */
+int64_t gsdfo_set_payload(gsdfo* o, const int32_t* keys, const float* payload, int64_t n) {
+    int64_t missing = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        auto it = o->tsdf_.find(Key{ keys[3 * i], keys[3 * i + 1], keys[3 * i + 2] });
+        if (it == o->tsdf_.end()) { ++missing; continue; }
+        it->second.dist = payload[5 * i];
+        it->second.grad[0] = payload[5 * i + 1]; it->second.grad[1] = payload[5 * i + 2]; it->second.grad[2] = payload[5 * i + 3];
+        it->second.weight = payload[5 * i + 4];
+    }
+    return missing;
+}
+
 /* ---- exports: MapGradPixelSdf::extract_pc and LayeredMarchingCubesNoColor -------------------------------- */
 
 /* MapGradPixelSdf::extract_pc -- MapGradPixelSdf.cpp:177-220.  Rows: x y z nx ny nz; voxels are visited in
@@ -556,11 +570,16 @@ void gsdfo_query(const gsdfo* o, const float* pts, int64_t n, float* dist, float
  * built only from the reference's point query weights()/tsdf() (MapGradPixelSdf.h:109-125) and the
  * tracker's back-projection (RigidPointOptimizer.cpp:46-47,67-70).  PARITY UNPINNED (self-defined).
  *
- * Pixel (u,v): d = R (x0, y0, 1), p(s) = s d + t, s = camera depth.  March s from zmin: 4 voxels per
- * step (fewer when the truncation band is thinner: min(4, factor - 1) voxels, at least 1) while the voxel under p(s) is
- * missing, so that the walk cannot jump over the band in front of a surface; 1 voxel per step inside the band.  A hit is the first sign
- * change phi_prev < 0 <= phi (the reference's SDF is negative in front of the surface) between two consecutive in-band samples; depth = linear interpolation of
- * s, normal = R^T grad/|grad| of the sample behind the surface (camera frame, like NormalEstimator). */
+ * Pixel (u,v): d = R (x0, y0, 1), p(s) = s d + t, s = camera depth.  March s from zmin.  While the voxel under p(s) is
+ * missing: COARSE steps of min(4, factor - 1) voxels of depth (at least 1; from a fusing pose the samples then coincide with
+ * the fused ones).  The band of existing voxels around a surface is >= ~6 voxels thick along its normal (2 factor + 1 voxels
+ * along the fusing rays, which the normal gate keeps within 72.5 degrees of the normal), so a coarse step (<= 5 voxels of
+ * 3-D length at the image corners) cannot jump it -- but it can jump its FRONT part and land behind the surface.  Hence: the first existing voxel found after a coarse step sends the
+ * walk back to the start of that step, and the stretch is walked again in FINE steps (1 voxel of depth, also across
+ * missing voxels).  Inside the band: fine steps.  A hit is the first sign change phi_prev < 0 <= phi (the reference's SDF
+ * is negative in front of the surface) between two existing samples that are consecutive or have ONE missing sample
+ * between them (fused pixel columns leave lateral gaps when a pixel is wider than a voxel); depth = linear interpolation of s,
+ * normal = R^T grad/|grad| of the sample behind the surface (camera frame, like NormalEstimator). */
 void gsdfo_raycast(const gsdfo* o, const float K[9], const float R[9], const float t[3], int W, int H,
                    float zmin, float zmax, float* depth, float* normals) {
     const float fx_inv = 1.f / K[0], fy_inv = 1.f / K[4], cx = K[2], cy = K[5];
@@ -574,10 +593,19 @@ void gsdfo_raycast(const gsdfo* o, const float K[9], const float R[9], const flo
             V3 out_n = { 0.f, 0.f, 0.f };
             bool prev_ok = false;
             float phi_prev = 0.f, s_prev = 0.f;
+            float fine_until = zmin;                   /* below this depth missing voxels are crossed in fine steps */
+            float s_coarse_from = -1.f;                /* start of the coarse step that led to s (< 0: s was reached by a fine step) */
             for (float s = zmin; s < zmax;) {
                 const V3 p = { s * d.x + t[0], s * d.y + t[1], s * d.z + t[2] };
                 const SdfVoxel* vox; Key idx;
                 const float w0 = oracle_weights(o, p, &vox, &idx);
+                if (w0 > 0.f && s_coarse_from >= 0.f) {        /* entered the band by a coarse step: walk that stretch again */
+                    fine_until = s;
+                    s = s_coarse_from + fine;
+                    s_coarse_from = -1.f;
+                    prev_ok = false;
+                    continue;
+                }
                 if (w0 > 0.f) {
                     V3 g;
                     const float phi = oracle_tsdf(o, *vox, idx, p, &g);
@@ -590,9 +618,13 @@ void gsdfo_raycast(const gsdfo* o, const float K[9], const float R[9], const flo
                     }
                     prev_ok = true; phi_prev = phi; s_prev = s;
                     s += fine;
+                } else if (prev_ok && s - s_prev < 1.5f * fine) {
+                    s += fine;                                  /* ONE missing sample inside the band is bridged (lateral gaps
+                                                                   between fused pixel columns): the previous sample stays */
                 } else {
                     prev_ok = false;
-                    s += coarse;
+                    if (s < fine_until) s += fine;
+                    else { s_coarse_from = s; s += coarse; }
                 }
             }
             const size_t i = (size_t)v * W + u;
@@ -959,9 +991,13 @@ gsdfo_ba* gsdfo_ba_create(gsdfo* o, const float K[9], int n, int W, int H, const
 }
 void gsdfo_ba_destroy(gsdfo_ba* b) { delete b; }
 
-/* getEnergy -- :273-321 */
-float gsdfo_ba_energy(gsdfo_ba* b) {
+/* getEnergy -- :273-321.  The per-voxel terms are the reference's float arithmetic; the reference adds them up in ONE float
+ * in the iteration order of its hash map (unknowable), which for ~10^6 terms leaves its own value uncertain at the 1e-3 level
+ * (terms below half an ulp of the running sum vanish).  gsdfo_ba_energy does the same in (z,y,x) order; gsdfo_ba_energy_f64
+ * adds the identical terms in double -- the order-independent value the GPU sweep is compared with. */
+static double ba_energy_impl(gsdfo_ba* b, float* E_float) {
     float E = 0.f;
+    double E64 = 0.0;
     std::vector<V3> A;
     for (const Key& idx : b->order) {
         const SdfVoxel& vox = b->o->tsdf_.at(idx);
@@ -979,11 +1015,20 @@ float gsdfo_ba_energy(gsdfo_ba* b) {
         mean = V3{ inv * mean.x, inv * mean.y, inv * mean.z };
         for (const V3& a : A) {
             const V3 r = { a.x - mean.x, a.y - mean.y, a.z - mean.z };
-            E += dot3(r, r);
+            const float term = dot3(r, r);
+            E += term;
+            E64 += (double)term;
         }
     }
+    if (E_float) *E_float = E;
+    return E64;
+}
+float gsdfo_ba_energy(gsdfo_ba* b) {
+    float E = 0.f;
+    ba_energy_impl(b, &E);
     return E;
 }
+double gsdfo_ba_energy_f64(gsdfo_ba* b) { return ba_energy_impl(b, nullptr); }
 
 /* solveDist -- :326-388 */
 void gsdfo_ba_solve_dist(gsdfo_ba* b, float damping) {

@@ -64,6 +64,8 @@ void   gsdfo_export_vis(const gsdfo* o, uint32_t* words, int words_per_voxel);
 /* test plumbing: replace the map by n (key, SdfVoxel) pairs (keys int32[n][3], payload float[n][5] = dist,gx,gy,gz,weight),
  * so that the restatements below can run on exactly the voxel values another implementation produced */
 void   gsdfo_set_map(gsdfo* o, const int32_t* keys, const float* payload, int64_t n);
+/* test plumbing: overwrite the payload of EXISTING voxels, keeping vis_ and the key set; returns the keys not found */
+int64_t gsdfo_set_payload(gsdfo* o, const int32_t* keys, const float* payload, int64_t n);
 /* MapGradPixelSdf::extract_pc -- MapGradPixelSdf.cpp:177-220: rows x y z nx ny nz of the voxels with weight >= 5 whose
  * surface point lies inside the voxel, voxels visited in (z,y,x) order.  rows6 == NULL only counts.  Returns the row count. */
 int64_t gsdfo_extract_pc(const gsdfo* o, float* rows6);
@@ -112,7 +114,8 @@ typedef struct gsdfo_ba gsdfo_ba;
 gsdfo_ba* gsdfo_ba_create(gsdfo* o, const float K[9], int n, int W, int H, const float* images_bgr,
                           const float* poses16, const int* frame_idx, float reg_weight);
 void   gsdfo_ba_destroy(gsdfo_ba* b);
-float  gsdfo_ba_energy(gsdfo_ba* b);                       /* getEnergy        :273-321 */
+float  gsdfo_ba_energy(gsdfo_ba* b);                       /* getEnergy        :273-321 (float sum, (z,y,x) order) */
+double gsdfo_ba_energy_f64(gsdfo_ba* b);                   /* the same float terms added in double (order-independent) */
 void   gsdfo_ba_solve_pose(gsdfo_ba* b, float damping);    /* solvePose        :499-590 */
 void   gsdfo_ba_solve_dist(gsdfo_ba* b, float damping);    /* solveDist        :326-388 */
 /* optimize() :611-662.  energies receives E0, then E after every pose / dist step (<= 2*max_it+1 values).

@@ -51,6 +51,8 @@ def lib():
         L.gsdfo_export_vis.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
         L.gsdfo_query.argtypes = [C.c_void_p, fp, C.c_int64, fp, fp, fp]
         L.gsdfo_set_map.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp, C.c_int64]
+        L.gsdfo_set_payload.restype = C.c_int64
+        L.gsdfo_set_payload.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp, C.c_int64]
         L.gsdfo_extract_pc.restype = C.c_int64
         L.gsdfo_extract_pc.argtypes = [C.c_void_p, fp]
         L.gsdfo_extract_mesh.restype = C.c_int64
@@ -160,6 +162,12 @@ class Oracle:
         p = _f32(payload).reshape(-1, 5)
         self.L.gsdfo_set_map(self.h, k.ctypes.data_as(C.POINTER(C.c_int32)), _fp(p), k.shape[0])
 
+    def set_payload(self, keys, payload):
+        """Overwrite the payload of existing voxels (vis_ and key set stay); returns the number of unknown keys."""
+        k = np.ascontiguousarray(keys, np.int32).reshape(-1, 3)
+        p = _f32(payload).reshape(-1, 5)
+        return int(self.L.gsdfo_set_payload(self.h, k.ctypes.data_as(C.POINTER(C.c_int32)), _fp(p), k.shape[0]))
+
     def extract_pc(self):
         """MapGradPixelSdf::extract_pc rows (x y z nx ny nz), voxels in (z,y,x) order."""
         n = int(self.L.gsdfo_extract_pc(self.h, None))
@@ -222,6 +230,8 @@ class PhotoBA:
         self.L.gsdfo_ba_destroy.argtypes = [C.c_void_p]
         self.L.gsdfo_ba_energy.restype = C.c_float
         self.L.gsdfo_ba_energy.argtypes = [C.c_void_p]
+        self.L.gsdfo_ba_energy_f64.restype = C.c_double
+        self.L.gsdfo_ba_energy_f64.argtypes = [C.c_void_p]
         self.L.gsdfo_ba_solve_pose.argtypes = [C.c_void_p, C.c_float]
         self.L.gsdfo_ba_solve_dist.argtypes = [C.c_void_p, C.c_float]
         self.L.gsdfo_ba_optimize.restype = C.c_int
@@ -242,6 +252,10 @@ class PhotoBA:
 
     def energy(self):
         return float(self.L.gsdfo_ba_energy(self.h))
+
+    def energy_f64(self):
+        """The same float terms added in double: free of the reference's summation-order uncertainty."""
+        return float(self.L.gsdfo_ba_energy_f64(self.h))
 
     def solve_pose(self, damping=1.0):
         self.L.gsdfo_ba_solve_pose(self.h, np.float32(damping))

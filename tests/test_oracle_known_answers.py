@@ -255,9 +255,11 @@ def test_raycast_recovers_the_plane(O, pkg):
     o = O.Oracle(VS, T10, W, H, K)
     o.update(depth, np.eye(3), np.zeros(3))
     z, n = o.raycast(np.eye(3), np.zeros(3))
-    assert (z > 0).all()
-    assert np.abs(z - z0).max() < 0.5 * float(VS)
     inner = (slice(8, H - 8), slice(8, W - 8))
+    # rays near the image border run along the edge of the fused columns (1 cm voxels, 1.1 cm between pixel rays at this
+    # depth), where two consecutive samples need not both exist
+    assert (z[inner] > 0).all() and (z > 0).mean() > 0.97
+    assert np.abs(z - z0)[z > 0].max() < 0.5 * float(VS)
     assert np.abs(n[2][inner] - 1).max() < 1e-3
     # camera 3 m further down the axis, looking back at the plane from its far side: the SDF goes + -> -, no hit
     Rb = np.diag([-1.0, 1.0, -1.0]).astype(np.float32)
@@ -265,9 +267,34 @@ def test_raycast_recovers_the_plane(O, pkg):
     assert (zb == 0).all()
     # a window narrower than the band in front of the surface still finds it; one that ends before it does not
     z2, _ = o.raycast(np.eye(3), np.zeros(3), zmin=1.45, zmax=1.6)
-    assert np.abs(z2 - z0).max() < 0.5 * float(VS)
+    assert (z2[inner] > 0).all() and np.abs(z2 - z0)[z2 > 0].max() < 0.5 * float(VS)
     z3, _ = o.raycast(np.eye(3), np.zeros(3), zmin=0.5, zmax=1.4)
     assert (z3 == 0).all()
+
+
+def test_raycast_oblique_view_does_not_jump_the_band(O, pkg):
+    """A plane fused head-on, rendered from up to 55 degrees off its normal and from a different distance: along such rays the
+    part of the band in FRONT of the surface can be thinner than a coarse step; the walk backs up (re-walks the last coarse
+    step in fine steps) whenever a coarse step ends on an existing voxel, so every ray finds the surface.
+    (2 cm voxels: a pixel at this resolution is narrower than a voxel, so the fused band has no lateral gaps.)"""
+    W, H = 160, 120
+    K = pkg.synth.intrinsics(W, H)
+    z0 = np.float32(1.5)
+    vs = np.float32(0.02)
+    o = O.Oracle(vs, np.float32(10) * vs, W, H, K)
+    for dx in (-0.6, -0.3, 0.0, 0.3, 0.6):                            # a wide strip of the plane
+        o.update(np.full((H, W), z0, np.float32), np.eye(3), np.array([dx, 0, 0], np.float32))
+    v, u = np.mgrid[30:90, 40:120]
+    x0 = (u - K[0, 2]) / K[0, 0]; y0 = (v - K[1, 2]) / K[1, 1]
+    for deg in (0.0, 30.0, 55.0):
+        a = np.deg2rad(deg)
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)   # camera turned about y
+        t = np.array([0, 0, z0], np.float32) - 1.2 * R[:, 2]         # its axis meets the plane point (0, 0, z0) at distance 1.2
+        z, n = o.raycast(R, t, zmin=0.5, zmax=3.0)
+        inner = z[30:90, 40:120]
+        assert (inner > 0).all(), deg
+        pts = inner[..., None] * (np.stack([x0, y0, np.ones_like(x0)], -1) @ R.T) + t
+        assert np.abs(pts[..., 2] - z0).max() < 1.25 * float(vs), deg   # the rendered points lie on the plane
 
 
 def test_raycast_thin_band(O, pkg):
@@ -282,7 +309,7 @@ def test_raycast_thin_band(O, pkg):
     for zmin in (0.5, 0.505, 0.511, 0.517):                         # every phase of the steps relative to the band
         z, _ = o.raycast(np.eye(3), np.zeros(3), zmin=zmin)
         assert (z > 0).mean() > 0.94                                 # a few border rays leave the fused columns
-        assert np.abs(z - z0)[z > 0].max() < 1.0 * float(vs)         # one sample spacing: phi = dist + 1.2 g.(c - p) is not metric
+        assert np.abs(z - z0)[z > 0].max() < 1.25 * float(vs)        # one sample spacing along an oblique ray: phi = dist + 1.2 g.(c - p) is not metric
 
 
 # ---- exports: marching cubes (classic case tables as data) and the point cloud -------------------------------------

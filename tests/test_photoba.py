@@ -1,7 +1,8 @@
 """PhotoBA (config C5): PhotometricOptimizer restated in the oracle and run on the GPU.
 not gpu: known-answer behaviour of the oracle (energy minimal at the true poses, perturbation raises it,
          optimisation brings energy and poses back).
-gpu:     energy / one pose step / one distance step / full optimize against the oracle."""
+gpu:     energy / one pose step / one distance step from identical state at the 1e-4 bar (6 and 50 keyframes), and the
+         full optimize() trajectory, against the oracle."""
 import numpy as np
 import pytest
 
@@ -58,37 +59,71 @@ def test_oracle_photoba_ignores_invisible_keyframes(pkg, O):
     assert e_all > 0 and e_none == 0.0
 
 
-@pytest.mark.gpu
-def test_gpu_photoba_matches_oracle(pkg, O):
-    seq, vs, T, frames, imgs, P, Pp = _scene(pkg, O)
-    n = len(frames)
+def _gpu_and_oracle_on_the_same_map(pkg, O, n=6):
+    """Fuse on the GPU (with vis_), fuse in the oracle, then give the oracle the GPU's voxel values: both BA implementations
+    start from identical maps (key sets and vis_ are bit-exact anyway, tests/test_gpu_parity.py)."""
+    seq, vs, T, frames, imgs, P, Pp = _scene(pkg, O, n=n)
     o = _oracle_map(O, seq, vs, T, frames)
-    g = pkg.GradSdf(vs, T, seq.W, seq.H, seq.K, capacity_log2=19)
-    g.enable_vis(32)
+    g = pkg.GradSdf(vs, T, seq.W, seq.H, seq.K, capacity_log2=20)
+    g.enable_vis(64)
     for d, R, t in frames:
         g.update(d, R, t)
-    ba = O.PhotoBA(o, imgs, Pp, np.arange(n))
-    g.ba_setup(imgs, Pp, np.arange(n))
-    e_o, e_g = ba.energy(), g.ba_energy()
-    assert e_g == pytest.approx(e_o, rel=2e-3)
+    keys, pay = g.export(sorted=True)
+    assert o.set_payload(keys, pay) == 0 and o.count() == len(keys)
+    return seq, g, o, imgs, P, Pp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [6, 50])
+def test_gpu_photoba_steps_match_oracle(pkg, O, n):
+    """Every sweep of PhotometricOptimizer against the oracle FROM IDENTICAL STATE (same voxel values, same poses), at the
+    bar of BASELINE.json's north_star (1e-4 on distance and pose; energy to 1e-4 relative): getEnergy, one solvePose, one
+    solveDist.  n = 50 keyframes is the size of BASELINE config C5."""
+    seq, g, o, imgs, P, Pp = _gpu_and_oracle_on_the_same_map(pkg, O, n=n)
+    idx = np.arange(n)
+    ba = O.PhotoBA(o, imgs, Pp, idx)
+    g.ba_setup(imgs, Pp, idx)
+    # the reference adds ~10^5 .. 10^6 float terms into one float in hash-map order: its own value is uncertain at the 1e-3
+    # level; the GPU sweep (double partial sums) is held to the order-independent sum of the same terms
+    e_o, e_g = ba.energy_f64(), g.ba_energy()
+    assert e_o > 0 and e_g == pytest.approx(e_o, rel=1e-4)
+    assert ba.energy() == pytest.approx(e_o, rel=3e-3)
     ba.solve_pose()
     g.ba_solve_pose()
-    assert np.abs(g.ba_poses() - ba.poses()).max() < 2e-4
-    e_o, e_g = ba.energy(), g.ba_energy()
-    assert e_g == pytest.approx(e_o, rel=5e-3)
-    ba.solve_dist()
+    step = np.abs(ba.poses() - Pp).max()
+    assert step > 1e-3                                           # the step is real ...
+    assert np.abs(g.ba_poses() - ba.poses()).max() < 1e-4         # ... and the same (measured: 4e-6)
+    # the distance step from identical state again: the oracle takes the GPU's poses
+    Pg = g.ba_poses()
+    ba2 = O.PhotoBA(o, imgs, Pg, idx)
+    assert g.ba_energy() == pytest.approx(ba2.energy_f64(), rel=1e-4)
+    before = g.export(sorted=True)[1][:, 0].copy()
+    ba2.solve_dist()
     g.ba_solve_dist()
     ko, po = o.export()
-    kg, pg = g.export()
+    kg, pg = g.export(sorted=True)
     assert np.array_equal(kg, ko)
-    assert np.abs(pg[:, 0] - po[:, 0]).max() < 2e-4             # distances after the Gauss-Newton step
-    e_o, e_g = ba.energy(), g.ba_energy()
-    assert e_g == pytest.approx(e_o, rel=1e-2)
+    assert np.abs(pg[:, 0] - before).max() > 1e-4                # distances did move ...
+    assert np.abs(pg[:, 0] - po[:, 0]).max() < 1e-6              # ... identically (measured: 7e-9)
+    assert g.ba_energy() == pytest.approx(ba2.energy_f64(), rel=1e-4)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_photoba_optimize_matches_oracle(pkg, O):
+    """The whole optimize() (:611-662) from identical state: same number of steps, the energy after every pose / distance
+    step within 3e-3 (the oracle's optimize() uses the reference's single-float energy sum, uncertain at that level -- see
+    the step test; single sweeps agree to 1e-5), final poses within 1e-4, and the optimisation does its job (energy
+    down, poses back towards the truth)."""
+    seq, g, o, imgs, P, Pp = _gpu_and_oracle_on_the_same_map(pkg, O, n=6)
+    n = 6
+    ba = O.PhotoBA(o, imgs, Pp, np.arange(n))
+    g.ba_setup(imgs, Pp, np.arange(n))
     conv_g, en_g = g.ba_optimize(5)
     conv_o, en_o = ba.optimize(5)
-    m = min(len(en_g), len(en_o))
-    assert m >= 5 and abs(len(en_g) - len(en_o)) <= 2
-    assert np.allclose(en_g[:m], en_o[:m], rtol=2e-2)           # the whole energy trajectory of optimize()
+    assert conv_g == conv_o and len(en_g) == len(en_o) >= 5
+    assert np.allclose(en_g, en_o, rtol=3e-3)
+    assert np.abs(g.ba_poses() - ba.poses()).max() < 1e-4
     assert en_g[-1] < 0.3 * en_g[0]
     assert np.abs(g.ba_poses() - P).max() < 0.5 * np.abs(Pp - P).max()
     g.close()

@@ -17,7 +17,9 @@ def main():
     ap.add_argument("--frames", type=int, default=2000)
     ap.add_argument("--out", default="/tmp/c4_mesh.ply")
     ap.add_argument("--dist-backend", default="nccl")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "allgather"])
+    ap.add_argument("--exchange", default="c-abi", choices=["c-abi", "allreduce", "allgather"],
+                    help="c-abi: gsdf_merge_allreduce (pack -> ncclAllReduce -> unpack inside libgsdf, communicator created before "
+                         "the timed exchange); allreduce / allgather: the torch.distributed harness of parallel.py")
     ap.add_argument("--force-exchange", action="store_true", help="run the exchange also with one rank (degenerate, for testing)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -45,17 +47,34 @@ def main():
         for d in dev:
             g.L.gsdf_dev_free(g.h, d)
         g._dev = []
-    t0 = time.perf_counter()
     exchanged = 0
+    comm = None
+    if (world > 1 or args.force_exchange) and args.exchange == "c-abi":
+        # communicator set-up is NOT part of the exchange time: rank 0's RCCL id travels through torch.distributed
+        idt = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(pkg.binding.rccl_unique_id()), dtype=torch.uint8).clone()
+        if world > 1:
+            idt = idt.cuda() if args.dist_backend == "nccl" else idt
+            dist.broadcast(idt, src=0)
+        comm = pkg.binding.rccl_comm_init(world, bytes(idt.cpu().numpy().tobytes()), rank, local)
+        if world > 1:
+            dist.barrier()
+    t0 = time.perf_counter()
     if world > 1 or args.force_exchange:
-        if world == 1 and not dist.is_initialized():
+        if args.exchange != "c-abi" and world == 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group(args.dist_backend, rank=0, world_size=1)
-        if args.exchange == "allreduce":
+        if args.exchange == "c-abi":
+            nb, nbytes = g.merge_allreduce_rccl(comm)
+            exchanged = nb * 64
+        elif args.exchange == "allreduce":
             exchanged = pkg.parallel.allreduce_merge(pkg.parallel.GpuBlockOps(g, 23), dist, device="cuda") * 64
         else:
             exchanged = pkg.parallel.exchange_and_merge(g, dist)
     t_merge = time.perf_counter() - t0
+    if comm is not None:
+        pkg.binding.rccl_comm_destroy(comm)
     if world > 1:
         tt = torch.tensor([t_fuse, t_merge], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
