@@ -619,9 +619,10 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                  * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
                  * overflow, and the distinct voxels of one wave instruction never compete for a bucket.
                  * (The HBM table keeps the full 64-bit finaliser.) */
-                static_assert(FUSE_NB == 512 || FUSE_NB == 384, "lattice constants exist for 512 and 384 buckets");
+                static_assert(FUSE_NB == 512 || FUSE_NB == 384 || FUSE_NB == 256, "lattice constants exist for 512, 384 and 256 buckets");
                 if (FUSE_NB == 512) bk[j] = (lx3 + 98u * ly3 + 143u * lz3) & 511u;
-                else bk[j] = (lx3 + 65u * ly3 + 138u * lz3) % 384u;            /* 3 workgroups per CU: min distance 7.9 */
+                else if (FUSE_NB == 256) bk[j] = (lx3 + 7u * ly3 + 72u * lz3) & 255u;      /* experiments: min distance 6.9 */
+                else bk[j] = (lx3 + 65u * ly3 + 138u * lz3) % 384u;            /* experiments: min distance 7.9 */
             }
             /* 2.-4. look the voxels up in the LDS table.  All pending samples of the batch advance
              *    together: bucket (4 keys) = one ds_read_b128, match / first-empty by selects, at most
@@ -799,10 +800,13 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=v"(rb[e]) : "v"(P[e]) : "memory");
             }
             static_assert(NE >= 2 && NE <= 4, "the wait statement names NE x 2 destination registers");
-            /* (the middle operands repeat earlier ones when NE < 4) */
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[NE - 2]), "+v"(rb[NE - 2]), "+v"(ra[NE - 1]), "+v"(rb[NE - 1])
-                         :: "memory");
+            if constexpr (NE == 4)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[2]), "+v"(rb[2]), "+v"(ra[3]), "+v"(rb[3]) :: "memory");
+            else if constexpr (NE == 3)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[2]), "+v"(rb[2]) :: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]) :: "memory");
             if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 1], T - TF); TF = T; }
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
