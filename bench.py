@@ -225,15 +225,19 @@ def main():
             if conv:
                 o2.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3], omp=True)
         dto = time.perf_counter() - tc
-        # ... and with every host core in the tracker's reduction; the fusion stays serialised by
-        # the reference's `omp critical` (MapGradPixelSdfOmp.cpp:112) whatever the thread count
+        # ... and with every host core in the tracker's parallel-for.  Only the tracker: the fusion keeps
+        # the 4 threads the reference's tracker leaves set (omp_set_num_threads(4), RigidPointOptimizerOmp.cpp:68) -- its
+        # `omp critical` (MapGradPixelSdfOmp.cpp:112) serialises the map update whatever the thread count, and with hundreds
+        # of threads the contention makes a frame take minutes.
         ncores = os.cpu_count() or 1
-        o3 = O.Oracle(vs, T, W, H, seq.K, threads=ncores)
+        o3 = O.Oracle(vs, T, W, H, seq.K, threads=4)
         tc = time.perf_counter()
         o3.update(frames[0][0], quat_to_R(p0[3:]), t0, omp=True)
         pose = p0.copy()
         for i in range(1, no):
+            o3.set_threads(ncores)
             conv, pose, _, _, _ = o3.track(frames[i][0], pose, omp=True)
+            o3.set_threads(4)
             if conv:
                 o3.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3], omp=True)
         dta = time.perf_counter() - tc
@@ -253,7 +257,7 @@ def main():
                "omp4_value": round((no - 1) / dto, 3) if no > 1 else 0.0,
                "omp4_note": "reference's OMP structure (fusion inside omp critical, 4-thread tracker), first %d frames" % no,
                "omp_all_value": round((no - 1) / dta, 3) if no > 1 else 0.0,
-               "omp_all_note": "the same with %d threads (all host cores) in the tracker, first %d frames" % (ncores, no)}
+               "omp_all_note": "the same with %d threads (all host cores) in the tracker's parallel-for, 4 in the fusion, first %d frames" % (ncores, no)}
 
     # HBM traffic of one k_fuse launch: PMC counters cannot be read from inside the process, so they come from the committed
     # rocprofv3 --pmc passes over this very command (profiles/pmc_latest.json names file and command); reported only for

@@ -95,6 +95,10 @@ class Oracle:
             self.L.gsdfo_destroy(self.h)
             self.h = None
 
+    def set_threads(self, threads):
+        """Threads of the OMP-structured variants (update(omp=True), track(omp=True))."""
+        self.L.gsdfo_set_threads(self.h, int(threads))
+
     def normals_cache(self):
         out = np.empty((11, self.H, self.W), np.float32)
         self.L.gsdfo_normals_cache(self.h, _fp(out))
