@@ -137,16 +137,19 @@ def main():
 
     # fused-only flavour (GT poses, update only) over the same K frames.  Measured BEFORE the event-timed replay:
     # recording timing events switches the HIP queue to a slower, profiled dispatch for the rest of the process.
-    g.reset()
-    sync_all()
-    tf = time.perf_counter()
-    for j, i in enumerate(range(1 + Wm, 1 + Wm + K)):
-        g.update_dev(dev[i], frames[i][1], frames[i][2])
-        if j % 32 == 31:
-            g.sync()                 # hundreds of launches queued without a sync make the HIP runtime throttle the host
-    t_enq = time.perf_counter() - tf
-    sync_all()
-    fused_fps = K / (time.perf_counter() - tf)
+    # Two rounds, the second one counts: the first long run of back-to-back launches in a process makes the HIP runtime grow
+    # its launch resources once (one launch call of ~40 ms).
+    for rnd in range(2):
+        g.reset()
+        sync_all()
+        tf = time.perf_counter()
+        for j, i in enumerate(range(1 + Wm, 1 + Wm + K)):
+            g.update_dev(dev[i], frames[i][1], frames[i][2])
+            if j % 32 == 31:
+                g.sync()             # hundreds of launches queued without a sync make the HIP runtime throttle the host
+        t_enq = time.perf_counter() - tf
+        sync_all()
+        fused_fps = K / (time.perf_counter() - tf)
     if os.environ.get("GSDF_BENCH_DEBUG"):
         print("fused-only: enqueue %.1f us/frame, total %.1f us/frame" % (t_enq / K * 1e6, 1e6 / fused_fps), file=sys.stderr)
 

@@ -511,11 +511,16 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             /* a tile that writes nothing itself has nothing to hand over: publish at once */
             if (!ordered) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        /* distinct voxels the tile will touch ~ samples / (pixels per voxel face): far tiles (or small
-         * voxels) would overflow the LDS table, so they are walked as 2 or 4 row bands */
+        /* Distinct voxels the tile will touch: the volume its rays sweep (pixels x samples / pixels per voxel face) plus
+         * half a voxel around that prism (a side of the tile is `side` voxels wide at depth zf).  Calibrated against
+         * counted voxels on the bench stream: counted / estimate = 0.93 median, never above 1 for tiles that matter.  Far
+         * tiles (or small voxels) would overflow the LDS table -- and a table filled beyond ~80 % probes long and drops
+         * samples into the deferred list -- so they are walked as 2 or 4 row bands, each flushed on its own. */
         const float zf = __uint_as_float(zmax_bits);
-        const float ppv = fmaxf(1.f, (g.fx * g.vs / zf) * (g.fy * g.vs / zf) * 1.1f);
-        const float est = n_valid * (float)nk_all / ppv;
+        const float ppr = (g.fx * g.vs / zf) * (g.fy * g.vs / zf);      /* pixels per voxel face at the far end */
+        const float side = (float)FUSE_T * __builtin_amdgcn_rsqf(ppr);
+        const float samples = n_valid * (float)nk_all;
+        const float est = fminf(samples, samples / ppr + (side * side + 2.f * side * (float)nk_all) * __builtin_amdgcn_sqrtf(n_valid * (1.f / 256.f)));
         n_pass = est <= 0.8f * FUSE_LCAP ? 1 : (est <= 1.6f * FUSE_LCAP ? 2 : 4);
         if (GSDF_EXPERIMENT(a.debug, 256)) n_pass = 1;
         if (GSDF_EXPERIMENT(a.debug, 512)) n_pass = 4;
@@ -732,24 +737,26 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
      * together, so the dependent HBM round trips (bucket keys -> payload) of its entries overlap. */
     if (!GSDF_EXPERIMENT(a.debug, 1)) {
         constexpr int NE = (FUSE_LCAP + FUSE_THREADS - 1) / FUSE_THREADS;
-        unsigned long long ekey[NE], bkey[NE], k0[NE];
+        constexpr uint32_t NOREC = 0xFFFFFFFFu;
+        unsigned long long bkey[NE], k0[NE];
         uint32_t home[NE];
-        gsdf_payload* P[NE];
+        uint32_t rec[NE];                   /* the entry's voxel record: index in the block, then index in the map; NOREC = no entry */
+        uint32_t have = 0u;                 /* bit e: slot e of this lane holds a voxel */
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             /* back from the tile-local key to the packed voxel key of the HBM map */
             const int i = tid + FUSE_THREADS * e;
             const uint32_t lk = i < FUSE_LCAP ? L.key[i] : FUSE_LKEY_EMPTY;
-            ekey[e] = lk == FUSE_LKEY_EMPTY ? GSDF_KEY_EMPTY
-                                            : gsdf_key_pack(ox + (int)(lk & 1023u), oy + (int)((lk >> 10) & 1023u), oz + (int)(lk >> 20));
-            bkey[e] = gsdf_block_key(ekey[e]);
+            const unsigned long long ek = gsdf_key_pack(ox + (int)(lk & 1023u), oy + (int)((lk >> 10) & 1023u), oz + (int)(lk >> 20));
+            bkey[e] = gsdf_block_key(ek);
             home[e] = gsdf_hash(bkey[e]) & a.tab.block_mask;
-            P[e] = nullptr;
+            rec[e] = lk == FUSE_LKEY_EMPTY ? NOREC : gsdf_block_local(ek);
+            if (lk != FUSE_LKEY_EMPTY) have |= 1u << e;
             k0[e] = GSDF_KEY_EMPTY;
         }
 #pragma unroll
         for (int e = 0; e < NE; ++e)
-            if (ekey[e] != GSDF_KEY_EMPTY) k0[e] = a.tab.bkeys[home[e]];         /* 512 KB of block keys: L2 hits */
+            if ((have >> e) & 1u) k0[e] = a.tab.bkeys[home[e]];                   /* 512 KB of block keys: L2 hits */
         unsigned long long TF = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
         /* meanwhile one wave waits for the adjacent tiles of lower colour (lane j watches neighbour j) */
         if (wave == 0 && L.ordered && pass == 0) {
@@ -776,13 +783,16 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 }
             }
         }
+        {
+            /* the blocks of this lane's entries, looked up (and inserted) together: the probe chains overlap */
+            int blk[NE];
+            gsdf_block_lookup_n<NE, true>(a.tab, bkey, home, k0, have, blk);
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            if (ekey[e] == GSDF_KEY_EMPTY) continue;
-            /* block already at its home entry: the common case; else probe on / insert the block */
-            const int b = k0[e] == bkey[e] ? (int)home[e] : gsdf_block_find_or_insert(a.tab, bkey[e], home[e], k0[e]);
-            if (b < 0) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); ekey[e] = GSDF_KEY_EMPTY; L.key[tid + FUSE_THREADS * e] = FUSE_LKEY_EMPTY; }
-            else P[e] = a.tab.vox + ((size_t)b * GSDF_BLOCK_VOX + gsdf_block_local(ekey[e]));
+            for (int e = 0; e < NE; ++e) {
+                if (!((have >> e) & 1u)) continue;
+                if (blk[e] < 0) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); rec[e] = NOREC; L.key[tid + FUSE_THREADS * e] = FUSE_LKEY_EMPTY; }
+                else rec[e] += (uint32_t)blk[e] * GSDF_BLOCK_VOX;                  /* < 2^31 records (gsdf_create) */
+            }
         }
         __syncthreads();                                              /* the wait above is over (or timed out) */
         if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 0], T - TF); TF = T; }
@@ -795,9 +805,10 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 ra[e] = gsdf_u32x4{ 0u, 0u, 0u, 0u }; rb[e] = ra[e];
-                if (ekey[e] == GSDF_KEY_EMPTY) continue;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ra[e]) : "v"(P[e]) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=v"(rb[e]) : "v"(P[e]) : "memory");
+                if (rec[e] == NOREC) continue;
+                const gsdf_payload* pe = a.tab.vox + rec[e];
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ra[e]) : "v"(pe) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=v"(rb[e]) : "v"(pe) : "memory");
             }
             static_assert(NE >= 2 && NE <= 4, "the wait statement names NE x 2 destination registers");
             if constexpr (NE == 4)
@@ -810,9 +821,10 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 1], T - TF); TF = T; }
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                if (ekey[e] == GSDF_KEY_EMPTY) continue;
+                if (rec[e] == NOREC) continue;
                 const int i = tid + FUSE_THREADS * e;
                 const uint32_t* G = &L.g[3 * i];
+                gsdf_payload* pe = a.tab.vox + rec[e];
                 gsdf_u32x4 oa, ob;
                 oa.x = __float_as_uint(__uint_as_float(ra[e].x) + fix2f(L.ws[2 * i]));
                 oa.y = __float_as_uint(__uint_as_float(ra[e].y) + fix2f(L.ws[2 * i + 1]));
@@ -820,9 +832,9 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 oa.w = __float_as_uint(__uint_as_float(ra[e].w) + fix2f(G[1]));
                 ob.x = __float_as_uint(__uint_as_float(rb[e].x) + fix2f(G[2]));
                 ob.y = a.tag; ob.z = 0u; ob.w = 0u;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(P[e]), "v"(oa) : "memory");
-                asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(P[e]), "v"(ob) : "memory");
-                vis_mark(a, P[e], frame_cur);
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(pe), "v"(oa) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(pe), "v"(ob) : "memory");
+                vis_mark(a, pe, frame_cur);
             }
             /* hand the voxels on: every storing wave drains its stores, then ONE lane publishes the flag.  (Tiles of
              * the highest colour drain too although nobody waits for their flag: the deferred contributions are
@@ -837,9 +849,9 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             unsigned int my_defer = 0u;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                if (ekey[e] == GSDF_KEY_EMPTY) continue;
-                L.key[tid + FUSE_THREADS * e] = FUSE_LKEY_DEFER | (uint32_t)(P[e] - a.tab.vox);   /* < 2^31 records (gsdf_create) */
-                vis_mark(a, P[e], frame_cur);
+                if (rec[e] == NOREC) continue;
+                L.key[tid + FUSE_THREADS * e] = FUSE_LKEY_DEFER | rec[e];
+                vis_mark(a, a.tab.vox + rec[e], frame_cur);
                 ++my_defer;
             }
             if (my_defer) atomicAdd(&L.n_defer, my_defer);
@@ -1102,13 +1114,16 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
         /* stage C: the voxel record (neighbouring pixels share lines: 4 x-adjacent voxels per line) */
         const gsdf_payload* P[TRK_PPT];
         float2 pa[TRK_PPT], pb[TRK_PPT], pc2[TRK_PPT];
+        int blk[TRK_PPT];
+        {
+            uint32_t want = 0u;
+#pragma unroll
+            for (int j = 0; j < TRK_PPT; ++j) want |= ok[j] ? 1u << j : 0u;
+            gsdf_block_lookup_n<TRK_PPT, false>(tab, bkey, home, k0, want, blk);   /* the pixels' probe chains overlap */
+        }
 #pragma unroll
         for (int j = 0; j < TRK_PPT; ++j) {
-            P[j] = nullptr;
-            if (ok[j]) {
-                const int b = k0[j] == bkey[j] ? (int)home[j] : gsdf_block_find(tab, bkey[j], home[j], k0[j]);
-                if (b >= 0) P[j] = tab.vox + ((size_t)b * GSDF_BLOCK_VOX + gsdf_block_local(key[j]));
-            }
+            P[j] = blk[j] >= 0 ? tab.vox + ((size_t)blk[j] * GSDF_BLOCK_VOX + gsdf_block_local(key[j])) : nullptr;
             if (P[j]) {
                 const float2* q = reinterpret_cast<const float2*>(P[j]);
                 pa[j] = q[0]; pb[j] = q[1]; pc2[j] = q[2];

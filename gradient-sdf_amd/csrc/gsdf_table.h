@@ -91,42 +91,70 @@ __host__ __device__ __forceinline__ unsigned long long gsdf_hash64(unsigned long
     return k;
 }
 __host__ __device__ __forceinline__ uint32_t gsdf_hash(unsigned long long k) { return (uint32_t)gsdf_hash64(k); }
-/* probe step of a block key: odd, so the sequence h, h + step, h + 2 step, ... visits every entry */
+/* Probe sequence of a block key with home entry h0: double hashing -- h0, h0 + step, h0 + 2 step, ... with an odd
+ * step, so every entry is visited.  (Measured alternative: the 16 entries of the home entry's 128-byte line first, so
+ * that later probes are L1 hits -- slower at every load factor: in-line clustering makes the longest chain of a wave,
+ * which is what a wave waits for, several times longer.) */
 __host__ __device__ __forceinline__ uint32_t gsdf_probe_step(unsigned long long bk) {
     return (uint32_t)(gsdf_hash64(bk) >> 32) | 1u;
 }
 
 #if defined(__HIPCC__)
-/* Block lookup with insertion; `first` is the key already loaded from the home entry `h` (callers
- * load it early to overlap the round trip).  Keys never change once written and records are zeroed by
- * the table clear, so keys are read with plain loads: a stale read can only show EMPTY, and then the
- * CAS is authoritative.  Returns the block index or -1 when the probe budget is exhausted. */
+/* Looks N block keys up TOGETHER: every round evaluates probe r of all pending keys and then issues probe r + 1 of those
+ * still pending back to back, so a lane's N chains of dependent loads overlap (a wave's round count is the longest
+ * chain of any of its lanes, not the sum over the N keys).  k[e] = the key already loaded from the home entry h[e]
+ * (callers load it early; h and k are scratch afterwards); bit e of `pend` = key e takes part.  b[e] = block index or -1 (INSERT: probe budget
+ * exhausted = table full; else: block absent).
+ * Keys never change once written and records are zeroed by the table clear, so keys are read with plain loads: a stale
+ * read can only show EMPTY, and then the CAS is authoritative (INSERT) -- kernels that only look up run after the
+ * inserting kernel has ended. */
+template <int N, bool INSERT>
+__device__ __forceinline__ void gsdf_block_lookup_n(const gsdf_table& T, const unsigned long long (&bk)[N], uint32_t (&h)[N],
+                                                    unsigned long long (&k)[N], uint32_t pend, int (&b)[N]) {
+    uint32_t step[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) { b[e] = -1; step[e] = 1u; }
+    for (int r = 0; r < GSDF_MAX_PROBE; ++r) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            if (!((pend >> e) & 1u)) continue;
+            unsigned long long kk = k[e];
+            if (INSERT && kk == GSDF_KEY_EMPTY) {
+                kk = atomicCAS(&T.bkeys[h[e]], GSDF_KEY_EMPTY, bk[e]);
+                if (kk == GSDF_KEY_EMPTY) kk = bk[e];
+            }
+            if (kk == bk[e]) { b[e] = (int)h[e]; pend &= ~(1u << e); }
+            else if (!INSERT && kk == GSDF_KEY_EMPTY) pend &= ~(1u << e);   /* entries are never freed: an empty one ends the chain */
+        }
+        if (!__any(pend != 0u)) break;
+        if (r == 0) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) step[e] = gsdf_probe_step(bk[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e)
+            if ((pend >> e) & 1u) { h[e] = (h[e] + step[e]) & T.block_mask; k[e] = T.bkeys[h[e]]; }
+    }
+}
+
+/* Single-key forms.  `first` is the key already loaded from the home entry `h`.  Return the block index or -1. */
 __device__ __forceinline__ int gsdf_block_find_or_insert(const gsdf_table& T, unsigned long long bk, uint32_t h,
                                                          unsigned long long first) {
-    unsigned long long k = first;
-    const uint32_t step = gsdf_probe_step(bk);
-    for (int probe = 0; probe < GSDF_MAX_PROBE; ++probe) {
-        if (k == GSDF_KEY_EMPTY) {
-            k = atomicCAS(&T.bkeys[h], GSDF_KEY_EMPTY, bk);
-            if (k == GSDF_KEY_EMPTY) return (int)h;
-        }
-        if (k == bk) return (int)h;
-        h = (h + step) & T.block_mask;
-        k = T.bkeys[h];
-    }
-    return -1;
+    const unsigned long long bks[1] = { bk };
+    uint32_t hs[1] = { h };
+    unsigned long long ks[1] = { first };
+    int bs[1];
+    gsdf_block_lookup_n<1, true>(T, bks, hs, ks, 1u, bs);
+    return bs[0];
 }
 __device__ __forceinline__ int gsdf_block_find(const gsdf_table& T, unsigned long long bk, uint32_t h,
                                                unsigned long long first) {
-    unsigned long long k = first;
-    const uint32_t step = gsdf_probe_step(bk);
-    for (int probe = 0; probe < GSDF_MAX_PROBE; ++probe) {
-        if (k == bk) return (int)h;
-        if (k == GSDF_KEY_EMPTY) return -1;           /* entries are never freed: an empty one ends the chain */
-        h = (h + step) & T.block_mask;
-        k = T.bkeys[h];
-    }
-    return -1;
+    const unsigned long long bks[1] = { bk };
+    uint32_t hs[1] = { h };
+    unsigned long long ks[1] = { first };
+    int bs[1];
+    gsdf_block_lookup_n<1, false>(T, bks, hs, ks, 1u, bs);
+    return bs[0];
 }
 
 /* tsdf_[vi] (operator[]: find, insert zero-initialised if absent) -- MapGradPixelSdf.cpp:109.
