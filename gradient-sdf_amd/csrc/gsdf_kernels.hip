@@ -394,34 +394,34 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
     /* main_scan_3d.cpp:261: if (conv) update.  The launch may have been queued before optimize() ended (the host
      * issues it behind every batch of passes): it runs only once the pose iteration is done AND converged; the
      * launch that finds it done but NOT converged only writes the frame's log row. */
+    /* everything the prologue needs from memory is requested at once (one scalar round trip, not three in a row):
+     * the gate, the device pose, the workgroup's tile */
+    const gsdf_dev_state* st_in = a.st;
+    const int done = st_in->done, conv = st_in->converged;
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = st_in->R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = st_in->pose7[i];
+    const uint32_t tile_id = a.tile_order[blockIdx.x];
     if (a.use_dev_pose) {
-        const int done = a.st->done, conv = a.st->converged;
         if (!(done && conv)) {
             if (done && blockIdx.x == 0 && tid == 0) fuse_log_row(a);
             return;
         }
-    }
-    const unsigned long long T0 = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
-    float R[9], t[3];
-    if (a.use_dev_pose) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = a.st->R[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t[i] = a.st->pose7[i];
     } else {
 #pragma unroll
         for (int i = 0; i < 9; ++i) R[i] = a.pose.R[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) t[i] = a.pose.t[i];
     }
+    const unsigned long long T0 = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
 
     const gsdf_frame_geom& g = a.g;
     const long long frame_cur = a.vis ? a.st->frame_cur : 0;   /* Sdf::counter_ of this update (snapshot by k_normals) */
     const int wave = tid >> 6, lane = tid & 63;
     const int zslice = wave >> 2;
     const int lx = lane & 7, ly = lane >> 3;
-    const int bid = (int)blockIdx.x;
-    const uint32_t tile_id = a.tile_order[bid];
     const int tile_x = (int)(tile_id & 0xFFFFu), tile_y = (int)(tile_id >> 16);
     bool valid = false;
     float z = 0.f;
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 const float pxw = s * Rxy.x + t[0], pyw = s * Rxy.y + t[1], pzw = s * Rxy.z + t[2];   /* :103 */
                 /* float2vox (:104): std::round; the rounded value is kept as a float too -- (float)vi == the rounded
                  * float for every index that fits an int, so vox2float needs no second conversion */
-                const float rx = roundf(g.inv_vs * pxw), ry = roundf(g.inv_vs * pyw), rz = roundf(g.inv_vs * pzw);
+                const float rx = gsdf_roundf(g.inv_vs * pxw), ry = gsdf_roundf(g.inv_vs * pyw), rz = gsdf_roundf(g.inv_vs * pzw);
                 const int vx = (int)rx, vy = (int)ry, vz = (int)rz;
                 const float dx = g.vs * rx - t[0], dy = g.vs * ry - t[1], dz = g.vs * rz - t[2];
                 const float pc_z = gsdf_sum3(R[2] * dx, R[5] * dy, R[8] * dz);   /* :105  (Rt row 2) */
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                  * overflow, and the distinct voxels of one wave instruction never compete for a bucket.
                  * (The HBM table keeps the full 64-bit finaliser.) */
                 static_assert(FUSE_NB == 512 || FUSE_NB == 384 || FUSE_NB == 256, "lattice constants exist for 512, 384 and 256 buckets");
-                if (FUSE_NB == 512) bk[j] = (lx3 + 98u * ly3 + 143u * lz3) & 511u;
+                if (FUSE_NB == 512) bk[j] = (lx3 + __umul24(98u, ly3) + __umul24(143u, lz3)) & 511u;   /* 24-bit multiply-adds: full rate (v_mul_lo_u32 is quarter rate) */
                 else if (FUSE_NB == 256) bk[j] = (lx3 + 7u * ly3 + 72u * lz3) & 255u;      /* experiments: min distance 6.9 */
                 else bk[j] = (lx3 + 65u * ly3 + 138u * lz3) % 384u;            /* experiments: min distance 7.9 */
             }

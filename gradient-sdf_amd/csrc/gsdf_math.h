@@ -63,7 +63,10 @@ GSDF_HD float gsdf_weight(float sdf, float T, float inv_T) {
 GSDF_HD float gsdf_truncate(float sdf, float T) { return fmaxf(-T, fminf(T, sdf)); }
 
 /* MapGradPixelSdf::float2vox, one component -- MapGradPixelSdf.h:74-77 (std::round = half away from zero) */
-GSDF_HD int32_t gsdf_float2vox1(float inv_vs, float p) { return (int32_t)roundf(inv_vs * p); }
+/* std::round as trunc(x + copysign(0.5 - 2^-25, x)): bit-identical to roundf for EVERY float (checked exhaustively,
+ * tools/round_check.c) in 3 VALU operations; the generic lowering (trunc, |x - t| >= 0.5, copysign, add) takes 6. */
+GSDF_HD float gsdf_roundf(float x) { return truncf(x + copysignf(0.49999997f, x)); }
+GSDF_HD int32_t gsdf_float2vox1(float inv_vs, float p) { return (int32_t)gsdf_roundf(inv_vs * p); }
 
 /* Eigen QuaternionBase::toRotationMatrix (SE3::rotationMatrix(), RigidPointOptimizer.cpp:53) */
 GSDF_HD void gsdf_quat_to_R(const float* q /*x y z w*/, float* R) {
