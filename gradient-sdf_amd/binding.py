@@ -71,6 +71,8 @@ def load_test_lib():
     L.gsdf_debug_flags.argtypes = [C.c_void_p, C.c_int]
     L.gsdf_debug_read.restype = C.c_int
     L.gsdf_debug_read.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    L.gsdf_debug_trace.restype = C.c_int
+    L.gsdf_debug_trace.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
     return L
 
 

@@ -203,9 +203,25 @@ const char* gsdf_last_error(void) { return g_gsdf_err.c_str(); }
 /* Test / measurement build only (libgsdf_test.so, make EXPERIMENTS=1); not part of include/gsdf.h and absent from the
  * production library.  Per context.  Bits 0-15 go to k_fuse: 4 every tile defers, 256 single band, 512 four bands,
  * 8192 every hand-off wait expires at once, 1/2/16/32/128/4096 ablation switches of tools/; bits 16+ go to the tracker. */
+#define GSDF_TRACE_WG 8192
+#define GSDF_TRACE_COLS 16
 int gsdf_debug_flags(gsdf_ctx* c, int flags) {
     if (!c) return GSDF_ERR_INVALID;
     c->debug = flags;
+    if (flags & 64) {                                  /* k_fuse trace: GSDF_TRACE_COLS time stamps per workgroup, pointer in dbg[23] */
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
+        if (!c->trace && hipMalloc((void**)&c->trace, (size_t)GSDF_TRACE_WG * GSDF_TRACE_COLS * 8) != hipSuccess) return GSDF_ERR_HIP;
+        if (hipMemset(c->trace, 0, (size_t)GSDF_TRACE_WG * GSDF_TRACE_COLS * 8) != hipSuccess) return GSDF_ERR_HIP;
+        const unsigned long long ptr = (unsigned long long)(uintptr_t)c->trace;
+        if (hipMemcpy(&c->st->dbg[23], &ptr, 8, hipMemcpyHostToDevice) != hipSuccess) return GSDF_ERR_HIP;
+    }
+    return GSDF_OK;
+}
+/* the trace of the last k_fuse launch: n_wg rows of GSDF_TRACE_COLS (16) values */
+int gsdf_debug_trace(gsdf_ctx* c, unsigned long long* out, int n_wg) {
+    if (!c || !out || !c->trace || n_wg > GSDF_TRACE_WG) return GSDF_ERR_INVALID;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
+    if (hipMemcpy(out, c->trace, (size_t)n_wg * GSDF_TRACE_COLS * 8, hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
     return GSDF_OK;
 }
 int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[24]) {
@@ -276,6 +292,7 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
 
 void gsdf_destroy(gsdf_ctx* c) {
     if (!c) return;
+    if (c->trace) { (void)hipFree(c->trace); c->trace = nullptr; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);

@@ -75,6 +75,7 @@ struct gsdf_ctx {
     unsigned int* progress_dev = nullptr;
     int adaptive = 1;                              /* issue tracker passes in batches, following the device (see enqueue_track) */
     int first_batch = 5, next_batch = 4;           /* launches per batch: 5 cover the usual <= 4 passes + their last head */
+    unsigned long long* trace = nullptr;           /* test build: per-workgroup time stamps of k_fuse (gsdf_debug_flags & 64) */
     int debug = 0;                                 /* path-forcing / measurement switches (gsdf_debug_flags; test build only) */
     float* frame_log = nullptr;
     long long frame_log_cap = 0;

@@ -19,8 +19,11 @@
  * -DGSDF_EXPERIMENTS: libgsdf_test.so.  The production library contains none of them. */
 #ifdef GSDF_EXPERIMENTS
 #define GSDF_EXPERIMENT(flags, mask) (((flags) & (mask)) != 0)
+/* k_fuse trace (debug bit 64): thread 0 of every workgroup stores time stamp `col` of its row (plain stores, no atomics) */
+#define GSDF_TRACE(a, tr, col) do { if (GSDF_EXPERIMENT((a).debug, 64) && threadIdx.x == 0) (tr)[col] = wall_clock64(); } while (0)
 #else
 #define GSDF_EXPERIMENT(flags, mask) (false)
+#define GSDF_TRACE(a, tr, col) do { } while (0)
 #endif
 #include "gsdf_math.h"
 
@@ -416,6 +419,16 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
         for (int i = 0; i < 3; ++i) t[i] = a.pose.t[i];
     }
     const unsigned long long T0 = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
+    unsigned long long* tr = nullptr;                         /* trace row of this workgroup (test build, debug bit 64) */
+    if (GSDF_EXPERIMENT(a.debug, 64)) {
+        tr = reinterpret_cast<unsigned long long*>(st_in->dbg[23]) + 16 * (size_t)blockIdx.x;
+        if (tid == 0) {
+            tr[0] = wall_clock64();
+            tr[14] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |              /* HW_ID */
+                     ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);       /* XCC_ID */
+            tr[15] = tile_id;
+        }
+    }
 
     const gsdf_frame_geom& g = a.g;
     const long long frame_cur = a.vis ? a.st->frame_cur : 0;   /* Sdf::counter_ of this update (snapshot by k_normals) */
@@ -556,6 +569,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
     unsigned int n_upd_w = 0u, n_val_w = 0u;                          /* wave-uniform counters */
     unsigned int dbg_go = 0u, dbg_full = 0u, dbg_lost = 0u;
     unsigned long long T1 = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
+    GSDF_TRACE(a, tr, 1);                                             /* prologue done */
     if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) atomicAdd(&a.st->dbg[4], T1 - T0);
     for (int pass = 0; pass < n_pass; ++pass) {
     /* lanes -> (pixel of the band, slice of the ray walk).  One band: as loaded above, FUSE_ZSPLIT slices.  Two bands
@@ -716,6 +730,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
     }
     __syncthreads();
     if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T2 = wall_clock64(); atomicAdd(&a.st->dbg[2], T2 - T1); T1 = T2; }
+    if (pass == 0) GSDF_TRACE(a, tr, 2);                              /* ray walk done (first band) */
     /* Flush the tile's distinct voxels: read-modify-write of the HBM payload with NO atomics.
      *
      * Mutual exclusion between tiles comes from two facts:
@@ -758,6 +773,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
         for (int e = 0; e < NE; ++e)
             if ((have >> e) & 1u) k0[e] = a.tab.bkeys[home[e]];                   /* 512 KB of block keys: L2 hits */
         unsigned long long TF = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
+        if (pass == 0) GSDF_TRACE(a, tr, 3);                          /* keys unpacked, home-entry loads issued */
         /* meanwhile one wave waits for the adjacent tiles of lower colour (lane j watches neighbour j) */
         if (wave == 0 && L.ordered && pass == 0) {
             bool need = false;
@@ -783,6 +799,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 }
             }
         }
+        if (pass == 0) GSDF_TRACE(a, tr, 4);                          /* neighbours of lower colour have published (wave 0) */
         {
             /* the blocks of this lane's entries, looked up (and inserted) together: the probe chains overlap */
             int blk[NE];
@@ -794,7 +811,9 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 else rec[e] += (uint32_t)blk[e] * GSDF_BLOCK_VOX;                  /* < 2^31 records (gsdf_create) */
             }
         }
+        if (pass == 0) GSDF_TRACE(a, tr, 5);                          /* wave 0: its blocks looked up */
         __syncthreads();                                              /* the wait above is over (or timed out) */
+        if (pass == 0) GSDF_TRACE(a, tr, 6);                          /* every wave has its blocks */
         if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 0], T - TF); TF = T; }
         const bool ordered = L.ordered != 0u;
         if (ordered) {
@@ -819,6 +838,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             else
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]) :: "memory");
             if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 1], T - TF); TF = T; }
+            if (pass == 0) GSDF_TRACE(a, tr, 7);                      /* wave 0: records arrived */
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 if (rec[e] == NOREC) continue;
@@ -840,10 +860,12 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
              * the highest colour drain too although nobody waits for their flag: the deferred contributions are
              * added by the last workgroup of this launch, after every tile's stores.) */
             if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 2], T - TF); TF = T; }
+            if (pass == 0) GSDF_TRACE(a, tr, 8);                      /* wave 0: stores issued */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 3], T - TF); TF = T; }
+            if (pass == 0) GSDF_TRACE(a, tr, 9);                      /* all stores drained, flag published */
         } else {
             /* near tile (or timed-out wait): everything goes through the deferred list */
             unsigned int my_defer = 0u;
@@ -889,6 +911,8 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
         __syncthreads();
     }
     }   /* pass */
+    GSDF_TRACE(a, tr, 10);                                            /* all bands done */
+    if (GSDF_EXPERIMENT(a.debug, 64) && tid == 0) tr[13] = (unsigned long long)n_pass;
     /* per-workgroup counters (plain stores into this workgroup's own row: no hot atomics) */
     if (lane == 0) { L.cnt[0][wave] = n_upd_w; L.cnt[1][wave] = n_val_w; }
     __syncthreads();

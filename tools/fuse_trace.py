@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of one k_fuse launch (test build, debug bit 64: thread 0 of every workgroup stores a time stamp at
+each phase boundary; 100 MHz clock).  Prints the phase durations by tile colour, when workgroups start, and how many
+workgroups are in which phase over the launch.   usage: fuse_trace.py [frame_index (default 20)] [extra debug flags]"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as G
+pkg = G.package()
+last = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+extra = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+n = last + 1
+seq = pkg.synth.Sequence("tum", 640, 480, n_frames=n, seed=0)
+vs = np.float32(0.01); T = np.float32(10) * vs
+frames = [seq.frame(i) for i in range(n)]
+L = pkg.binding.load_test_lib()
+g = pkg.GradSdf(vs, T, 640, 480, seq.K, capacity_log2=22, lib=L)
+dev = [g.upload(f[0]) for f in frames]
+for i in range(n - 1):
+    g.update_dev(dev[i], frames[i][1], frames[i][2])
+g.sync()
+g.debug_flags(64 | extra)
+g.update_dev(dev[n - 1], frames[n - 1][1], frames[n - 1][2])
+g.sync()
+NW = 1200
+buf = (ctypes.c_ulonglong * (NW * 16))()
+assert L.gsdf_debug_trace(g.h, buf, NW) == 0
+t = np.array(list(buf), dtype=np.int64).reshape(NW, 16)
+t0 = t[:, 0].min()
+ts = (t[:, :11] - t0) / 100.0          # us
+tile = t[:, 15]; tx = tile & 0xFFFF; ty = tile >> 16
+colour = (tx & 1) + 2 * (ty & 1)
+xcc = t[:, 14] >> 32
+hw = t[:, 14] & 0xFFFFFFFF
+npass = t[:, 13]
+single = npass == 1
+print("launch span %.1f us; workgroups %d, single band %d; per XCC: %s" % (ts[:, 10].max(), NW, single.sum(), np.bincount(xcc.astype(int), minlength=8).tolist()))
+names = ["prologue", "walk", "keys", "wait", "lookup(w0)", "lookup(all)", "rec loads", "stores", "drain+flag", "tail"]
+d = np.diff(ts[:, :11], axis=1)
+print("phase durations, us (mean | median | p90) over single-band workgroups")
+for c in list(range(4)) + [None]:
+    sel = single & ((colour == c) if c is not None else True)
+    print(" colour %s (%d tiles): total %.1f" % (c if c is not None else "all", sel.sum(), (ts[sel, 10] - ts[sel, 0]).mean()))
+    for k, nm in enumerate(names):
+        x = d[sel, k]
+        print("    %-12s %6.2f | %6.2f | %6.2f" % (nm, x.mean(), np.median(x), np.percentile(x, 90)))
+# start times: the dispatch rounds
+st = np.sort(ts[:, 0])
+print("start times us: wg 0 %.1f, 256 %.1f, 511 %.1f, 512 %.1f, 600 %.1f, 800 %.1f, 1000 %.1f, 1199 %.1f" % tuple(st[[0, 256, 511, 512, 600, 800, 1000, 1199]]))
+# occupancy of phases over time
+edges = np.arange(0, ts[:, 10].max() + 2, 2.0)
+print("time   running  prologue walk  flush(wait) flush(other)")
+for a in edges[:-1]:
+    m = a + 1.0
+    run = (ts[:, 0] <= m) & (ts[:, 10] > m)
+    pro = (ts[:, 0] <= m) & (ts[:, 1] > m)
+    wk = (ts[:, 1] <= m) & (ts[:, 2] > m)
+    wt = (ts[:, 3] <= m) & (ts[:, 4] > m)
+    fl = (ts[:, 2] <= m) & (ts[:, 10] > m) & ~wt
+    print("%5.0f  %6d  %6d  %5d  %6d  %6d" % (a, run.sum(), pro.sum(), wk.sum(), wt.sum(), fl.sum()))
+np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "fuse_trace.npy"), t)
+g.close()
