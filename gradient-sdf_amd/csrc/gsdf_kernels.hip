@@ -264,9 +264,6 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #define FUSE_LKEY_EMPTY 0xFFFFFFFFu      /* LDS keys are 32-bit: voxel coordinates relative to the tile origin, 10 bits each */
 #define FUSE_LKEY_DEFER 0x80000000u      /* flush: the entry goes to the deferred list, low 31 bits = voxel record index */
 #define FUSE_LPROBE 12
-#ifndef FUSE_BATCH
-#define FUSE_BATCH 1                     /* samples of a lane in flight through the LDS lookup: 1 measured fastest (2: +4 us, 3: +6 us per fusion) */
-#endif
 #ifndef FUSE_OCC
 #define FUSE_OCC (2 * FUSE_ZSPLIT)        /* waves per SIMD the register allocation must allow: 2 workgroups per CU */
 #endif
@@ -284,6 +281,13 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #endif
 #define FUSE_NSTAT (FUSE_SPREAD ? 8 : 4) /* waves of a workgroup that hold distinct pixels */
 typedef uint32_t gsdf_u32x4 __attribute__((ext_vector_type(4)));
+typedef float gsdf_f2 __attribute__((ext_vector_type(2)));           /* packed f32 arithmetic (v_pk_*_f32): two results per issue slot */
+/* a * b + c with a, b < 2^24 (b uniform): full rate, where the 32-bit v_mul_lo_u32 is quarter rate */
+__device__ __forceinline__ uint32_t gsdf_mad_u24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 
 struct fuse_args {
     gsdf_frame_geom g;
@@ -600,125 +604,97 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
 #endif
     nk = __builtin_amdgcn_readfirstlane(nk);
     if (nk > 0 && __any(valid)) {                    /* waves without any valid pixel skip the walk */
-        for (int c0 = 0; c0 < nk; c0 += FUSE_BATCH) {
-            uint32_t key[FUSE_BATCH], bk[FUSE_BATCH];
-            unsigned long long qw[FUSE_BATCH], qs[FUSE_BATCH];
-            int qg[FUSE_BATCH][3];
-            int vox[FUSE_BATCH][3];
-            bool act[FUSE_BATCH], local[FUSE_BATCH];
-            /* 1. the samples of this batch (the last batch of a walk may be short: wave-uniform skip) */
-#pragma unroll
-            for (int j = 0; j < FUSE_BATCH; ++j) {
-                act[j] = false; local[j] = false; key[j] = 0u; bk[j] = 0u;
-                vox[j][0] = vox[j][1] = vox[j][2] = 0;
-                if (c0 + j >= nk) continue;
-                const int kk = k_lo + c0 + j;
-                const float s = z + (float)kk * g.vs;
-                const float pxw = s * Rxy.x + t[0], pyw = s * Rxy.y + t[1], pzw = s * Rxy.z + t[2];   /* :103 */
-                /* float2vox (:104): std::round; the rounded value is kept as a float too -- (float)vi == the rounded
-                 * float for every index that fits an int, so vox2float needs no second conversion */
-                const float rx = gsdf_roundf(g.inv_vs * pxw), ry = gsdf_roundf(g.inv_vs * pyw), rz = gsdf_roundf(g.inv_vs * pzw);
-                const int vx = (int)rx, vy = (int)ry, vz = (int)rz;
-                const float dx = g.vs * rx - t[0], dy = g.vs * ry - t[1], dz = g.vs * rz - t[2];
-                const float pc_z = gsdf_sum3(R[2] * dx, R[5] * dy, R[8] * dz);   /* :105  (Rt row 2) */
-                const float sdf = pc_z - z;                                /* :106 */
-                const float w = gsdf_weight(sdf, g.T, g.inv_T);            /* :107 */
-                act[j] = valid && w > 0.f && c0 + j < nk_lane;
-                n_upd_w += (unsigned int)__popcll(__ballot(act[j]));
-                vox[j][0] = vx; vox[j][1] = vy; vox[j][2] = vz;
-                /* tile-local key: 10 bits per axis relative to the tile origin */
-                const uint32_t lx3 = (uint32_t)(vx - ox), ly3 = (uint32_t)(vy - oy), lz3 = (uint32_t)(vz - oz);
-                local[j] = range_ok && ((lx3 | ly3 | lz3) >> 10) == 0u;
-                key[j] = lx3 | (ly3 << 10) | (lz3 << 20);
-                qw[j] = f2fix(w);
-                qs[j] = f2fix(w * gsdf_truncate(sdf, g.T));                /* :111 as additive sum */
-                qg[j][0] = (int)(w * Rn.x); qg[j][1] = (int)(w * Rn.y); qg[j][2] = (int)(w * Rn.z);   /* :112, 2^-21 (truncating) */
-                /* LDS bucket: a LATTICE hash, not a random one.  A tile's voxels are a compact oblique prism;
-                 * x + 98 y + 143 z (mod 512) sends any two voxels closer than ~8.6 cells to different buckets
-                 * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
-                 * overflow, and the distinct voxels of one wave instruction never compete for a bucket.
-                 * (The HBM table keeps the full 64-bit finaliser.) */
-                static_assert(FUSE_NB == 512 || FUSE_NB == 384 || FUSE_NB == 256, "lattice constants exist for 512, 384 and 256 buckets");
-                if (FUSE_NB == 512) bk[j] = (lx3 + __umul24(98u, ly3) + __umul24(143u, lz3)) & 511u;   /* 24-bit multiply-adds: full rate (v_mul_lo_u32 is quarter rate) */
-                else if (FUSE_NB == 256) bk[j] = (lx3 + 7u * ly3 + 72u * lz3) & 255u;      /* experiments: min distance 6.9 */
-                else bk[j] = (lx3 + 65u * ly3 + 138u * lz3) % 384u;            /* experiments: min distance 7.9 */
-            }
-            /* 2.-4. look the voxels up in the LDS table.  All pending samples of the batch advance
-             *    together: bucket (4 keys) = one ds_read_b128, match / first-empty by selects, at most
-             *    one CAS per sample and probe.  Plain LDS reads: a stale EMPTY is resolved by the CAS.
-             *    Entries are never removed and inserts take the first empty slot, so the used slots of a
-             *    bucket are a prefix. */
-            const int nb = nk - c0 < FUSE_BATCH ? nk - c0 : FUSE_BATCH;   /* wave-uniform */
-            int slot[FUSE_BATCH];
-            bool pend[FUSE_BATCH];
-#pragma unroll
-            for (int j = 0; j < FUSE_BATCH; ++j) { slot[j] = -1; pend[j] = act[j] && local[j] && !GSDF_EXPERIMENT(a.debug, 2); }
-            if (GSDF_EXPERIMENT(a.debug, 32)) {                   /* experiment: no lookup, slot straight from the hash */
-#pragma unroll
-                for (int j = 0; j < FUSE_BATCH; ++j) { if (act[j]) slot[j] = (int)(4 * bk[j] + (key[j] & 3)); pend[j] = false; }
-            }
+        /* One sample per lane and iteration (2, 3, 4 or 6 samples in flight were measured slower: registers).  The loop
+         * is bound by VALU issue when both workgroups of a CU walk, so it is written for instruction count: x and y go
+         * through packed (2 x f32) instructions, the clamp is one v_med3, keys / hash / LDS addresses use shift-adds and
+         * 24-bit multiply-adds (v_mul_lo_u32 is quarter rate), the weight goes to fixed point without the double trick. */
+        const gsdf_f2 Rxy2 = { Rxy.x, Rxy.y }, t2 = { t[0], t[1] }, Rz2 = { R[2], R[5] }, Rn2 = { Rn.x, Rn.y };
+        float kf = (float)k_lo;                                       /* small integers: exact */
+        for (int c0 = 0; c0 < nk; ++c0, kf += 1.f) {
+            /* 1. the sample */
+            const float sd = z + kf * g.vs;
+            const gsdf_f2 pxy = sd * Rxy2 + t2;                       /* :103 */
+            const float pzw = sd * Rxy.z + t[2];
+            /* float2vox (:104): std::round; the rounded value is kept as a float too -- (float)vi == the rounded
+             * float for every index that fits an int, so vox2float needs no second conversion */
+            const gsdf_f2 qxy = g.inv_vs * pxy;
+            const float rx = gsdf_roundf(qxy.x), ry = gsdf_roundf(qxy.y), rz = gsdf_roundf(g.inv_vs * pzw);
+            const int vx = (int)rx, vy = (int)ry, vz = (int)rz;
+            const gsdf_f2 rxy = { rx, ry };
+            const gsdf_f2 dxy = g.vs * rxy - t2;
+            const float dz = g.vs * rz - t[2];
+            const gsdf_f2 cxy = Rz2 * dxy;
+            const float pc_z = gsdf_sum3(cxy.x, cxy.y, R[8] * dz);    /* :105  (Rt row 2) */
+            const float sdf = pc_z - z;                                /* :106 */
+            /* :107 Sdf::weight: 1 for sdf <= 0 (there 1 - sdf / T >= 1), the ramp up to T, 0 beyond (and for NaN) */
+            const float w = sdf <= g.T ? __builtin_amdgcn_fmed3f(1.f - sdf * g.inv_T, -__builtin_inff(), 1.f) : 0.f;
+            const bool act = valid && w > 0.f && c0 < nk_lane;
+            n_upd_w += (unsigned int)__popcll(__ballot(act));
+            /* tile-local key: 10 bits per axis relative to the tile origin */
+            const uint32_t lx3 = (uint32_t)(vx - ox), ly3 = (uint32_t)(vy - oy), lz3 = (uint32_t)(vz - oz);
+            const bool local = range_ok && (lx3 | ly3 | lz3) < 1024u;
+            const uint32_t key = lx3 + (ly3 << 10) + (lz3 << 20);
+            /* LDS bucket: a LATTICE hash, not a random one.  A tile's voxels are a compact oblique prism;
+             * x + 98 y + 143 z (mod 512) sends any two voxels closer than ~8.6 cells to different buckets
+             * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
+             * overflow, and the distinct voxels of one wave instruction never compete for a bucket.
+             * (The HBM table keeps the full 64-bit finaliser.) */
+            static_assert(FUSE_NB == 512 || FUSE_NB == 384 || FUSE_NB == 256, "lattice constants exist for 512, 384 and 256 buckets");
+            uint32_t bk;
+            if (FUSE_NB == 512) bk = gsdf_mad_u24(lz3, 143u, gsdf_mad_u24(ly3, 98u, lx3)) & 511u;
+            else if (FUSE_NB == 256) bk = (lx3 + 7u * ly3 + 72u * lz3) & 255u;      /* experiments: min distance 6.9 */
+            else bk = (lx3 + 65u * ly3 + 138u * lz3) % 384u;            /* experiments: min distance 7.9 */
+            /* 2.-4. look the voxel up in the LDS table: bucket (4 keys) = one ds_read_b128; the first slot that holds
+             *    the key or is empty decides (used slots are a prefix: entries are never removed and inserts take the
+             *    first empty slot), at most one CAS per probe.  Plain LDS reads: a stale EMPTY is resolved by the CAS. */
+            int slot = -1;
+            bool pend = act && local && !GSDF_EXPERIMENT(a.debug, 2);
+            if (GSDF_EXPERIMENT(a.debug, 32)) { if (act) slot = (int)(4 * bk + (key & 3)); pend = false; }   /* experiment: no lookup */
             for (int probe = 0; probe < FUSE_LPROBE; ++probe) {
-                /* only samples that still have a pending lane somewhere in the wave cost instructions */
-                bool go[FUSE_BATCH];
-                bool any = false;
-#pragma unroll
-                for (int j = 0; j < FUSE_BATCH; ++j) { go[j] = j < nb && __any(pend[j]); any = any || go[j]; if (go[j]) ++dbg_go; }
-                if (!any) break;
-                uint4 kk4[FUSE_BATCH];
-#pragma unroll
-                for (int j = 0; j < FUSE_BATCH; ++j) {
-                    if (!go[j]) continue;
-                    kk4[j] = *reinterpret_cast<const uint4*>(&L.key[4 * bk[j]]);
+                if (!__any(pend)) break;
+                ++dbg_go;
+                const uint4 k4 = *reinterpret_cast<const uint4*>(&L.key[4 * bk]);
+                const bool h0 = k4.x == key, h1 = k4.y == key, h2 = k4.z == key, h3 = k4.w == key;
+                const bool m0 = h0 | (k4.x == FUSE_LKEY_EMPTY), m1 = h1 | (k4.y == FUSE_LKEY_EMPTY),
+                           m2 = h2 | (k4.z == FUSE_LKEY_EMPTY), m3 = h3 | (k4.w == FUSE_LKEY_EMPTY);
+                int pos = m3 ? 3 : -1;
+                pos = m2 ? 2 : pos; pos = m1 ? 1 : pos; pos = m0 ? 0 : pos;
+                const bool hit = h0 | h1 | h2 | h3;
+                const int at = (int)(4u * bk) + pos;
+                const bool try_cas = pend && !hit && pos >= 0;
+                if (pend && hit) { slot = at; pend = false; }
+                if (pend && pos < 0) bk = bk + 1u == (uint32_t)FUSE_NB ? 0u : bk + 1u;               /* bucket full of others */
+                if (GSDF_EXPERIMENT(a.debug, 128) && __any(pend && pos < 0)) ++dbg_full;
+                if (try_cas) {
+                    const uint32_t old = atomicCAS(&L.key[at], FUSE_LKEY_EMPTY, key);
+                    if (old == FUSE_LKEY_EMPTY || old == key) { slot = at; pend = false; }
                 }
-                int cas_at[FUSE_BATCH];
-#pragma unroll
-                for (int j = 0; j < FUSE_BATCH; ++j) {
-                    cas_at[j] = -1;
-                    if (!go[j]) continue;
-                    int hit = kk4[j].w == key[j] ? 3 : -1;
-                    hit = kk4[j].z == key[j] ? 2 : hit; hit = kk4[j].y == key[j] ? 1 : hit; hit = kk4[j].x == key[j] ? 0 : hit;
-                    int emp = kk4[j].w == FUSE_LKEY_EMPTY ? 3 : -1;
-                    emp = kk4[j].z == FUSE_LKEY_EMPTY ? 2 : emp; emp = kk4[j].y == FUSE_LKEY_EMPTY ? 1 : emp; emp = kk4[j].x == FUSE_LKEY_EMPTY ? 0 : emp;
-                    if (pend[j] && hit >= 0) { slot[j] = (int)(4 * bk[j]) + hit; pend[j] = false; }
-                    cas_at[j] = (pend[j] && emp >= 0) ? (int)(4 * bk[j]) + emp : -1;
-                    if (pend[j] && emp < 0) bk[j] = bk[j] + 1u == (uint32_t)FUSE_NB ? 0u : bk[j] + 1u;   /* bucket full of others */
-                    if (GSDF_EXPERIMENT(a.debug, 128) && __any(pend[j] && emp < 0)) ++dbg_full;
-                }
-                uint32_t old[FUSE_BATCH];
-#pragma unroll
-                for (int j = 0; j < FUSE_BATCH; ++j)
-                    old[j] = (go[j] && cas_at[j] >= 0) ? atomicCAS(&L.key[cas_at[j]], FUSE_LKEY_EMPTY, key[j]) : 0u;
-#pragma unroll
-                for (int j = 0; j < FUSE_BATCH; ++j)
-                    if (go[j] && cas_at[j] >= 0 && (old[j] == FUSE_LKEY_EMPTY || old[j] == key[j])) { slot[j] = cas_at[j]; pend[j] = false; }
-                if (GSDF_EXPERIMENT(a.debug, 128)) {
-#pragma unroll
-                    for (int j = 0; j < FUSE_BATCH; ++j) if (go[j] && __any(cas_at[j] >= 0 && pend[j])) ++dbg_lost;
-                }
+                if (GSDF_EXPERIMENT(a.debug, 128) && __any(try_cas && pend)) ++dbg_lost;
                 /* a lost CAS (slot taken by another voxel) re-reads the same bucket in the next probe */
             }
             /* 5. accumulate (integer adds: exact and order-independent) */
-#pragma unroll
-            for (int j = 0; j < FUSE_BATCH; ++j) {
-                if (j >= nb || !act[j] || GSDF_EXPERIMENT(a.debug, 2)) continue;
-                if (GSDF_EXPERIMENT(a.debug, 16)) continue;
-                if (slot[j] >= 0) {
-                    atomicAdd(&L.ws[2 * slot[j]], qw[j]);
-                    atomicAdd(&L.ws[2 * slot[j] + 1], qs[j]);
-                    uint32_t* G = &L.g[3 * slot[j]];
-                    atomicAdd(G + 0, (uint32_t)qg[j][0]);
-                    atomicAdd(G + 1, (uint32_t)qg[j][1]);
-                    atomicAdd(G + 2, (uint32_t)qg[j][2]);
-                } else {
-                    /* LDS table full for this voxel, or voxel outside the local key range: deferred list */
-                    if (!gsdf_key_in_range(vox[j][0], vox[j][1], vox[j][2])) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); continue; }
-                    gsdf_payload* p = gsdf_find_or_insert(a.tab, gsdf_key_pack(vox[j][0], vox[j][1], vox[j][2]));
-                    if (!p) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
-                    else {
-                        defer_append(a, p, fix2f(qw[j]), fix2f(qs[j]), fix2f((uint32_t)qg[j][0]), fix2f((uint32_t)qg[j][1]), fix2f((uint32_t)qg[j][2]));
-                        L.any_defer = 1u;
-                        vis_mark(a, p, frame_cur);
-                    }
+            if (!act || GSDF_EXPERIMENT(a.debug, 2) || GSDF_EXPERIMENT(a.debug, 16)) continue;
+            /* w is a multiple of 2^-24 (1 - x is exact for x >= 1/2 and rounded to 2^-24 below): w 2^24 is an integer */
+            const unsigned long long qw = (unsigned long long)(uint32_t)(w * 16777216.f) << 16;
+            const unsigned long long qs = f2fix(w * __builtin_amdgcn_fmed3f(sdf, -g.T, g.T));   /* :111 as additive sum; Sdf::truncate */
+            const gsdf_f2 gxy = w * Rn2;
+            const int qg0 = (int)gxy.x, qg1 = (int)gxy.y, qg2 = (int)(w * Rn.z);                /* :112, 2^-21 (truncating) */
+            if (slot >= 0) {
+                atomicAdd(&L.ws[2 * slot], qw);
+                atomicAdd(&L.ws[2 * slot + 1], qs);
+                uint32_t* G = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(L.g) + gsdf_mad_u24((uint32_t)slot, 12u, 0u));
+                atomicAdd(G + 0, (uint32_t)qg0);
+                atomicAdd(G + 1, (uint32_t)qg1);
+                atomicAdd(G + 2, (uint32_t)qg2);
+            } else {
+                /* LDS table full for this voxel, or voxel outside the local key range: deferred list */
+                if (!gsdf_key_in_range(vx, vy, vz)) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); continue; }
+                gsdf_payload* p = gsdf_find_or_insert(a.tab, gsdf_key_pack(vx, vy, vz));
+                if (!p) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
+                else {
+                    defer_append(a, p, fix2f(qw), fix2f(qs), fix2f((uint32_t)qg0), fix2f((uint32_t)qg1), fix2f((uint32_t)qg2));
+                    L.any_defer = 1u;
+                    vis_mark(a, p, frame_cur);
                 }
             }
         }
