@@ -320,7 +320,9 @@ struct fuse_args {
 
 struct fuse_lds {
     uint32_t key[FUSE_LCAP] __attribute__((aligned(16)));
-    unsigned long long ws[FUSE_LCAP * 2] __attribute__((aligned(16)));   /* per entry: sum w, sum w * truncated sdf (2^-40) */
+    unsigned long long ws[FUSE_LCAP * 2] __attribute__((aligned(16)));   /* sum w [0, LCAP), sum w * truncated sdf [LCAP, 2 LCAP) (2^-40): two
+                                                                            arrays of 8-byte entries, so a wave's scattered 64-bit adds use all
+                                                                            banks (16-byte entries leave half of them idle) */
     uint32_t g[FUSE_LCAP * 3] __attribute__((aligned(16)));              /* per entry: sum w * R n (2^-21); odd stride: a wave's
                                                                             scattered entries spread over the banks */
     unsigned int cnt[2][4 * FUSE_ZSPLIT];   /* per wave: samples with w > 0, valid pixels */
@@ -680,8 +682,8 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             const gsdf_f2 gxy = w * Rn2;
             const int qg0 = (int)gxy.x, qg1 = (int)gxy.y, qg2 = (int)(w * Rn.z);                /* :112, 2^-21 (truncating) */
             if (slot >= 0) {
-                atomicAdd(&L.ws[2 * slot], qw);
-                atomicAdd(&L.ws[2 * slot + 1], qs);
+                atomicAdd(&L.ws[slot], qw);
+                atomicAdd(&L.ws[FUSE_LCAP + slot], qs);
                 uint32_t* G = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(L.g) + gsdf_mad_u24((uint32_t)slot, 12u, 0u));
                 atomicAdd(G + 0, (uint32_t)qg0);
                 atomicAdd(G + 1, (uint32_t)qg1);
@@ -822,8 +824,8 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 const uint32_t* G = &L.g[3 * i];
                 gsdf_payload* pe = a.tab.vox + rec[e];
                 gsdf_u32x4 oa, ob;
-                oa.x = __float_as_uint(__uint_as_float(ra[e].x) + fix2f(L.ws[2 * i]));
-                oa.y = __float_as_uint(__uint_as_float(ra[e].y) + fix2f(L.ws[2 * i + 1]));
+                oa.x = __float_as_uint(__uint_as_float(ra[e].x) + fix2f(L.ws[i]));
+                oa.y = __float_as_uint(__uint_as_float(ra[e].y) + fix2f(L.ws[FUSE_LCAP + i]));
                 oa.z = __float_as_uint(__uint_as_float(ra[e].z) + fix2f(G[0]));
                 oa.w = __float_as_uint(__uint_as_float(ra[e].w) + fix2f(G[1]));
                 ob.x = __float_as_uint(__uint_as_float(rb[e].x) + fix2f(G[2]));
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                     const uint32_t* G = &L.g[3 * i];
                     gsdf_deferred d;
                     d.p = a.tab.vox + (key & ~FUSE_LKEY_DEFER);
-                    d.w = fix2f(L.ws[2 * i]); d.s = fix2f(L.ws[2 * i + 1]);
+                    d.w = fix2f(L.ws[i]); d.s = fix2f(L.ws[FUSE_LCAP + i]);
                     d.gx = fix2f(G[0]); d.gy = fix2f(G[1]); d.gz = fix2f(G[2]);
                     d.pad = 0u;
                     a.deferred[o] = d;
