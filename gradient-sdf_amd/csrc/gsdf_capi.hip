@@ -242,6 +242,7 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
     *out = nullptr;
     if (!(voxel_size > 0.f) || !(trunc_dist > 0.f)) return fail(GSDF_ERR_INVALID, "voxel_size and trunc_dist must be > 0");
     if (capacity_log2 < 10 || capacity_log2 > 30) return fail(GSDF_ERR_INVALID, "capacity_log2 must be in [10, 30]");
+    if (!(trunc_dist < 2.f)) return fail(GSDF_ERR_INVALID, "trunc_dist must be < 2 m (fixed-point range of the fusion kernel's accumulators)");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
         (void)hipGetLastError();

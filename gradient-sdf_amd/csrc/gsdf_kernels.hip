@@ -267,15 +267,26 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #ifndef FUSE_OCC
 #define FUSE_OCC (2 * FUSE_ZSPLIT)        /* waves per SIMD the register allocation must allow: 2 workgroups per CU */
 #endif
-/* LDS accumulators are fixed point (exact, order-independent integer adds).
- *  - weight and weighted distance: 64 bit, 2^-40.  dist = s / w must hold to 1e-4 also for a voxel whose only sample
- *    has a weight of 2^-24 (w = 1 - sdf/T is a multiple of 2^-24), and such a voxel must EXIST (w > 0): both sums keep
- *    every bit of their float terms (|x| >= 2^-17 exactly, below that to 2^-40).
- *  - weighted normal: signed 32 bit, 2^-21.  A ray's samples are >= one voxel apart, so at most 2 of them round to one
- *    voxel: a voxel collects <= 2 x 256 terms of a tile, each |term| <= 1 => |sum| <= 512 < 2^10.  A term is truncated
- *    to 2^-21 (2.4e-7 absolute; the gradient bar is 1e-4 relative to max(1, weight)). */
-#define FUSE_FIX_ONE 2097152.0f          /* 2^21 */
-#define FUSE_FIX_INV 4.76837158203125e-07f
+/* LDS accumulators are fixed point (exact, order-independent integer adds) in THREE 64-bit words per entry, each in its
+ * own array of 8-byte entries (a wave's scattered adds then use all banks; the walk is bound by LDS cycles).  Several
+ * sums share a word and are added as ONE integer; the flush separates them again (a negative low field has borrowed 1
+ * from the field above it).  A ray's samples are >= one voxel apart, so at most 2 of them round to one voxel: a voxel
+ * collects <= 2 x 256 terms of a tile.
+ *  - acc[0]  bits 0..50: sum of w * truncated sdf, signed, 2^-40.  dist = s / w must hold to 1e-4 also for a voxel whose
+ *            only sample has a weight of 2^-24: the sum keeps every bit of its float terms (|x| >= 2^-17 exactly, below
+ *            that to 2^-40); 512 terms of |x| <= T < 2 m stay below 2^50 (gsdf_create checks T).
+ *            bits 51..61: sum of the LOW 2 bits of the z terms of the normal (512 x 3 < 2^11).
+ *  - acc[1]  bits 0..33: sum of w in units of 2^-24.  w = 1 - sdf / T is a multiple of 2^-24 (the subtraction is exact
+ *            for sdf / T >= 1/2 and rounded to 2^-24 below), so the weight sum is EXACT (512 x 2^24 = 2^33) and a voxel
+ *            exists (w > 0) exactly when the reference creates it.
+ *            bits 34..63: sum of the z terms of the normal without their low 2 bits (floor), signed.
+ *  - acc[2]  bits 0..31 / 32..63: sums of the x / y terms of the normal, signed.
+ *  Normal terms w (R n) are truncated to 2^-21 (4.8e-7; |sum| <= 512 < 2^10): the tracker NORMALISES the stored
+ *  gradient, so voxels of small weight need the resolution (2^-19 for z was tried: pose parity lost after 3 passes). */
+#define FUSE_FIX_G 2097152.0f            /* 2^21 */
+#define FUSE_FIX_G_INV 4.76837158203125e-07f
+#define FUSE_FIX_W 16777216.0f           /* 2^24 */
+#define FUSE_FIX_W_INV 5.9604644775390625e-08f
 #ifndef FUSE_SPREAD
 #define FUSE_SPREAD 1                    /* spread lane -> (pixel, slice) mapping, see k_fuse */
 #endif
@@ -320,11 +331,7 @@ struct fuse_args {
 
 struct fuse_lds {
     uint32_t key[FUSE_LCAP] __attribute__((aligned(16)));
-    unsigned long long ws[FUSE_LCAP * 2] __attribute__((aligned(16)));   /* sum w [0, LCAP), sum w * truncated sdf [LCAP, 2 LCAP) (2^-40): two
-                                                                            arrays of 8-byte entries, so a wave's scattered 64-bit adds use all
-                                                                            banks (16-byte entries leave half of them idle) */
-    uint32_t g[FUSE_LCAP * 3] __attribute__((aligned(16)));              /* per entry: sum w * R n (2^-21); odd stride: a wave's
-                                                                            scattered entries spread over the banks */
+    unsigned long long acc[3][FUSE_LCAP] __attribute__((aligned(16)));  /* see above: s | w + gz | gx + gy */
     unsigned int cnt[2][4 * FUSE_ZSPLIT];   /* per wave: samples with w > 0, valid pixels */
     unsigned int n_defer, defer_base;
     unsigned int st_min[FUSE_NSTAT], st_max[FUSE_NSTAT];  /* per wave: smallest / largest valid depth (float bits) */
@@ -345,7 +352,28 @@ __device__ __forceinline__ unsigned long long f2fix(float x) {
 __device__ __forceinline__ float fix2f(unsigned long long v) {
     return __ll2float_rn((long long)v) * 9.094947017729282e-13f;   /* 2^-40 */
 }
-__device__ __forceinline__ float fix2f(uint32_t v) { return (float)(int)v * FUSE_FIX_INV; }
+/* one sample's contribution as the three words of the accumulator layout above */
+__device__ __forceinline__ void fuse_pack(uint32_t wi, unsigned long long s_fix, int gx, int gy, int gz,
+                                          unsigned long long& a0, unsigned long long& a1, unsigned long long& a2) {
+    a0 = s_fix + ((unsigned long long)((uint32_t)gz & 3u) << 51);
+    a1 = (unsigned long long)wi | ((unsigned long long)((uint32_t)gz & ~3u) << 32);       /* floor(gz / 4) 2^34: no carry between the words */
+    a2 = (unsigned long long)(uint32_t)gx | ((unsigned long long)(uint32_t)(gy + (gx >> 31)) << 32);
+}
+/* the sums of one LDS entry as floats (one rounding each, of the exact fixed-point sum) */
+struct fuse_sums { float w, s, gx, gy, gz; };
+__device__ __forceinline__ fuse_sums fuse_unpack(unsigned long long a0, unsigned long long a1, unsigned long long a2) {
+    fuse_sums r;
+    const long long sv = (long long)(a0 << 13) >> 13;                 /* sign-extended bits 0..50 */
+    const int gz_lo = (int)((a0 - (unsigned long long)sv) >> 51);
+    r.s = __ll2float_rn(sv) * 9.094947017729282e-13f;                 /* 2^-40 */
+    r.w = __ull2float_rn(a1 & 0x3FFFFFFFFull) * FUSE_FIX_W_INV;
+    r.gz = (float)((int)((long long)a1 >> 34) * 4 + gz_lo) * FUSE_FIX_G_INV;
+    const int gx = (int)(uint32_t)a2;
+    const int gy = (int)(uint32_t)(a2 >> 32) - (gx >> 31);           /* a negative low field borrowed 1 */
+    r.gx = (float)gx * FUSE_FIX_G_INV;
+    r.gy = (float)gy * FUSE_FIX_G_INV;
+    return r;
+}
 
 /* additive update with float atomics: merge / resolve kernels */
 __device__ __forceinline__ void hbm_accumulate(const gsdf_table& T, unsigned long long key, float w, float s,
@@ -377,11 +405,9 @@ __device__ __forceinline__ void vis_mark(const fuse_args& a, const gsdf_payload*
 
 __device__ __forceinline__ void fuse_lds_clear(fuse_lds& L, int tid) {
     gsdf_u32x4* k4 = reinterpret_cast<gsdf_u32x4*>(L.key);
-    gsdf_u32x4* a4 = reinterpret_cast<gsdf_u32x4*>(L.ws);
-    gsdf_u32x4* g4 = reinterpret_cast<gsdf_u32x4*>(L.g);
+    gsdf_u32x4* a4 = reinterpret_cast<gsdf_u32x4*>(L.acc);
     for (int i = tid; i < FUSE_LCAP / 4; i += FUSE_THREADS) k4[i] = gsdf_u32x4{ FUSE_LKEY_EMPTY, FUSE_LKEY_EMPTY, FUSE_LKEY_EMPTY, FUSE_LKEY_EMPTY };
-    for (int i = tid; i < FUSE_LCAP; i += FUSE_THREADS) a4[i] = gsdf_u32x4{ 0u, 0u, 0u, 0u };
-    for (int i = tid; i < FUSE_LCAP * 3 / 4; i += FUSE_THREADS) g4[i] = gsdf_u32x4{ 0u, 0u, 0u, 0u };
+    for (int i = tid; i < 3 * FUSE_LCAP / 2; i += FUSE_THREADS) a4[i] = gsdf_u32x4{ 0u, 0u, 0u, 0u };
 }
 
 /* per-frame log row of the Scan3D loop: pose7, converged, passes, hits of the last pass (main_scan_3d.cpp:268-280) */
@@ -459,7 +485,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             valid = !(z <= g.zmin || z >= g.zmax);                         /* MapGradPixelSdf.cpp:87 */
             Rxy = gsdf_matvec(R, xy);                                      /* :91 */
             const gsdf_v3 rn = gsdf_matvec(R, n);                          /* :93 */
-            Rn = gsdf_v3{ rn.x * FUSE_FIX_ONE, rn.y * FUSE_FIX_ONE, rn.z * FUSE_FIX_ONE };   /* exact (power of two) */
+            Rn = gsdf_v3{ rn.x * FUSE_FIX_G, rn.y * FUSE_FIX_G, rn.z * FUSE_FIX_G };         /* exact (power of two) */
             if ((double)gsdf_dot3(n, n) < .1) valid = false;               /* :95 (same comparison as the reference: NaN passes) */
             const float nd = gsdf_dot3(n, xy);
             if (nd * nd * ninv < .25) valid = false;                       /* :98 */
@@ -676,25 +702,25 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             }
             /* 5. accumulate (integer adds: exact and order-independent) */
             if (!act || GSDF_EXPERIMENT(a.debug, 2) || GSDF_EXPERIMENT(a.debug, 16)) continue;
-            /* w is a multiple of 2^-24 (1 - x is exact for x >= 1/2 and rounded to 2^-24 below): w 2^24 is an integer */
-            const unsigned long long qw = (unsigned long long)(uint32_t)(w * 16777216.f) << 16;
+            /* w 2^24 is an integer (see the accumulator layout) */
+            const uint32_t wi = (uint32_t)(w * FUSE_FIX_W);
             const unsigned long long qs = f2fix(w * __builtin_amdgcn_fmed3f(sdf, -g.T, g.T));   /* :111 as additive sum; Sdf::truncate */
             const gsdf_f2 gxy = w * Rn2;
-            const int qg0 = (int)gxy.x, qg1 = (int)gxy.y, qg2 = (int)(w * Rn.z);                /* :112, 2^-21 (truncating) */
+            const int qg0 = (int)gxy.x, qg1 = (int)gxy.y, qg2 = (int)(w * Rn.z);                /* :112 (truncating) */
+            unsigned long long q0, qwz, qgxy;
+            fuse_pack(wi, qs, qg0, qg1, qg2, q0, qwz, qgxy);
             if (slot >= 0) {
-                atomicAdd(&L.ws[slot], qw);
-                atomicAdd(&L.ws[FUSE_LCAP + slot], qs);
-                uint32_t* G = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(L.g) + gsdf_mad_u24((uint32_t)slot, 12u, 0u));
-                atomicAdd(G + 0, (uint32_t)qg0);
-                atomicAdd(G + 1, (uint32_t)qg1);
-                atomicAdd(G + 2, (uint32_t)qg2);
+                atomicAdd(&L.acc[0][slot], q0);
+                atomicAdd(&L.acc[1][slot], qwz);
+                atomicAdd(&L.acc[2][slot], qgxy);
             } else {
                 /* LDS table full for this voxel, or voxel outside the local key range: deferred list */
                 if (!gsdf_key_in_range(vx, vy, vz)) { atomicOr(&a.st->status, GSDF_STATUS_KEY_RANGE); continue; }
                 gsdf_payload* p = gsdf_find_or_insert(a.tab, gsdf_key_pack(vx, vy, vz));
                 if (!p) atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL);
                 else {
-                    defer_append(a, p, fix2f(qw), fix2f(qs), fix2f((uint32_t)qg0), fix2f((uint32_t)qg1), fix2f((uint32_t)qg2));
+                    const fuse_sums d = fuse_unpack(q0, qwz, qgxy);
+                    defer_append(a, p, d.w, d.s, d.gx, d.gy, d.gz);
                     L.any_defer = 1u;
                     vis_mark(a, p, frame_cur);
                 }
@@ -821,14 +847,14 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             for (int e = 0; e < NE; ++e) {
                 if (rec[e] == NOREC) continue;
                 const int i = tid + FUSE_THREADS * e;
-                const uint32_t* G = &L.g[3 * i];
+                const fuse_sums d = fuse_unpack(L.acc[0][i], L.acc[1][i], L.acc[2][i]);
                 gsdf_payload* pe = a.tab.vox + rec[e];
                 gsdf_u32x4 oa, ob;
-                oa.x = __float_as_uint(__uint_as_float(ra[e].x) + fix2f(L.ws[i]));
-                oa.y = __float_as_uint(__uint_as_float(ra[e].y) + fix2f(L.ws[FUSE_LCAP + i]));
-                oa.z = __float_as_uint(__uint_as_float(ra[e].z) + fix2f(G[0]));
-                oa.w = __float_as_uint(__uint_as_float(ra[e].w) + fix2f(G[1]));
-                ob.x = __float_as_uint(__uint_as_float(rb[e].x) + fix2f(G[2]));
+                oa.x = __float_as_uint(__uint_as_float(ra[e].x) + d.w);
+                oa.y = __float_as_uint(__uint_as_float(ra[e].y) + d.s);
+                oa.z = __float_as_uint(__uint_as_float(ra[e].z) + d.gx);
+                oa.w = __float_as_uint(__uint_as_float(ra[e].w) + d.gy);
+                ob.x = __float_as_uint(__uint_as_float(rb[e].x) + d.gz);
                 ob.y = a.tag; ob.z = 0u; ob.w = 0u;
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(pe), "v"(oa) : "memory");
                 asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(pe), "v"(ob) : "memory");
@@ -866,11 +892,11 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                     if (key == FUSE_LKEY_EMPTY) continue;
                     const unsigned int o = L.defer_base + atomicAdd(&L.n_defer, 1u);
                     if (o >= a.deferred_cap) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); continue; }
-                    const uint32_t* G = &L.g[3 * i];
+                    const fuse_sums u = fuse_unpack(L.acc[0][i], L.acc[1][i], L.acc[2][i]);
                     gsdf_deferred d;
                     d.p = a.tab.vox + (key & ~FUSE_LKEY_DEFER);
-                    d.w = fix2f(L.ws[i]); d.s = fix2f(L.ws[FUSE_LCAP + i]);
-                    d.gx = fix2f(G[0]); d.gy = fix2f(G[1]); d.gz = fix2f(G[2]);
+                    d.w = u.w; d.s = u.s;
+                    d.gx = u.gx; d.gy = u.gy; d.gz = u.gz;
                     d.pad = 0u;
                     a.deferred[o] = d;
                 }
