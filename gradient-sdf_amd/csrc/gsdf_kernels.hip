@@ -51,6 +51,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+/* wave-64 unsigned minimum / maximum the same way (lanes without a source keep the identity); result in every lane */
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umin(uint32_t v) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return m < v ? m : v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umax(uint32_t v) {
+    const uint32_t m = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return m > v ? m : v;
+}
+__device__ __forceinline__ void wave_uminmax(uint32_t& lo, uint32_t& hi) {
+    lo = dpp_umin<0x111, 0xf>(lo); hi = dpp_umax<0x111, 0xf>(hi);
+    lo = dpp_umin<0x112, 0xf>(lo); hi = dpp_umax<0x112, 0xf>(hi);
+    lo = dpp_umin<0x114, 0xf>(lo); hi = dpp_umax<0x114, 0xf>(hi);
+    lo = dpp_umin<0x118, 0xf>(lo); hi = dpp_umax<0x118, 0xf>(hi);
+    lo = dpp_umin<0x142, 0xa>(lo); hi = dpp_umax<0x142, 0xa>(hi);
+    lo = dpp_umin<0x143, 0xc>(lo); hi = dpp_umax<0x143, 0xc>(hi);
+    lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+    hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+}
+
 /* wave-64 sums of N values at once: every DPP stage is applied to all N values before the next stage, so
  * the N dependency chains interleave instead of stalling on each other; lane 63 ends up with the totals */
 template <int N>
@@ -471,17 +493,13 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
     bool valid = false;
     float z = 0.f;
     gsdf_v3 Rxy = { 0.f, 0.f, 0.f }, Rn = { 0.f, 0.f, 0.f };   /* Rn carries the fixed-point scale: w * Rn is the scaled term */
-    auto load_pixel = [&](int px, int py, const float* dp, const float* x0p, const float* y0p, const float* nip,
-                          const float* nxp, const float* nyp, const float* nzp) {
-        valid = px < g.W && py < g.H;
+    auto finish_pixel = [&](bool inside, float zr, float x0r, float y0r, float ninv, float nxr, float nyr, float nzr) {
+        valid = inside;
         z = 0.f;
-        if (valid) {
-            /* all seven loads are issued together: one memory round trip, not two */
-            const size_t idx = (size_t)py * g.W + px;
-            z = dp[idx];
-            const gsdf_v3 xy = { x0p[idx], y0p[idx], 1.f };                /* :90 */
-            const gsdf_v3 n = { nxp[idx], nyp[idx], nzp[idx] };            /* :92 */
-            const float ninv = nip[idx];
+        if (inside) {
+            z = zr;
+            const gsdf_v3 xy = { x0r, y0r, 1.f };                          /* :90 */
+            const gsdf_v3 n = { nxr, nyr, nzr };                           /* :92 */
             valid = !(z <= g.zmin || z >= g.zmax);                         /* MapGradPixelSdf.cpp:87 */
             Rxy = gsdf_matvec(R, xy);                                      /* :91 */
             const gsdf_v3 rn = gsdf_matvec(R, n);                          /* :93 */
@@ -491,18 +509,35 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             if (nd * nd * ninv < .25) valid = false;                       /* :98 */
         }
     };
-    /* the common case is one band: load its pixels now, the loads overlap the table clear */
+    auto load_pixel = [&](int px, int py, const float* dp, const float* x0p, const float* y0p, const float* nip,
+                          const float* nxp, const float* nyp, const float* nzp) {
+        const bool inside = px < g.W && py < g.H;
+        float r[7] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        if (inside) {
+            /* all seven loads are issued together: one memory round trip, not two */
+            const size_t idx = (size_t)py * g.W + px;
+            r[0] = dp[idx]; r[1] = x0p[idx]; r[2] = y0p[idx]; r[3] = nip[idx]; r[4] = nxp[idx]; r[5] = nyp[idx]; r[6] = nzp[idx];
+        }
+        finish_pixel(inside, r[0], r[1], r[2], r[3], r[4], r[5], r[6]);
+    };
+    /* the common case is one band: its pixels are requested now; the table clear and everything of the tile-wide
+     * decisions that does not depend on the pixels (corner rays of the tile's frustum) run while the loads are in flight */
 #if FUSE_SPREAD
     /* Lanes of a wave are spread out, because lanes that hit the same voxel in one instruction serialise in the LDS
      * atomics: a wave takes 32 pixels (every 2nd in x, every (4 / bands)-th in y: wave w has phase (w & 1, w >> 1)) and
      * BOTH slices of their ray walk (lanes 0-31 / 32-63), so neighbouring lanes are >= 2 pixels or half a ray apart. */
     static_assert(FUSE_ZSPLIT == 2, "the spread mapping splits a ray between the two halves of a wave");
-    load_pixel(tile_x * FUSE_T + 2 * lx + (wave & 1), tile_y * FUSE_T + 4 * (ly & 3) + (wave >> 1),
-               a.depth, a.nc.x0, a.nc.y0, a.nc.ninv, a.nx, a.ny, a.nz);
+    const int px0 = tile_x * FUSE_T + 2 * lx + (wave & 1), py0 = tile_y * FUSE_T + 4 * (ly & 3) + (wave >> 1);
 #else
-    load_pixel(tile_x * FUSE_T + (wave & 1) * 8 + lx, tile_y * FUSE_T + ((wave >> 1) & 1) * 8 + ly,
-               a.depth, a.nc.x0, a.nc.y0, a.nc.ninv, a.nx, a.ny, a.nz);
+    const int px0 = tile_x * FUSE_T + (wave & 1) * 8 + lx, py0 = tile_y * FUSE_T + ((wave >> 1) & 1) * 8 + ly;
 #endif
+    float raw[7] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    const bool inside0 = px0 < g.W && py0 < g.H;
+    if (inside0) {
+        const size_t idx = (size_t)py0 * g.W + px0;
+        raw[0] = a.depth[idx]; raw[1] = a.nc.x0[idx]; raw[2] = a.nc.y0[idx]; raw[3] = a.nc.ninv[idx];
+        raw[4] = a.nx[idx]; raw[5] = a.ny[idx]; raw[6] = a.nz[idx];
+    }
     /* meanwhile: empty table */
     fuse_lds_clear(L, tid);
     if (GSDF_EXPERIMENT(a.debug, 128)) {                    /* phase timer: all seven pixel loads have arrived */
@@ -514,19 +549,30 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
         L.plane[0] = a.depth; L.plane[1] = a.nc.x0; L.plane[2] = a.nc.y0; L.plane[3] = a.nc.ninv;
         L.plane[4] = a.nx; L.plane[5] = a.ny; L.plane[6] = a.nz;
     }
+    /* extreme components of the rays through the tile's corners (plus a pixel of margin): R (x0, y0, 1) */
+    float dmin[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, dmax[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
+    {
+        const float rfx = __frcp_rn(g.fx), rfy = __frcp_rn(g.fy);       /* a bounding box with margin: no parity item */
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float u = (float)(tile_x * FUSE_T + ((c & 1) ? FUSE_T : -1)), v = (float)(tile_y * FUSE_T + ((c & 2) ? FUSE_T : -1));
+            const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ (u - g.cx) * rfx, (v - g.cy) * rfy, 1.f });
+            dmin[0] = fminf(dmin[0], d.x); dmin[1] = fminf(dmin[1], d.y); dmin[2] = fminf(dmin[2], d.z);
+            dmax[0] = fmaxf(dmax[0], d.x); dmax[1] = fmaxf(dmax[1], d.y); dmax[2] = fmaxf(dmax[2], d.z);
+        }
+    }
+    if (GSDF_EXPERIMENT(a.debug, 64)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSDF_TRACE(a, tr, 11); }   /* pixel loads arrived */
+    finish_pixel(inside0, raw[0], raw[1], raw[2], raw[3], raw[4], raw[5], raw[6]);
     /* depth range of the tile and the number of valid pixels: one entry per wave that holds distinct pixels */
     if (FUSE_SPREAD || zslice == 0) {
         unsigned int zb = valid ? __float_as_uint(z) : 0x7F800000u, zt = valid ? __float_as_uint(z) : 0u;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned int o1 = __shfl_xor(zb, o), o2 = __shfl_xor(zt, o);
-            zb = o1 < zb ? o1 : zb; zt = o2 > zt ? o2 : zt;
-        }
+        wave_uminmax(zb, zt);                                         /* DPP: no LDS round trips */
         /* spread mapping: both halves of a wave hold the same 32 pixels */
         const float cnt = (float)__popcll(FUSE_SPREAD ? (__ballot(valid) & 0xFFFFFFFFull) : __ballot(valid));
         if (lane == 0) { L.st_min[wave] = zb; L.st_max[wave] = zt; L.st_cnt[wave] = cnt; }
     }
     __syncthreads();
+    GSDF_TRACE(a, tr, 12);                                            /* tile statistics reduced */
     const int nk_all = 2 * g.factor + 1;
     const int colour = (tile_x & 1) + 2 * (tile_y & 1);
     unsigned int* my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
@@ -562,10 +608,11 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
          * tiles (or small voxels) would overflow the LDS table -- and a table filled beyond ~80 % probes long and drops
          * samples into the deferred list -- so they are walked as 2 or 4 row bands, each flushed on its own. */
         const float zf = __uint_as_float(zmax_bits);
-        const float ppr = (g.fx * g.vs / zf) * (g.fy * g.vs / zf);      /* pixels per voxel face at the far end */
+        const float rzf = __builtin_amdgcn_rcpf(zf);                    /* an estimate: hardware reciprocals will do */
+        const float ppr = (g.fx * g.vs * rzf) * (g.fy * g.vs * rzf);    /* pixels per voxel face at the far end */
         const float side = (float)FUSE_T * __builtin_amdgcn_rsqf(ppr);
         const float samples = n_valid * (float)nk_all;
-        const float est = fminf(samples, samples / ppr + (side * side + 2.f * side * (float)nk_all) * __builtin_amdgcn_sqrtf(n_valid * (1.f / 256.f)));
+        const float est = fminf(samples, samples * __builtin_amdgcn_rcpf(ppr) + (side * side + 2.f * side * (float)nk_all) * __builtin_amdgcn_sqrtf(n_valid * (1.f / 256.f)));
         n_pass = est <= 0.8f * FUSE_LCAP ? 1 : (est <= 1.6f * FUSE_LCAP ? 2 : 4);
         if (GSDF_EXPERIMENT(a.debug, 256)) n_pass = 1;
         if (GSDF_EXPERIMENT(a.debug, 512)) n_pass = 4;
@@ -576,16 +623,9 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
          * within 1024 cells of it (huge depth range at tiny voxels) takes the deferred route instead */
         const float s_lo = __uint_as_float(zmin_bits) - ((float)g.factor + 1.f) * g.vs;
         const float s_hi = __uint_as_float(zmax_bits) + ((float)g.factor + 1.f) * g.vs;
-        float mn[3] = { 3.0e38f, 3.0e38f, 3.0e38f };
-        const float rfx = __frcp_rn(g.fx), rfy = __frcp_rn(g.fy);       /* a bounding box with margin: no parity item */
+        float mn[3];                                                    /* a bilinear form is smallest at a vertex of its box */
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float u = (float)(tile_x * FUSE_T + ((c & 1) ? FUSE_T : -1)), v = (float)(tile_y * FUSE_T + ((c & 2) ? FUSE_T : -1));
-            const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ (u - g.cx) * rfx, (v - g.cy) * rfy, 1.f });
-            mn[0] = fminf(mn[0], fminf(s_lo * d.x, s_hi * d.x));
-            mn[1] = fminf(mn[1], fminf(s_lo * d.y, s_hi * d.y));
-            mn[2] = fminf(mn[2], fminf(s_lo * d.z, s_hi * d.z));
-        }
+        for (int i = 0; i < 3; ++i) mn[i] = fminf(fminf(s_lo * dmin[i], s_hi * dmin[i]), fminf(s_lo * dmax[i], s_hi * dmax[i]));
         const bool any_valid = zmax_bits != 0u;
         /* clamped so that the integer conversion is defined whatever the pose; a clamped origin fails range_ok */
         const float lim = 2.0e6f;

@@ -44,6 +44,8 @@ for c in list(range(4)) + [None]:
     for k, nm in enumerate(names):
         x = d[sel, k]
         print("    %-12s %6.2f | %6.2f | %6.2f" % (nm, x.mean(), np.median(x), np.percentile(x, 90)))
+pl = (t[:, 11] - t[:, 0]) / 100.0; ps = (t[:, 12] - t[:, 0]) / 100.0
+print("prologue detail (single band, mean us): pixel loads arrived %.2f, statistics reduced %.2f, decisions made %.2f" % (pl[single].mean(), ps[single].mean(), d[single, 0].mean()))
 # start times: the dispatch rounds
 st = np.sort(ts[:, 0])
 print("start times us: wg 0 %.1f, 256 %.1f, 511 %.1f, 512 %.1f, 600 %.1f, 800 %.1f, 1000 %.1f, 1199 %.1f" % tuple(st[[0, 256, 511, 512, 600, 800, 1000, 1199]]))
