@@ -282,10 +282,15 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #ifndef FUSE_LCAP
 #define FUSE_LCAP 2048                   /* LDS table entries: 512 buckets of 4 */
 #endif
-#define FUSE_NB (FUSE_LCAP / 4)
+#ifndef FUSE_BSLOTS
+#define FUSE_BSLOTS 4                    /* keys per bucket of the LDS table = one ds_read_b128 per probe (2 per bucket: half the read and
+                                            compare work, 1.03 probes per sample on typical tiles -- but dense tiles then cluster: long probe
+                                            chains, 20 k samples per frame on the deferred route, 68 us instead of 61) */
+#endif
+#define FUSE_NB (FUSE_LCAP / FUSE_BSLOTS)
 #define FUSE_LKEY_EMPTY 0xFFFFFFFFu      /* LDS keys are 32-bit: voxel coordinates relative to the tile origin, 10 bits each */
 #define FUSE_LKEY_DEFER 0x80000000u      /* flush: the entry goes to the deferred list, low 31 bits = voxel record index */
-#define FUSE_LPROBE 12
+#define FUSE_LPROBE (48 / FUSE_BSLOTS)   /* buckets probed before a sample takes the deferred route */
 #ifndef FUSE_OCC
 #define FUSE_OCC (2 * FUSE_ZSPLIT)        /* waves per SIMD the register allocation must allow: 2 workgroups per CU */
 #endif
@@ -705,33 +710,43 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             /* LDS bucket: a LATTICE hash, not a random one.  A tile's voxels are a compact oblique prism;
              * x + 98 y + 143 z (mod 512) sends any two voxels closer than ~8.6 cells to different buckets
              * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
-             * overflow, and the distinct voxels of one wave instruction never compete for a bucket.
-             * (The HBM table keeps the full 64-bit finaliser.) */
-            static_assert(FUSE_NB == 512 || FUSE_NB == 384 || FUSE_NB == 256, "lattice constants exist for 512, 384 and 256 buckets");
+             * overflow, and the distinct voxels of one wave instruction never compete for a bucket: counted on
+             * tiles of the bench stream, 1.004 probes per sample.  (The HBM table keeps the full 64-bit finaliser.) */
+            static_assert((FUSE_BSLOTS == 2 && FUSE_NB == 1024) || (FUSE_BSLOTS == 4 && FUSE_NB == 512), "lattice constants exist for 1024 x 2 and 512 x 4");
             uint32_t bk;
-            if (FUSE_NB == 512) bk = gsdf_mad_u24(lz3, 143u, gsdf_mad_u24(ly3, 98u, lx3)) & 511u;
-            else if (FUSE_NB == 256) bk = (lx3 + 7u * ly3 + 72u * lz3) & 255u;      /* experiments: min distance 6.9 */
-            else bk = (lx3 + 65u * ly3 + 138u * lz3) % 384u;            /* experiments: min distance 7.9 */
-            /* 2.-4. look the voxel up in the LDS table: bucket (4 keys) = one ds_read_b128; the first slot that holds
-             *    the key or is empty decides (used slots are a prefix: entries are never removed and inserts take the
-             *    first empty slot), at most one CAS per probe.  Plain LDS reads: a stale EMPTY is resolved by the CAS. */
+            if (FUSE_BSLOTS == 2) bk = gsdf_mad_u24(lz3, 75u, gsdf_mad_u24(ly3, 86u, lx3)) & 1023u;
+            else bk = gsdf_mad_u24(lz3, 143u, gsdf_mad_u24(ly3, 98u, lx3)) & 511u;
+            /* 2.-4. look the voxel up in the LDS table: one read per bucket; the first slot that holds the key or is empty
+             *    decides (used slots are a prefix: entries are never removed and inserts take the first empty slot), at
+             *    most one CAS per probe.  Plain LDS reads: a stale EMPTY is resolved by the CAS. */
             int slot = -1;
             bool pend = act && local && !GSDF_EXPERIMENT(a.debug, 2);
-            if (GSDF_EXPERIMENT(a.debug, 32)) { if (act) slot = (int)(4 * bk + (key & 3)); pend = false; }   /* experiment: no lookup */
+            if (GSDF_EXPERIMENT(a.debug, 32)) { if (act) slot = (int)(FUSE_BSLOTS * bk + (key & (FUSE_BSLOTS - 1))); pend = false; }   /* experiment: no lookup */
             for (int probe = 0; probe < FUSE_LPROBE; ++probe) {
                 if (!__any(pend)) break;
                 ++dbg_go;
-                const uint4 k4 = *reinterpret_cast<const uint4*>(&L.key[4 * bk]);
-                const bool h0 = k4.x == key, h1 = k4.y == key, h2 = k4.z == key, h3 = k4.w == key;
-                const bool m0 = h0 | (k4.x == FUSE_LKEY_EMPTY), m1 = h1 | (k4.y == FUSE_LKEY_EMPTY),
-                           m2 = h2 | (k4.z == FUSE_LKEY_EMPTY), m3 = h3 | (k4.w == FUSE_LKEY_EMPTY);
-                int pos = m3 ? 3 : -1;
-                pos = m2 ? 2 : pos; pos = m1 ? 1 : pos; pos = m0 ? 0 : pos;
-                const bool hit = h0 | h1 | h2 | h3;
-                const int at = (int)(4u * bk) + pos;
+                int pos;
+                bool hit;
+                if (FUSE_BSLOTS == 2) {
+                    const uint2 k2 = *reinterpret_cast<const uint2*>(&L.key[2 * bk]);
+                    const bool h0 = k2.x == key, h1 = k2.y == key;
+                    const bool m0 = h0 | (k2.x == FUSE_LKEY_EMPTY), m1 = h1 | (k2.y == FUSE_LKEY_EMPTY);
+                    pos = m1 ? 1 : -1;
+                    pos = m0 ? 0 : pos;
+                    hit = h0 | h1;
+                } else {
+                    const uint4 k4 = *reinterpret_cast<const uint4*>(&L.key[4 * bk]);
+                    const bool h0 = k4.x == key, h1 = k4.y == key, h2 = k4.z == key, h3 = k4.w == key;
+                    const bool m0 = h0 | (k4.x == FUSE_LKEY_EMPTY), m1 = h1 | (k4.y == FUSE_LKEY_EMPTY),
+                               m2 = h2 | (k4.z == FUSE_LKEY_EMPTY), m3 = h3 | (k4.w == FUSE_LKEY_EMPTY);
+                    pos = m3 ? 3 : -1;
+                    pos = m2 ? 2 : pos; pos = m1 ? 1 : pos; pos = m0 ? 0 : pos;
+                    hit = h0 | h1 | h2 | h3;
+                }
+                const int at = (int)((uint32_t)FUSE_BSLOTS * bk) + pos;
                 const bool try_cas = pend && !hit && pos >= 0;
                 if (pend && hit) { slot = at; pend = false; }
-                if (pend && pos < 0) bk = bk + 1u == (uint32_t)FUSE_NB ? 0u : bk + 1u;               /* bucket full of others */
+                if (pend && pos < 0) bk = (bk + 1u) & (uint32_t)(FUSE_NB - 1);                       /* bucket full of others */
                 if (GSDF_EXPERIMENT(a.debug, 128) && __any(pend && pos < 0)) ++dbg_full;
                 if (try_cas) {
                     const uint32_t old = atomicCAS(&L.key[at], FUSE_LKEY_EMPTY, key);
