@@ -291,6 +291,9 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #define FUSE_LKEY_EMPTY 0xFFFFFFFFu      /* LDS keys are 32-bit: voxel coordinates relative to the tile origin, 10 bits each */
 #define FUSE_LKEY_DEFER 0x80000000u      /* flush: the entry goes to the deferred list, low 31 bits = voxel record index */
 #define FUSE_LPROBE (48 / FUSE_BSLOTS)   /* buckets probed before a sample takes the deferred route */
+#ifndef FUSE_BOUNDS
+#define FUSE_BOUNDS __launch_bounds__(FUSE_THREADS, FUSE_OCC)
+#endif
 #ifndef FUSE_OCC
 #define FUSE_OCC (2 * FUSE_ZSPLIT)        /* waves per SIMD the register allocation must allow: 2 workgroups per CU */
 #endif
@@ -450,7 +453,7 @@ __device__ __forceinline__ void fuse_log_row(const fuse_args& a) {
     st->log_rows = r + 1;
 }
 
-__global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
+__global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     __shared__ fuse_lds L;
     const int tid = threadIdx.x;
     /* main_scan_3d.cpp:261: if (conv) update.  The launch may have been queued before optimize() ended (the host
@@ -712,9 +715,14 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
              * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
              * overflow, and the distinct voxels of one wave instruction never compete for a bucket: counted on
              * tiles of the bench stream, 1.004 probes per sample.  (The HBM table keeps the full 64-bit finaliser.) */
-            static_assert((FUSE_BSLOTS == 2 && FUSE_NB == 1024) || (FUSE_BSLOTS == 4 && FUSE_NB == 512), "lattice constants exist for 1024 x 2 and 512 x 4");
+            static_assert((FUSE_BSLOTS == 2 && FUSE_NB == 1024) || (FUSE_BSLOTS == 4 && (FUSE_NB == 512 || FUSE_NB == 480)), "lattice constants exist for 1024 x 2, 512 x 4 and 480 x 4");
             uint32_t bk;
             if (FUSE_BSLOTS == 2) bk = gsdf_mad_u24(lz3, 75u, gsdf_mad_u24(ly3, 86u, lx3)) & 1023u;
+            else if (FUSE_NB == 480) {                                 /* x + 313 y + 195 z (mod 480): min distance 8.1; 1.12 probes per sample on the densest tiles */
+                const uint32_t hx = gsdf_mad_u24(lz3, 195u, gsdf_mad_u24(ly3, 313u, lx3));         /* < 2^20 for local keys */
+                bk = hx - 480u * __umulhi(hx, 8947849u);                /* exact for hx < 2^20 */
+                bk = bk < 480u ? bk : 0u;                               /* keys outside the local range: any bucket, never used */
+            }
             else bk = gsdf_mad_u24(lz3, 143u, gsdf_mad_u24(ly3, 98u, lx3)) & 511u;
             /* 2.-4. look the voxel up in the LDS table: one read per bucket; the first slot that holds the key or is empty
              *    decides (used slots are a prefix: entries are never removed and inserts take the first empty slot), at
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
             bool pend = act && local && !GSDF_EXPERIMENT(a.debug, 2);
             if (GSDF_EXPERIMENT(a.debug, 32)) { if (act) slot = (int)(FUSE_BSLOTS * bk + (key & (FUSE_BSLOTS - 1))); pend = false; }   /* experiment: no lookup */
             for (int probe = 0; probe < FUSE_LPROBE; ++probe) {
-                if (!__any(pend)) break;
+                if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
                 ++dbg_go;
                 int pos;
                 bool hit;
@@ -746,7 +754,7 @@ __global__ __launch_bounds__(FUSE_THREADS, FUSE_OCC) void k_fuse(fuse_args a) {
                 const int at = (int)((uint32_t)FUSE_BSLOTS * bk) + pos;
                 const bool try_cas = pend && !hit && pos >= 0;
                 if (pend && hit) { slot = at; pend = false; }
-                if (pend && pos < 0) bk = (bk + 1u) & (uint32_t)(FUSE_NB - 1);                       /* bucket full of others */
+                if (pend && pos < 0) bk = bk + 1u == (uint32_t)FUSE_NB ? 0u : bk + 1u;                       /* bucket full of others */
                 if (GSDF_EXPERIMENT(a.debug, 128) && __any(pend && pos < 0)) ++dbg_full;
                 if (try_cas) {
                     const uint32_t old = atomicCAS(&L.key[at], FUSE_LKEY_EMPTY, key);
