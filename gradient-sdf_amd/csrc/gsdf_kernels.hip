@@ -1279,6 +1279,16 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
      * runs on across optimize() calls, tp.rot): launch j accumulates into buffer j % 3, reads j - 1 and clears
      * j + 1, which nothing has touched since launch j - 2 read it.  Every launch does the clearing first, also
      * the ones that return early. */
+    /* the depth of this lane's (first) pixels does not depend on the pose: requested now, it arrives under the head */
+    float z_pre[TRK_PPT];
+    {
+        const int N = g.W * g.H, base0 = (int)blockIdx.x * GSDF_TRACK_BLOCK + tid, nthreads = tp.n_track_blocks * GSDF_TRACK_BLOCK;
+#pragma unroll
+        for (int j = 0; j < TRK_PPT; ++j) {
+            const int pix = base0 + j * nthreads;
+            z_pre[j] = pix < N ? depth[pix] : 0.f;
+        }
+    }
     double* acc_cur = rows + (size_t)(tp.rot % 3u) * GSDF_TRACK_ROWSET;
     const double* acc_prev = rows + (size_t)((tp.rot + 2u) % 3u) * GSDF_TRACK_ROWSET;
     if (blockIdx.x == 0) {
@@ -1359,7 +1369,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
     float acc[GSDF_TRACK_NSUM];
 #pragma unroll
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
-    trk_gather(g, tab, depth, nullptr, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, tp.n_track_blocks * GSDF_TRACK_BLOCK, acc);
+    trk_gather(g, tab, depth, z_pre, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, tp.n_track_blocks * GSDF_TRACK_BLOCK, acc);
     __syncthreads();                                                      /* wsum is reused */
     wave_sum_to_lane63(acc);
     if (lane == 63) {
