@@ -646,3 +646,70 @@ def test_get_voxels_returns_the_stored_record(pkg, O):
     assert np.array_equal(got[:500].view(np.uint32), pay[sel].view(np.uint32))
     assert (got[500:] == 0).all()
     g.close()
+
+
+def _contention_worker(rank, out_dir, n_rounds):
+    """One of two processes that fuse the same stream on the same GPU at the same time (own context each)."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    pkg = graft.package()
+    W, H = 640, 480
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=4, seed=1)
+    vs = np.float32(0.01)
+    g = pkg.GradSdf(vs, np.float32(10) * vs, W, H, seq.K, capacity_log2=22)
+    frames = [seq.frame(i) for i in range(seq.n)]
+    dev = [g.upload(f[0]) for f in frames]
+    open(os.path.join(out_dir, "ready%d" % rank), "w").close()
+    import time
+    t0 = time.time()
+    while not all(os.path.exists(os.path.join(out_dir, "ready%d" % r)) for r in (0, 1)) and time.time() - t0 < 120:
+        time.sleep(0.001)
+    keys = pay = None
+    timeouts = deferred = 0
+    for rnd in range(n_rounds):                       # many rounds: the two processes' kernels interleave on the device
+        g.reset()
+        for d, f in zip(dev, frames):
+            g.update_dev(d, f[1], f[2])
+        g.sync()
+        st = g.stats()
+        timeouts += st["fuse_timeouts"]; deferred += st["n_deferred"]
+        k, p = g.export(sorted=True)
+        if keys is None:
+            keys, pay = k, p
+        else:                                          # every round must give the same map (sums up to float-atomic order)
+            assert np.array_equal(k, keys)
+            assert np.abs(p - pay).max() <= 1e-4 * max(1.0, float(np.abs(pay).max()))
+    np.savez(os.path.join(out_dir, "proc%d.npz" % rank), keys=keys, pay=pay, timeouts=timeouts, deferred=deferred)
+    g.close()
+
+
+def test_two_processes_fuse_on_one_gpu_at_the_same_time(pkg, O, tmp_path):
+    """Two processes share the GPU: each tile hand-off of the ordered flush now competes with a foreign kernel for the CUs
+    (waits get longer, and a wait that expires sends its tile through the deferred list -- the forced form of that path is
+    test_fusion_forced_paths_match_oracle[8192]).  Whatever the interleaving, both maps must equal the oracle's."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_contention_worker, args=(r, str(tmp_path), 12)) for r in (0, 1)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    W, H = 640, 480
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=4, seed=1)
+    vs = np.float32(0.01)
+    o = O.Oracle(vs, np.float32(10) * vs, W, H, seq.K)
+    for i in range(seq.n):
+        o.update(*seq.frame(i))
+    ko, po = o.export()
+    for r in (0, 1):
+        z = np.load(tmp_path / ("proc%d.npz" % r))
+        assert np.array_equal(z["keys"], ko), "voxel key sets differ"
+        assert np.abs(z["pay"][:, 0] - po[:, 0]).max() <= TOL
+        scale = np.maximum(1.0, po[:, 4])
+        assert (np.abs(z["pay"][:, 4] - po[:, 4]) / scale).max() <= TOL
+        assert (np.abs(z["pay"][:, 1:4] - po[:, 1:4]).max(axis=1) / scale).max() <= TOL
+        print("process %d: %d hand-off waits expired, %d deferred contributions over 12 rounds" % (r, int(z["timeouts"]), int(z["deferred"])))
