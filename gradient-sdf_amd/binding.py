@@ -112,6 +112,7 @@ def load(path=None):
         "gsdf_enable_vis": (C.c_int, [vp, C.c_int]),
         "gsdf_export_vis": (C.c_int, [vp, i32p, C.POINTER(C.c_uint32), C.c_int, C.c_int64, i64p]),
         "gsdf_ba_setup": (C.c_int, [vp, C.c_int, fp, fp, C.POINTER(C.c_int), C.c_float]),
+        "gsdf_ba_set_loss": (C.c_int, [vp, C.c_int, C.c_float]),
         "gsdf_ba_energy": (C.c_int, [vp, fp]),
         "gsdf_ba_solve_pose": (C.c_int, [vp, C.c_float]),
         "gsdf_ba_solve_dist": (C.c_int, [vp, C.c_float]),
@@ -160,7 +161,7 @@ ABI_SYMBOLS = [
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
     "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
-    "gsdf_ba_setup", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
+    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
     "gsdf_merge_allreduce", "gsdf_merge_allreduce_with", "gsdf_rccl_unique_id", "gsdf_rccl_comm_init", "gsdf_rccl_comm_destroy",
@@ -358,6 +359,9 @@ class GradSdf:
         idx = np.ascontiguousarray(frame_idx, dtype=np.int32)
         self._chk(self.L.gsdf_ba_setup(self.h, self._ba_n, _fp(img), _fp(P), idx.ctypes.data_as(C.POINTER(C.c_int)),
                                        np.float32(reg_weight)))
+
+    def ba_set_loss(self, loss, lam=0.5):
+        self._chk(self.L.gsdf_ba_set_loss(self.h, int(loss), np.float32(lam)))
 
     def ba_energy(self):
         e = C.c_float(0)

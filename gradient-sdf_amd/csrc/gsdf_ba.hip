@@ -74,6 +74,7 @@ struct ba_args {
     const float* t;           /* n x 3 */
     const int* frame_idx;
     float fx, fy, cx, cy, vs, reg_weight;
+    float trunc_sq;
 };
 
 struct ba_voxel { float dist, w; gsdf_v3 grad, gn, c; };
@@ -96,6 +97,12 @@ __device__ __forceinline__ bool ba_visible(const ba_args& a, size_t slot, int i)
     if (f >= 32 * a.vis_words) return false;
     return (a.vis[slot * a.vis_words + (f >> 5)] >> (f & 31)) & 1u;
 }
+/* LossFunction::TRUNC_L2 (loss.h:45): a keyframe whose intensity residual is too large is left out of the voxel's sums
+ * (solveDist :364, solvePose :542); every other loss value behaves like L2 in the reference's code */
+__device__ __forceinline__ bool ba_truncated(const ba_args& a, const gsdf_v3& A) {
+    return a.trunc_sq >= 0.f && fmaxf(A.x * A.x, fmaxf(A.y * A.y, A.z * A.z)) > a.trunc_sq;
+}
+
 /* projection shared by getIntensity / computeJc / computeJdOneFrame (:165-177) */
 __device__ __forceinline__ bool ba_project(const ba_args& a, const ba_voxel& v, int i, gsdf_v3* point, float* m, float* n) {
     const float* Ri = a.R + 9 * i;
@@ -195,6 +202,7 @@ __global__ __launch_bounds__(256) void k_ba_dist(ba_args a, float damping) {
             if (!ba_project(a, v, i, &p, &m, &n)) continue;
             const ba_img im = { a.W, a.H, a.images + (size_t)i * a.W * a.H * 3 };
             const gsdf_v3 A = ba_interp(n, m, im);
+            if (ba_truncated(a, A)) continue;                                  /* :364 */
             ++Nj;
             float G[9];
             ba_image_pi_grad(a, p, m, n, i, G);
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /*
                 if (!ba_project(a, v, i, &p, &m, &n)) continue;
                 const ba_img im = { a.W, a.H, a.images + (size_t)i * a.W * a.H * 3 };
                 const gsdf_v3 A = ba_interp(n, m, im);
+                if (ba_truncated(a, A)) continue;                              /* :542 */
                 mean = gsdf_v3{ mean.x + A.x, mean.y + A.y, mean.z + A.z };
                 ++Nj;
                 seen |= 1ull << (i & 63);

@@ -673,6 +673,7 @@ static gsdf_ba_dev ba_dev(gsdf_ctx* c) {
     d.n = c->ba_n; d.W = c->W; d.H = c->H;
     d.images = c->ba_images; d.R = c->ba_Rt; d.t = c->ba_Rt + 9 * (size_t)c->ba_n; d.frame_idx = c->ba_frame_idx;
     d.fx = c->K[0]; d.fy = c->K[4]; d.cx = c->K[2]; d.cy = c->K[5]; d.vs = c->voxel_size; d.reg_weight = c->ba_reg;
+    d.trunc_sq = c->ba_trunc_sq;
     return d;
 }
 static int ba_upload_poses(gsdf_ctx* c) {
@@ -684,6 +685,13 @@ static int ba_upload_poses(gsdf_ctx* c) {
 static int ba_require(gsdf_ctx* c) {
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     if (!c->ba_n) return fail(GSDF_ERR_INVALID, "gsdf_ba_setup was not called");
+    return GSDF_OK;
+}
+
+int gsdf_ba_set_loss(gsdf_ctx* c, int loss, float lambda) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    if (loss < 0 || loss > 4 || !(lambda >= 0.f)) return fail(GSDF_ERR_INVALID, "loss must be a LossFunction value (0..4), lambda >= 0");
+    c->ba_trunc_sq = loss == 4 ? lambda * lambda : -1.f;          /* the reference's code only distinguishes TRUNC_L2 */
     return GSDF_OK;
 }
 

@@ -63,6 +63,7 @@ struct gsdf_ctx {
     /* PhotoBA (PhotometricOptimizer) */
     int ba_n = 0;
     float ba_reg = 10.f;
+    float ba_trunc_sq = -1.f;                      /* OptSettings::lambda_sq when loss == TRUNC_L2, else < 0 */
     float* ba_images = nullptr;
     float* ba_Rt = nullptr;                        /* device: n x 9 rotations then n x 3 translations */
     int* ba_frame_idx = nullptr;

@@ -160,6 +160,7 @@ struct gsdf_ba_dev {
     const float* t;
     const int* frame_idx;
     float fx, fy, cx, cy, vs, reg_weight;
+    float trunc_sq;               /* TRUNC_L2 (PhotometricOptimizer.cpp:364,:542): lambda^2, or < 0 for every other loss */
 };
 void gsdf_launch_ba_energy(hipStream_t s, const gsdf_ba_dev& d, double* block_E);
 void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping);

@@ -15,11 +15,15 @@
 
 #include "MapGradPixelSdf.h"
 
+enum LossFunction { L2 = 0, CAUCHY = 1, HUBER = 2, TUKEY = 3, TRUNC_L2 = 4 };   /* loss.h:39-46 */
+
 struct OptSettings {                       /* PhotometricOptimizer.h:49-66 */
     int max_it = 25;
     float conv_threshold = 1e-4f;
     float damping = 1.0f;
+    float lambda = 0.5f;                   /* lambda of the weight function (not the LM damping) */
     float reg_weight = 10.0f;
+    LossFunction loss = CAUCHY;            /* only TRUNC_L2 changes the computation, as in the reference (:364, :542) */
 };
 
 /* float BGR image in [0,1], rows x cols x 3 (cv::Mat CV_32FC3 as produced by ImageLoader::load_color) */
@@ -49,6 +53,7 @@ class PhotometricOptimizer {
             for (int k = 0; k < 16; ++k) P[16 * i + k] = poses_[i].m[k];
         }
         check(gsdf_ba_setup(tSDF_->handle(), (int)n, img.data(), P.data(), frame_idx_.data(), settings_.reg_weight), "gsdf_ba_setup");
+        check(gsdf_ba_set_loss(tSDF_->handle(), (int)settings_.loss, settings_.lambda), "gsdf_ba_set_loss");
         uploaded_ = true;
     }
     void download() {

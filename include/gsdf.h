@@ -137,6 +137,10 @@ int gsdf_export_vis(gsdf_ctx* c, int32_t* keys, uint32_t* words, int words_per_v
  * and distance step (<= 2*max_it+1 values), *converged = relative change < 5e-4. */
 int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float* poses16_host, const int* frame_idx,
                   float reg_weight);
+/* OptSettings::loss and OptSettings::lambda (PhotometricOptimizer.h:54-57; LossFunction, loss.h:39-46: 0 L2, 1 CAUCHY -- the
+ * default --, 2 HUBER, 3 TUKEY, 4 TRUNC_L2).  As in the reference only TRUNC_L2 changes the computation: solveDist (:364) and
+ * solvePose (:542) then leave out a keyframe whose intensity residual exceeds lambda^2 in any channel.  Default: CAUCHY, 0.5. */
+int gsdf_ba_set_loss(gsdf_ctx* c, int loss, float lambda);
 int gsdf_ba_energy(gsdf_ctx* c, float* E);
 int gsdf_ba_solve_pose(gsdf_ctx* c, float damping);
 int gsdf_ba_solve_dist(gsdf_ctx* c, float damping);

@@ -867,7 +867,7 @@ int gsdfo_track(gsdfo* o, const float* depth, const float K[9], float pose7[7],
 
 /* ==================================================================================================
  * PhotoBA oracle: PhotometricOptimizer restated (ps_optimizer/PhotometricOptimizer.cpp), L2 loss path
- * (the default CAUCHY setting never enters the TRUNC_L2 branches, :358,:541).
+ * (the default CAUCHY setting never enters the TRUNC_L2 branches :364,:542; gsdfo_ba_set_loss selects them).
  * ================================================================================================== */
 namespace {
 
@@ -929,6 +929,10 @@ struct gsdfo_ba {
     std::vector<float> t;          /* n x 3 */
     std::vector<int> frame_idx;
     float reg_weight;
+    int loss = 1;                /* LossFunction (loss.h:39-46): 0 L2, 1 CAUCHY (OptSettings default), 2 HUBER, 3 TUKEY, 4 TRUNC_L2 */
+    float lambda_sq = 0.25f;     /* OptSettings::lambda_sq, lambda = 0.5 (PhotometricOptimizer.h:62-63) */
+    /* the only place the loss enters: solveDist :364 and solvePose :542 skip a keyframe whose residual is too large */
+    bool truncated(const V3& a) const { return loss == 4 && std::max(a.x * a.x, std::max(a.y * a.y, a.z * a.z)) > lambda_sq; }
     std::vector<Key> order;        /* voxel visiting order (z,y,x) */
 
     Img img(int i) const { return Img{ W, H, images.data() + (size_t)i * W * H * 3 }; }
@@ -1023,6 +1027,7 @@ static double ba_energy_impl(gsdfo_ba* b, float* E_float) {
     if (E_float) *E_float = E;
     return E64;
 }
+void gsdfo_ba_set_loss(gsdfo_ba* b, int loss, float lambda) { b->loss = loss; b->lambda_sq = lambda * lambda; }
 float gsdfo_ba_energy(gsdfo_ba* b) {
     float E = 0.f;
     ba_energy_impl(b, &E);
@@ -1040,6 +1045,7 @@ void gsdfo_ba_solve_dist(gsdfo_ba* b, float damping) {
             if (!b->visible(idx, i)) continue;
             V3 a;
             if (!b->intensity(idx, vox, i, &a)) continue;
+            if (b->truncated(a)) continue;                                              /* :364 */
             ++Nj;
             /* computeJdOneFrame :160-203: Jd = image_grad * pi_grad * (-Rt * grad) */
             V3 p; float G[9];
@@ -1103,6 +1109,7 @@ void gsdfo_ba_solve_pose(gsdfo_ba* b, float) {
             if (!b->visible(idx, i)) continue;
             V3 a, p; float G[9];
             if (!b->intensity(idx, vox, i, &a) || !b->image_pi_grad(idx, vox, i, &p, G)) continue;
+            if (b->truncated(a)) continue;                                              /* :542 */
             /* computeJc :206-233: Jc = [ -G * Rt , G * skew(point) ]  (3x6) */
             const float* Ri = &b->R[9 * i];
             std::array<float, 18> J;

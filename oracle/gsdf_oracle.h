@@ -114,6 +114,8 @@ typedef struct gsdfo_ba gsdfo_ba;
 gsdfo_ba* gsdfo_ba_create(gsdfo* o, const float K[9], int n, int W, int H, const float* images_bgr,
                           const float* poses16, const int* frame_idx, float reg_weight);
 void   gsdfo_ba_destroy(gsdfo_ba* b);
+/* OptSettings::loss / lambda (PhotometricOptimizer.h:54-57, loss.h:39-46): only TRUNC_L2 (4) changes anything, as in the reference */
+void   gsdfo_ba_set_loss(gsdfo_ba* b, int loss, float lambda);
 float  gsdfo_ba_energy(gsdfo_ba* b);                       /* getEnergy        :273-321 (float sum, (z,y,x) order) */
 double gsdfo_ba_energy_f64(gsdfo_ba* b);                   /* the same float terms added in double (order-independent) */
 void   gsdfo_ba_solve_pose(gsdfo_ba* b, float damping);    /* solvePose        :499-590 */

@@ -254,6 +254,12 @@ class PhotoBA:
             self.L.gsdfo_ba_destroy(self.h)
             self.h = None
 
+    def set_loss(self, loss, lam=0.5):
+        """OptSettings::loss / lambda; 4 = TRUNC_L2 (the only value the reference's code distinguishes)."""
+        self.L.gsdfo_ba_set_loss.restype = None
+        self.L.gsdfo_ba_set_loss.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        self.L.gsdfo_ba_set_loss(self.h, int(loss), np.float32(lam))
+
     def energy(self):
         return float(self.L.gsdfo_ba_energy(self.h))
 

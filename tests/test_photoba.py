@@ -59,6 +59,34 @@ def test_oracle_photoba_ignores_invisible_keyframes(pkg, O):
     assert e_all > 0 and e_none == 0.0
 
 
+def test_oracle_photoba_trunc_l2_known_answers(pkg, O):
+    """LossFunction::TRUNC_L2 (PhotometricOptimizer.cpp:364,:542): a keyframe whose intensity exceeds lambda in any channel is
+    left out of a voxel's sums.  lambda above every intensity (images are in [0, 1]) = the default loss, bit for bit;
+    lambda = 0 leaves out every keyframe that sees anything: the steps do nothing; in between the step differs."""
+    seq, vs, T, frames, imgs, P, Pp = _scene(pkg, O)
+    n = len(frames)
+
+    def step(loss, lam):
+        o = _oracle_map(O, seq, vs, T, frames)
+        ba = O.PhotoBA(o, imgs, Pp, np.arange(n))
+        if loss is not None:
+            ba.set_loss(loss, lam)
+        ba.solve_pose()
+        ba.solve_dist()
+        return ba.poses(), o.export()[1][:, 0].copy()
+
+    p_def, d_def = step(None, 0)
+    p_big, d_big = step(4, 2.0)
+    assert np.array_equal(p_def, p_big) and np.array_equal(d_def, d_big)
+    p_cau, d_cau = step(1, 0.01)                                  # any loss but TRUNC_L2 ignores lambda, as in the reference
+    assert np.array_equal(p_def, p_cau) and np.array_equal(d_def, d_cau)
+    p_zero, d_zero = step(4, 0.0)
+    o0 = _oracle_map(O, seq, vs, T, frames)
+    assert np.array_equal(p_zero, Pp) and np.array_equal(d_zero, o0.export()[1][:, 0])
+    p_mid, d_mid = step(4, 0.5)
+    assert np.abs(p_mid - p_def).max() > 1e-5 and np.abs(p_mid - Pp).max() > 1e-4
+
+
 def _gpu_and_oracle_on_the_same_map(pkg, O, n=6):
     """Fuse on the GPU (with vis_), fuse in the oracle, then give the oracle the GPU's voxel values: both BA implementations
     start from identical maps (key sets and vis_ are bit-exact anyway, tests/test_gpu_parity.py)."""
@@ -106,6 +134,36 @@ def test_gpu_photoba_steps_match_oracle(pkg, O, n):
     assert np.abs(pg[:, 0] - before).max() > 1e-4                # distances did move ...
     assert np.abs(pg[:, 0] - po[:, 0]).max() < 1e-6              # ... identically (measured: 7e-9)
     assert g.ba_energy() == pytest.approx(ba2.energy_f64(), rel=1e-4)
+    g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_photoba_trunc_l2_matches_oracle(pkg, O):
+    """The TRUNC_L2 gates of solvePose / solveDist on the GPU against the oracle, from identical state."""
+    n = 6
+    seq, g, o, imgs, P, Pp = _gpu_and_oracle_on_the_same_map(pkg, O, n=n)
+    idx = np.arange(n)
+    ba = O.PhotoBA(o, imgs, Pp, idx)
+    ba.set_loss(4, 0.5)
+    g.ba_setup(imgs, Pp, idx)
+    g.ba_set_loss(4, 0.5)
+    ba.solve_pose()
+    g.ba_solve_pose()
+    assert np.abs(ba.poses() - Pp).max() > 1e-4
+    assert np.abs(g.ba_poses() - ba.poses()).max() < 1e-4
+    # the gate really was active: the untruncated step is another one
+    ref = O.PhotoBA(o, imgs, Pp, idx)
+    ref.solve_pose()
+    assert np.abs(ref.poses() - ba.poses()).max() > 1e-5
+    ba2 = O.PhotoBA(o, imgs, g.ba_poses(), idx)
+    ba2.set_loss(4, 0.5)
+    ba2.solve_dist()
+    g.ba_solve_dist()
+    ko, po = o.export()
+    kg, pg = g.export(sorted=True)
+    assert np.array_equal(kg, ko) and np.abs(pg[:, 0] - po[:, 0]).max() < 1e-6
+    with pytest.raises(Exception):
+        g.ba_set_loss(7, 0.5)
     g.close()
 
 
