@@ -1265,6 +1265,13 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
         normals_tile(*reinterpret_cast<nrm_lds*>(dyn_lds), t % nj.ntx, t / nj.ntx, g.W, g.H, nj.r, nj.nc, depth, nj.nx, nj.ny, nj.nz);
         return;
     }
+    /* test build, debug bit 64 of the tracker flags: time stamps of thread 0 in rows 2048 + pass * 512 + workgroup of the
+     * trace buffer (rows 0..2047 belong to k_fuse), tools/track_trace.py */
+    unsigned long long* trk_tr = nullptr;
+    if (GSDF_EXPERIMENT(tp.debug, 64) && blockIdx.x < 512u && tp.pass_index < 12) {
+        trk_tr = reinterpret_cast<unsigned long long*>(st->dbg[23]) + 16 * (2048 + (size_t)tp.pass_index * 512 + blockIdx.x);
+        if (threadIdx.x == 0) trk_tr[0] = wall_clock64();
+    }
     __shared__ float wsum[GSDF_TRACK_BLOCK / 64][32];
     __shared__ double gsum[GSDF_TRACK_BLOCK / 32][32];
     __shared__ float tot[32];
@@ -1363,6 +1370,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
         for (int i = 0; i < 7; ++i) pose[i] = sh_pose[i];
     }
+    if (trk_tr && threadIdx.x == 0) trk_tr[1] = wall_clock64();                         /* head done */
     if (k >= tp.max_passes || GSDF_EXPERIMENT(tp.debug, 2)) return;                     /* head-only launch */
 
     /* ---- gather + normal-equation sums of pass k with the current pose ---- */
@@ -1370,6 +1378,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
 #pragma unroll
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
     trk_gather(g, tab, depth, z_pre, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, tp.n_track_blocks * GSDF_TRACK_BLOCK, acc);
+    if (trk_tr && threadIdx.x == 0) trk_tr[2] = wall_clock64();                         /* wave 0: gather done */
     __syncthreads();                                                      /* wsum is reused */
     wave_sum_to_lane63(acc);
     if (lane == 63) {
@@ -1388,6 +1397,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
          * resolution whatever their order */
         if (tid < GSDF_TRACK_NSUM) unsafeAtomicAdd(&acc_cur[(blockIdx.x % GSDF_TRACK_GROUPS) * 32 + tid], (double)v);
     }
+    if (trk_tr && threadIdx.x == 0) trk_tr[3] = wall_clock64();
 }
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
                             gsdf_dev_state* st, double* partials, int n_blocks, const gsdf_track_params& tp_in,
