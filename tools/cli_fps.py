@@ -71,7 +71,7 @@ print("%-46s %9.2f frames/s   (CPU oracle, serial, %d frames)" % ("C1 spheres, t
 # ---- C2: the bench stream as TUM files ------------------------------------------------------------------------------
 seq = pkg.synth.Sequence("tum", 640, 480, n_frames=a.frames_tum, seed=0)
 ds = pkg.synth.write_dataset(seq, os.path.join(tmp, "c2"), layout="tum", with_poses=False)
-for th in (2, 8, 16):
+for th in (2, 8, 16, 32):
     run(ds, "tum", ["--decode-threads", str(th)], "C2 S-tum x%d, tracked, %d decode threads" % (a.frames_tum, th))
 run(ds, "tum", ["--sync"], "C2 S-tum x%d, tracked, --sync" % a.frames_tum)
 shutil.rmtree(tmp, ignore_errors=True)
