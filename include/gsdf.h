@@ -63,6 +63,7 @@ const char* gsdf_version(void);
  * capacity_log2 in [10, 30]: 2^capacity_log2 32-byte voxel records, organised as 2^(capacity_log2-6) blocks of
  * 4x4x4 voxels (BASELINE configs: 22 and 25).  A surface map fills its blocks to ~70 %, so it holds about
  * 0.6 * 2^capacity_log2 voxels before GSDF_ERR_TABLE_FULL.
+ * trunc_dist (T) must be below 2 m: the fusion kernel accumulates a tile's w * sdf sums in 51-bit fixed point (2^-40).
  * device: HIP device ordinal.  Fails with GSDF_ERR_NO_DEVICE when no GPU is present. */
 int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device);
 /* delete tSDF -- main_scan_3d.cpp:314 */

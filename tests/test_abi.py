@@ -66,6 +66,7 @@ def test_bad_arguments_are_rejected(pkg):
     h = ctypes.c_void_p()
     assert L.gsdf_create(ctypes.byref(h), np.float32(-1), np.float32(0.1), 16, 0) == pkg.binding.ERR_INVALID
     assert L.gsdf_create(ctypes.byref(h), np.float32(0.01), np.float32(0.1), 5, 0) == pkg.binding.ERR_INVALID
+    assert L.gsdf_create(ctypes.byref(h), np.float32(0.2), np.float32(2.0), 16, 0) == pkg.binding.ERR_INVALID   # T < 2 m (fixed-point range)
     assert L.gsdf_sync(None) == pkg.binding.ERR_INVALID
 
 
