@@ -1273,8 +1273,6 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
         if (threadIdx.x == 0) trk_tr[0] = wall_clock64();
     }
     __shared__ float wsum[GSDF_TRACK_BLOCK / 64][32];
-    __shared__ double gsum[GSDF_TRACK_BLOCK / 32][32];
-    __shared__ float tot[32];
     __shared__ float sh_pose[8];
     __shared__ int sh_done;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1317,52 +1315,58 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
     } else {
         /* ---- head: every workgroup reduces the rows of pass k-1 in the same fixed order, solves the
          * 6x6 system and applies the update -- bit-identical everywhere, so no workgroup has to wait for
-         * another one inside a launch; workgroup 0 publishes the result for the next launch / the host ---- */
-        /* the row reads do not depend on the state words: issue them first so that both memory round
-         * trips overlap (a launch that finds `done` set wasted 16 loads per lane, and is rare) */
-        /* lane (g, v) = (tid / 32, tid % 32) sums groups g, g + T/32, ... of value v, in increasing order */
-        double gs = 0.0;
-        for (int grp = tid >> 5; grp < GSDF_TRACK_GROUPS; grp += GSDF_TRACK_BLOCK / 32) gs += acc_prev[grp * 32 + (tid & 31)];
+         * another one inside a launch; workgroup 0 publishes the result for the next launch / the host ----
+         * Wave 0 does it alone: lane v < 29 adds the GSDF_TRACK_GROUPS group sums of value v in increasing order (all
+         * loads in flight at once, issued before the state words are looked at: a launch that finds `done` set wasted
+         * them, and is rare), `v_readlane` hands the 29 totals to every lane, the solve runs without an LDS stage; the
+         * other waves meet it at ONE barrier (two LDS stages behind three barriers before). */
         const gsdf_trk_buf& in = st->trk[(k - 1) & 1];
-        const int in_done = in.done;
+        if (wave == 0) {
+            double gs = 0.0;
+            if (lane < GSDF_TRACK_NSUM) {
+                double part[GSDF_TRACK_GROUPS];
 #pragma unroll
-        for (int i = 0; i < 7; ++i) pose[i] = in.pose7[i];
-        const int passes = in.passes + 1;
-        if (in_done) return;                                              /* this optimize() already ended */
-        gsum[tid >> 5][tid & 31] = gs;
-        __syncthreads();
-        if (tid < GSDF_TRACK_NSUM) {
-            double v = gsum[0][tid];
+                for (int grp = 0; grp < GSDF_TRACK_GROUPS; ++grp) part[grp] = acc_prev[grp * 32 + lane];
+                gs = part[0];
 #pragma unroll
-            for (int w = 1; w < GSDF_TRACK_BLOCK / 32; ++w) v += gsum[w][tid];
-            tot[tid] = (float)v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int done, converged;
-            trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, GSDF_EXPERIMENT(tp.debug, 1), pose, &done, &converged);
+                for (int grp = 1; grp < GSDF_TRACK_GROUPS; ++grp) gs += part[grp];
+            }
+            const int in_done = in.done;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) sh_pose[i] = pose[i];
-            sh_done = done;
-            if (blockIdx.x == 0) {
-                gsdf_trk_buf& o = st->trk[k & 1];
+            for (int i = 0; i < 7; ++i) pose[i] = in.pose7[i];
+            const int passes = in.passes + 1;
+            int done = 1, converged = 0;
+            if (!in_done) {                                               /* else: this optimize() already ended */
+                const float totv = (float)gs;
+                float tot[GSDF_TRACK_NSUM];                               /* the 29 sums, in every lane */
 #pragma unroll
-                for (int i = 0; i < 7; ++i) { o.pose7[i] = pose[i]; st->pose7[i] = pose[i]; }
-                o.done = done; o.converged = converged; o.passes = passes;
-                /* make `done` sticky in the other parity as well: launches that the host queued beyond the
-                 * end of this optimize() must not take the older buffer for live state and redo the step
-                 * (workgroups of THIS launch that still read it return early, which is what they do anyway) */
-                if (done) st->trk[(k - 1) & 1].done = 1;
-                gsdf_quat_to_R(pose + 3, st->R);
-                st->converged = converged;
-                st->done = done;
-                st->passes = passes;
-                st->last_hits = tot[28];
-                st->n_hit += (unsigned long long)tot[28];
-                /* progress for the host's adaptive pass issue (pinned host memory, system scope) */
-                if (tp.progress)                 /* one word, so the host reads a consistent (passes, done) pair */
-                    __hip_atomic_store(&tp.progress[0], (tp.serial << 16) | (done ? 0x8000u : 0u) | (unsigned int)(passes & 0x7FFF),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int i = 0; i < GSDF_TRACK_NSUM; ++i) tot[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(totv), i));
+                trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, GSDF_EXPERIMENT(tp.debug, 1), pose, &done, &converged);
+                if (blockIdx.x == 0 && tid == 0) {
+                    gsdf_trk_buf& o = st->trk[k & 1];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) { o.pose7[i] = pose[i]; st->pose7[i] = pose[i]; }
+                    o.done = done; o.converged = converged; o.passes = passes;
+                    /* make `done` sticky in the other parity as well: launches that the host queued beyond the
+                     * end of this optimize() must not take the older buffer for live state and redo the step
+                     * (workgroups of THIS launch that still read it return early, which is what they do anyway) */
+                    if (done) st->trk[(k - 1) & 1].done = 1;
+                    gsdf_quat_to_R(pose + 3, st->R);
+                    st->converged = converged;
+                    st->done = done;
+                    st->passes = passes;
+                    st->last_hits = tot[28];
+                    st->n_hit += (unsigned long long)tot[28];
+                    /* progress for the host's adaptive pass issue (pinned host memory, system scope) */
+                    if (tp.progress)             /* one word, so the host reads a consistent (passes, done) pair */
+                        __hip_atomic_store(&tp.progress[0], (tp.serial << 16) | (done ? 0x8000u : 0u) | (unsigned int)(passes & 0x7FFF),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) sh_pose[i] = pose[i];
+                sh_done = done;
             }
         }
         __syncthreads();
