@@ -17,6 +17,9 @@ rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k
 cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $out/bench_kernel_stats.csv 2>/dev/null
 python $root/tools/trace_summary.py /tmp/kt > $out/bench_kernel_summary.txt 2>&1
 python $root/tools/trace_timeline.py /tmp/kt > $out/bench_kernel_timeline.txt 2>&1
+# the same trace over the default 200-step window (a quarter of its frames does not converge: 25 passes, no fusion)
+rm -rf /tmp/ktd && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktd -o bench -- python $root/bench.py --cpu-frames 0 > $out/bench_default_profiled.json 2> $out/rocprof_kernel_trace_default.err
+python $root/tools/trace_summary.py /tmp/ktd > $out/bench_default_kernel_summary.txt 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
