@@ -280,7 +280,10 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #endif
 #define FUSE_THREADS (256 * FUSE_ZSPLIT)
 #ifndef FUSE_LCAP
-#define FUSE_LCAP 2048                   /* LDS table entries: 512 buckets of 4 */
+#define FUSE_LCAP 2048                   /* LDS table entries: 512 buckets of 4 (57 KB with the accumulators).  -DFUSE_LCAP=2560 (640 buckets,
+                                            72 KB, still two workgroups per CU) keeps far tiles (2.5-3 m at 640x480 / 1 cm) in one band: fusions
+                                            of frames with far geometry 68 -> 63 us, near scenes 62 -> 63 us (measured; the bench stream's
+                                            driver window is a near scene) */
 #endif
 #ifndef FUSE_BSLOTS
 #define FUSE_BSLOTS 4                    /* keys per bucket of the LDS table = one ds_read_b128 per probe (2 per bucket: half the read and
@@ -288,6 +291,10 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
                                             chains, 20 k samples per frame on the deferred route, 68 us instead of 61) */
 #endif
 #define FUSE_NB (FUSE_LCAP / FUSE_BSLOTS)
+/* A tile whose voxels fit uses only the first FUSE_LCAP_SMALL entries (512 buckets: the bucket index is a mask, and the flush
+ * has a slot less per lane to look at); the full table is for far tiles, which would otherwise be walked in two bands */
+#define FUSE_LCAP_SMALL 2048
+#define FUSE_DUAL (FUSE_LCAP == 2560 && FUSE_BSLOTS == 4)
 #define FUSE_LKEY_EMPTY 0xFFFFFFFFu      /* LDS keys are 32-bit: voxel coordinates relative to the tile origin, 10 bits each */
 #define FUSE_LKEY_DEFER 0x80000000u      /* flush: the entry goes to the deferred list, low 31 bits = voxel record index */
 #define FUSE_LPROBE (48 / FUSE_BSLOTS)   /* buckets probed before a sample takes the deferred route */
@@ -586,6 +593,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     unsigned int* my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
     /* every lane derives the tile-wide decisions from the four entries (same result everywhere) */
     int n_pass;
+    int big = 0;                                                    /* the tile (each of its bands) uses the full LDS table */
     int ox, oy, oz;
     bool range_ok;
     {
@@ -625,6 +633,8 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         if (GSDF_EXPERIMENT(a.debug, 256)) n_pass = 1;
         if (GSDF_EXPERIMENT(a.debug, 512)) n_pass = 4;
         if (!(n_valid > 0.f)) n_pass = 1;
+        big = FUSE_DUAL ? (est > 0.8f * FUSE_LCAP_SMALL * (float)n_pass ? 1 : 0) : 0;
+        big = __builtin_amdgcn_readfirstlane(big);
         n_pass = __builtin_amdgcn_readfirstlane(n_pass);
         /* origin of the tile-local voxel coordinates: the world bounding box of the tile's frustum chunk
          * (4 corner rays x the two ends of the sampled depth range) minus a margin; a sample whose voxel is not
@@ -685,6 +695,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
          * through packed (2 x f32) instructions, the clamp is one v_med3, keys / hash / LDS addresses use shift-adds and
          * 24-bit multiply-adds (v_mul_lo_u32 is quarter rate), the weight goes to fixed point without the double trick. */
         const gsdf_f2 Rxy2 = { Rxy.x, Rxy.y }, t2 = { t[0], t[1] }, Rz2 = { R[2], R[5] }, Rn2 = { Rn.x, Rn.y };
+        const uint32_t nb_used = (FUSE_DUAL && !big) ? (uint32_t)(FUSE_LCAP_SMALL / FUSE_BSLOTS) : (uint32_t)FUSE_NB;   /* buckets of this tile's table */
         float kf = (float)k_lo;                                       /* small integers: exact */
         for (int c0 = 0; c0 < nk; ++c0, kf += 1.f) {
             /* 1. the sample */
@@ -715,9 +726,14 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
              * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
              * overflow, and the distinct voxels of one wave instruction never compete for a bucket: counted on
              * tiles of the bench stream, 1.004 probes per sample.  (The HBM table keeps the full 64-bit finaliser.) */
-            static_assert((FUSE_BSLOTS == 2 && FUSE_NB == 1024) || (FUSE_BSLOTS == 4 && (FUSE_NB == 512 || FUSE_NB == 480)), "lattice constants exist for 1024 x 2, 512 x 4 and 480 x 4");
+            static_assert((FUSE_BSLOTS == 2 && FUSE_NB == 1024) || (FUSE_BSLOTS == 4 && (FUSE_NB == 512 || FUSE_NB == 480 || FUSE_NB == 640)), "lattice constants exist for 1024 x 2, 512 x 4, 480 x 4 and 640 x 4");
             uint32_t bk;
             if (FUSE_BSLOTS == 2) bk = gsdf_mad_u24(lz3, 75u, gsdf_mad_u24(ly3, 86u, lx3)) & 1023u;
+            else if (FUSE_NB == 640 && (big || !FUSE_DUAL)) {          /* x + 253 y + 541 z (mod 640): min distance 9.3; 1.000 probes per sample on the densest tiles */
+                const uint32_t hx = gsdf_mad_u24(lz3, 541u, gsdf_mad_u24(ly3, 253u, lx3));         /* < 2^20 for local keys */
+                bk = hx - 640u * __umulhi(hx, 6710887u);                /* exact for hx < 2^21 */
+                bk = bk < 640u ? bk : 0u;                               /* keys outside the local range: any bucket, never used */
+            }
             else if (FUSE_NB == 480) {                                 /* x + 313 y + 195 z (mod 480): min distance 8.1; 1.12 probes per sample on the densest tiles */
                 const uint32_t hx = gsdf_mad_u24(lz3, 195u, gsdf_mad_u24(ly3, 313u, lx3));         /* < 2^20 for local keys */
                 bk = hx - 480u * __umulhi(hx, 8947849u);                /* exact for hx < 2^20 */
@@ -754,7 +770,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
                 const int at = (int)((uint32_t)FUSE_BSLOTS * bk) + pos;
                 const bool try_cas = pend && !hit && pos >= 0;
                 if (pend && hit) { slot = at; pend = false; }
-                if (pend && pos < 0) bk = bk + 1u == (uint32_t)FUSE_NB ? 0u : bk + 1u;                       /* bucket full of others */
+                if (pend && pos < 0) bk = bk + 1u == nb_used ? 0u : bk + 1u;                                 /* bucket full of others */
                 if (GSDF_EXPERIMENT(a.debug, 128) && __any(pend && pos < 0)) ++dbg_full;
                 if (try_cas) {
                     const uint32_t old = atomicCAS(&L.key[at], FUSE_LKEY_EMPTY, key);
@@ -828,7 +844,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         for (int e = 0; e < NE; ++e) {
             /* back from the tile-local key to the packed voxel key of the HBM map */
             const int i = tid + FUSE_THREADS * e;
-            const uint32_t lk = i < FUSE_LCAP ? L.key[i] : FUSE_LKEY_EMPTY;
+            const uint32_t lk = (i < FUSE_LCAP && (big || !FUSE_DUAL || i < FUSE_LCAP_SMALL)) ? L.key[i] : FUSE_LKEY_EMPTY;
             const unsigned long long ek = gsdf_key_pack(ox + (int)(lk & 1023u), oy + (int)((lk >> 10) & 1023u), oz + (int)(lk >> 20));
             bkey[e] = gsdf_block_key(ek);
             home[e] = gsdf_hash(bkey[e]) & a.tab.block_mask;
@@ -896,8 +912,11 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
                 asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ra[e]) : "v"(pe) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=v"(rb[e]) : "v"(pe) : "memory");
             }
-            static_assert(NE >= 2 && NE <= 4, "the wait statement names NE x 2 destination registers");
-            if constexpr (NE == 4)
+            static_assert(NE >= 2 && NE <= 5, "the wait statement names NE x 2 destination registers");
+            if constexpr (NE == 5)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[2]), "+v"(rb[2]), "+v"(ra[3]), "+v"(rb[3]), "+v"(ra[4]), "+v"(rb[4]) :: "memory");
+            else if constexpr (NE == 4)
                 asm volatile("s_waitcnt vmcnt(0)"
                              : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]), "+v"(ra[2]), "+v"(rb[2]), "+v"(ra[3]), "+v"(rb[3]) :: "memory");
             else if constexpr (NE == 3)
