@@ -72,6 +72,18 @@ int require_frame(gsdf_ctx* c) {
     return GSDF_OK;
 }
 
+/* Which size of the fusion kernel's LDS table (gsdf_kernels.hip, FUSE_LCAP): the larger one while many tiles did not fit the
+ * small one lately (far geometry).  The count comes from a pinned word the last workgroup of every fusion writes; it lags by a
+ * launch or two -- a hint, never a condition for correctness (either kernel fuses any tile). */
+static int fuse_far_table(const gsdf_ctx* c) {
+#ifdef GSDF_EXPERIMENTS
+    if (c->debug & 1024) return 1;                         /* tests: pin the larger table */
+    if (c->debug & 2048) return 0;
+#endif
+    if (c->far_table >= 0) return c->far_table;
+    return c->progress && c->progress[3] * 16u > (unsigned int)c->fuse_blocks ? 1 : 0;
+}
+
 /* normals_done: the frame's normals were computed beside its first tracker pass (enqueue_track) */
 int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done) {
     const size_t N = (size_t)c->W * c->H;
@@ -94,7 +106,10 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
                          c->deferred_cap, c->fuse_tag, c->tile_flags, c->tile_order, c->frame_log, c->frame_log_cap, c->vis, c->vis_words,
                          c->debug & 0xFFFF, c->fuse_ticket,
                          /* long deferred lists lately (the note lags by a launch or two: a hint, not a condition) */
-                         c->progress && c->progress[2] > 8192u ? 1 : 0, c->progress ? c->progress_dev + 2 : nullptr);
+                         c->progress && c->progress[2] > 8192u ? 1 : 0, c->progress ? c->progress_dev + 2 : nullptr,
+                         /* many tiles did not fit the small LDS table lately (far geometry): the kernel with the larger one.
+                          * Like the note above a hint that lags by a launch or two, never a condition for correctness. */
+                         fuse_far_table(c));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
@@ -202,7 +217,8 @@ const char* gsdf_last_error(void) { return g_gsdf_err.c_str(); }
 #ifdef GSDF_EXPERIMENTS
 /* Test / measurement build only (libgsdf_test.so, make EXPERIMENTS=1); not part of include/gsdf.h and absent from the
  * production library.  Per context.  Bits 0-15 go to k_fuse: 4 every tile defers, 256 single band, 512 four bands,
- * 8192 every hand-off wait expires at once, 1/2/16/32/128/4096 ablation switches of tools/; bits 16+ go to the tracker. */
+ * 8192 every hand-off wait expires at once, 1024 / 2048 pin the larger / smaller LDS table, 1/2/16/32/64/128/4096 measurement
+ * switches of tools/; bits 16+ go to the tracker. */
 #define GSDF_TRACE_WG 8192
 #define GSDF_TRACE_COLS 16
 int gsdf_debug_flags(gsdf_ctx* c, int flags) {
@@ -284,6 +300,7 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         if (env) c->adaptive = atoi(env);
         if ((env = getenv("GSDF_FIRST_BATCH")) && atoi(env) >= 2) c->first_batch = atoi(env);
         if ((env = getenv("GSDF_NEXT_BATCH")) && atoi(env) >= 1) c->next_batch = atoi(env);
+        if ((env = getenv("GSDF_FAR_TABLE"))) c->far_table = atoi(env);       /* experiments: 0 / 1 pin the fusion kernel's table size */
     }
     int rc = gsdf_reset(c);
     if (rc != GSDF_OK) { gsdf_destroy(c); return rc; }

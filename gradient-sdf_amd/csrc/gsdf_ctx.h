@@ -75,6 +75,7 @@ struct gsdf_ctx {
     volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */
     unsigned int* progress_dev = nullptr;
     int adaptive = 1;                              /* issue tracker passes in batches, following the device (see enqueue_track) */
+    int far_table = -1;                            /* fusion kernel's LDS table: -1 chosen per launch from the previous fusions, 0 / 1 pinned */
     int first_batch = 5, next_batch = 4;           /* launches per batch: 5 cover the usual <= 4 passes + their last head */
     unsigned long long* trace = nullptr;           /* test build: per-workgroup time stamps of k_fuse (gsdf_debug_flags & 64) */
     int debug = 0;                                 /* path-forcing / measurement switches (gsdf_debug_flags; test build only) */

@@ -42,6 +42,7 @@ struct gsdf_dev_state {
     int passes;
     int max_passes;
     unsigned int fuse_timeouts;   /* fusion tiles whose bounded wait for a neighbour expired (they deferred instead) */
+    unsigned int far_tiles;       /* tiles of the running fusion whose voxels do not fit the small LDS table in one band (reset by its last workgroup) */
     unsigned int last_deferred;   /* length of the deferred list of the last fusion launch */
     float last_hits;
     float conv_sq;
@@ -97,7 +98,8 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       int debug /* path-forcing / measurement switches, honoured by -DGSDF_EXPERIMENTS builds only */,
                       unsigned int* ticket /* device word, zeroed once: arrivals of finished workgroups */,
                       int resolve_follows /* also queue k_fuse_resolve (long deferred lists) */,
-                      unsigned int* host_note /* nullable pinned host word: receives the length of the deferred list */);
+                      unsigned int* host_note /* nullable, 2 pinned host words: length of the deferred list, tiles too big for the small LDS table */,
+                      int far_table /* use the kernel with the larger LDS table */);
 int  gsdf_fuse_grid_blocks(int W, int H);
 void gsdf_fuse_tile_order(int W, int H, uint32_t* order_host /* [gsdf_fuse_grid_blocks] */);
 /* per-launch parameters of one Gauss-Newton pass (RigidOptimizer.h:57-62) */

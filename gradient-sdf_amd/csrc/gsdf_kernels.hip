@@ -279,12 +279,15 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #define FUSE_ZSPLIT 2                    /* slices of the ray walk: a tile is walked by 4 waves (8x8 pixels each) x FUSE_ZSPLIT */
 #endif
 #define FUSE_THREADS (256 * FUSE_ZSPLIT)
-#ifndef FUSE_LCAP
-#define FUSE_LCAP 2048                   /* LDS table entries: 512 buckets of 4 (57 KB with the accumulators).  -DFUSE_LCAP=2560 (640 buckets,
-                                            72 KB, still two workgroups per CU) keeps far tiles (2.5-3 m at 640x480 / 1 cm) in one band: fusions
-                                            of frames with far geometry 68 -> 63 us, near scenes 62 -> 63 us (measured; the bench stream's
-                                            driver window is a near scene) */
-#endif
+/* LDS table entries.  The kernel exists in two sizes (template parameter LCAP, FUSE_LCAP below is that parameter):
+ *   2048  512 buckets of 4, 57 KB with the accumulators: near scenes;
+ *   2560  640 buckets, 72 KB (still two workgroups per CU): keeps far tiles (2.5-3 m at 640x480 / 1 cm), which the small
+ *         table has to walk in two bands, in one; near tiles use its first 2048 entries.  Fusions of frames with far
+ *         geometry 68 -> 63 us, of near scenes 62 -> 63 us (the bigger table clear competes with the CU's other walk).
+ * The host picks per launch from what the previous fusions reported (tiles that did not fit the small table). */
+#define FUSE_LCAP LCAP
+#define FUSE_LCAP_NEAR 2048
+#define FUSE_LCAP_FAR 2560
 #ifndef FUSE_BSLOTS
 #define FUSE_BSLOTS 4                    /* keys per bucket of the LDS table = one ds_read_b128 per probe (2 per bucket: half the read and
                                             compare work, 1.03 probes per sample on typical tiles -- but dense tiles then cluster: long probe
@@ -366,6 +369,7 @@ struct fuse_args {
 };
 #define FUSE_RESOLVE_INLINE 8192u       /* deferred entries the last workgroup adds itself even when a resolve launch follows */
 
+template <int LCAP>
 struct fuse_lds {
     uint32_t key[FUSE_LCAP] __attribute__((aligned(16)));
     unsigned long long acc[3][FUSE_LCAP] __attribute__((aligned(16)));  /* see above: s | w + gz | gx + gy */
@@ -440,7 +444,8 @@ __device__ __forceinline__ void vis_mark(const fuse_args& a, const gsdf_payload*
     atomicOr(&a.vis[slot * a.vis_words + (frame >> 5)], 1u << (frame & 31));
 }
 
-__device__ __forceinline__ void fuse_lds_clear(fuse_lds& L, int tid) {
+template <int LCAP>
+__device__ __forceinline__ void fuse_lds_clear(fuse_lds<LCAP>& L, int tid) {
     gsdf_u32x4* k4 = reinterpret_cast<gsdf_u32x4*>(L.key);
     gsdf_u32x4* a4 = reinterpret_cast<gsdf_u32x4*>(L.acc);
     for (int i = tid; i < FUSE_LCAP / 4; i += FUSE_THREADS) k4[i] = gsdf_u32x4{ FUSE_LKEY_EMPTY, FUSE_LKEY_EMPTY, FUSE_LKEY_EMPTY, FUSE_LKEY_EMPTY };
@@ -460,8 +465,9 @@ __device__ __forceinline__ void fuse_log_row(const fuse_args& a) {
     st->log_rows = r + 1;
 }
 
+template <int LCAP>
 __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
-    __shared__ fuse_lds L;
+    __shared__ fuse_lds<LCAP> L;
     const int tid = threadIdx.x;
     /* main_scan_3d.cpp:261: if (conv) update.  The launch may have been queued before optimize() ended (the host
      * issues it behind every batch of passes): it runs only once the pose iteration is done AND converged; the
@@ -635,6 +641,8 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         if (!(n_valid > 0.f)) n_pass = 1;
         big = FUSE_DUAL ? (est > 0.8f * FUSE_LCAP_SMALL * (float)n_pass ? 1 : 0) : 0;
         big = __builtin_amdgcn_readfirstlane(big);
+        /* tiles the small table cannot hold in one band: what the host chooses the next launches' table size by */
+        if (tid == 0 && est > 0.8f * FUSE_LCAP_SMALL) atomicAdd(&a.st->far_tiles, 1u);
         n_pass = __builtin_amdgcn_readfirstlane(n_pass);
         /* origin of the tile-local voxel coordinates: the world bounding box of the tile's frustum chunk
          * (4 corner rays x the two ends of the sampled depth range) minus a margin; a sample whose voxel is not
@@ -1038,7 +1046,12 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         if (mine) { a.st->n_deferred += n; __hip_atomic_store(a.deferred_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         a.st->last_deferred = n;
         /* the host decides by it, without waiting, whether the next launches get a k_fuse_resolve behind them */
-        if (a.host_note) __hip_atomic_store(a.host_note, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.host_note) {
+            __hip_atomic_store(a.host_note, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.host_note + 1, __hip_atomic_load(&a.st->far_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __hip_atomic_store(&a.st->far_tiles, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.use_dev_pose) fuse_log_row(a);
     }
@@ -1070,7 +1083,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
                       unsigned int tag, unsigned int* tile_flags, const uint32_t* tile_order, float* log_rows,
                       long long max_rows, uint32_t* vis, int vis_words, int debug, unsigned int* ticket, int resolve_follows,
-                      unsigned int* host_note) {
+                      unsigned int* host_note, int far_table) {
     fuse_args a;
     a.host_note = host_note;
     a.ticket = ticket; a.log_rows = use_dev_pose ? log_rows : nullptr; a.max_rows = max_rows; a.resolve_follows = resolve_follows;
@@ -1083,7 +1096,8 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     gsdf_dev_state* gate = use_dev_pose ? st : nullptr;
     a.tile_flags = tile_flags; a.ntx = ntx; a.nty = nty; a.tile_order = tile_order;
     const int n = ntx * nty;
-    hipLaunchKernelGGL(k_fuse, dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(debug, 4096) ? 81920 : 0, s, a);   /* experiment: 1 workgroup per CU */
+    if (far_table) hipLaunchKernelGGL(k_fuse<FUSE_LCAP_FAR>, dim3(n), dim3(FUSE_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(k_fuse<FUSE_LCAP_NEAR>, dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(debug, 4096) ? 81920 : 0, s, a);   /* experiment: 1 workgroup per CU */
     if (resolve_follows)
         hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st);
 }

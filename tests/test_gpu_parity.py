@@ -71,7 +71,10 @@ def test_fusion_keys_bit_exact(pkg, O, kind, W, H, vs, trunc):
                                         (512, "every tile walked as 4 row bands (far-tile path)"),
                                         (256, "single band only (far tiles overflow the LDS table into the deferred list)"),
                                         (512 + 4, "4 bands, deferred"),
-                                        (8192, "every hand-off wait expires at once (timed-out tiles defer)")])
+                                        (8192, "every hand-off wait expires at once (timed-out tiles defer)"),
+                                        (1024, "the kernel with the larger LDS table (far scenes)"),
+                                        (1024 + 512, "larger table, 4 bands"),
+                                        (1024 + 4, "larger table, every tile defers")])
 def test_fusion_forced_paths_match_oracle(pkg, O, flags, name):
     """The flush has a fast path (ordered tiles, plain read-modify-write handed from tile to tile) and
     fallbacks chosen per tile from its depth; force each of them on the same input.  The switches exist only
