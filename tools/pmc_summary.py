@@ -15,7 +15,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for root in args:
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"].split("(")[0][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")[:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
     if not (k.startswith("k_fuse") or k.startswith("k_track") or k.startswith("k_normals")):
@@ -32,13 +32,16 @@ if as_json is None:
         for c, (m, n, nt) in d.items():
             print("   %-28s mean %16.1f  (executed launches: %d of %d)" % (c, m, n, nt))
 else:
-    kf = res.get("k_fuse", {})
+    # the fusion kernel exists in two table sizes (k_fuse<2048>, k_fuse<2560>): the one with the most executed launches
+    fuse = sorted((k for k in res if k.startswith("k_fuse")), key=lambda k: -res[k].get("FETCH_SIZE", (0, 0, 0))[1])
+    kf = res[fuse[0]] if fuse else {}
     fetch_kb = kf.get("FETCH_SIZE", (0, 0, 0))[0]
     write_kb = kf.get("WRITE_SIZE", (0, 0, 0))[0]
     out = {"source": "profiles/<tag>_pmc_counters.txt", "command": as_json,
            "unit_note": "FETCH_SIZE / WRITE_SIZE in KB as reported by rocprofv3 (TCC_EA0_RDREQ / WRREQ based); on gfx950 FETCH_SIZE "
                         "reports half the bytes of wide coalesced streams and is uncalibrated for the scattered 16-byte accesses of this "
                         "kernel (MI355X_MICROARCH.md, HBM section): the figure is an estimate, ratios between kernel versions are exact",
+           "kernel": fuse[0] if fuse else None,
            "k_fuse": {"FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
                       "TCC_HIT": kf.get("TCC_HIT_sum", (0,))[0], "TCC_MISS": kf.get("TCC_MISS_sum", (0,))[0],
                       "TCC_ATOMIC": kf.get("TCC_ATOMIC_sum", (0,))[0],

@@ -6,7 +6,7 @@ if not files:
     sys.exit("no kernel_trace.csv under " + root)
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(files[0])):
-    d[r["Kernel_Name"].split("(")[0][:48]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    d[r["Kernel_Name"].split("(")[0].replace("void ", "")[:48]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("%-50s %6s %8s %8s %8s %8s %10s" % ("kernel", "n", "min", "med", "p90", "max", "sum_us"))
 for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
     v.sort()

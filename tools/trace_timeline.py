@@ -10,7 +10,7 @@ dump = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 t_origin = int(rows[0]["Start_Timestamp"]) if rows else 0
 for ri, r in enumerate(rows):
-    name = r["Kernel_Name"].split("(")[0][:24]
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:24]
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     grid = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
     gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
