@@ -288,6 +288,9 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #define FUSE_LCAP LCAP
 #define FUSE_LCAP_NEAR 2048
 #define FUSE_LCAP_FAR 2560
+#ifndef FUSE_POLL_SLEEP
+#define FUSE_POLL_SLEEP 8                  /* x 64 cycles between two looks at the neighbours' flags */
+#endif
 #ifndef FUSE_BSLOTS
 #define FUSE_BSLOTS 4                    /* keys per bucket of the LDS table = one ds_read_b128 per probe (2 per bucket: half the read and
                                             compare work, 1.03 probes per sample on typical tiles -- but dense tiles then cluster: long probe
@@ -882,7 +885,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             for (;;) {
                 if (!ok) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag;
                 if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(FUSE_POLL_SLEEP);
                 /* 2 ms at 100 MHz: give up, defer instead (the test build can make every wait expire at once) */
                 if (wall_clock64() - t0 > 200000ull || GSDF_EXPERIMENT(a.debug, 8192)) {
                     if (lane == 0) { L.ordered = 0u; atomicAdd(&a.st->fuse_timeouts, 1u); }
