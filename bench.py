@@ -7,16 +7,26 @@ converged (main_scan_3d.cpp:255-266), enqueued through the C-ABI entry gsdf_trac
 with the frame already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]:
 TUM fr1/xyz-format synthetic stream, 640x480, 1 cm voxels, trunc = 10 voxels, capacity 2^22.
 
-Multi-GPU: tracking makes frame i depend on the map of all frames < i, so the fused+tracked path
-does not shard ("replicas only"): --gpus N runs N independent streams (seed = rank),
-one process per GPU, and `value` = all frames of all ranks / max-over-ranks time ("weak").
+`python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the environment bench.py starts the N rank
+processes itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set); under torch.distributed.run it is one of the
+ranks.  Either way a rank asserts WORLD_SIZE == --gpus.
+
+Multi-GPU, two flavours in one run:
+  * fused+tracked (`value`): tracking makes frame i depend on the map of all frames < i, so the path does not shard --
+    N independent replica streams (seed = rank), no data-path collective, `value` = frames of all ranks / max-over-ranks time;
+  * `config.sharded` (BASELINE configs[3], the flavour that DOES shard): GT-pose fusion of contiguous frame shards of ONE
+    sphere-orbit stream (main_scan_3d.cpp:250-254), `--c4-frames` per rank, then ONE gsdf_merge_allreduce (RCCL all-reduce of
+    the per-voxel sums over the union of blocks) on a communicator created outside the timed region, then the mesh on rank 0.
 
 Output: ONE JSON line on rank 0 (contract in the task statement) including
+  value         median of `--repeats` timed windows (each: reset, frame 0, W warm-up steps, barrier, K timed steps, barrier);
+                every run is listed in config.value_runs
   roofline      dominant kernel (k_fuse): algorithmic bytes per launch / mean HIP-event duration, measured live in a replay
                 of the same frames; `traffic` (HBM bytes per launch from rocprofv3 PMC passes over THIS command, committed
-                under profiles/ and named in `traffic_source`); `tracker`: the same for k_track_pass
-  cpu_baseline  the CPU oracle ("port" of the reference's serial path) timed on a bounded sample, plus its OMP-structured
-                variants (4 threads as in the reference, and all host cores)
+                under profiles/ and named in `traffic_source`); `tracker` and `raycast`: the same for k_track_pass / k_raycast
+  cpu_baseline  the CPU oracle ("port" of the reference's serial path) timed on the SAME frames as `value` (the warm-up frames
+                are fused untimed first), plus its OMP-structured variants (4 threads as in the reference, and all host cores);
+                rank 0 at N = 1 only
 
 Two windows are worth knowing: the driver's `--steps 20 --warmup 5` covers frames 6..25 of the stream, which all
 converge in 3-4 Gauss-Newton passes; the default 200 steps run into the stretch where the reference's tracker does not
@@ -25,6 +35,8 @@ converge (25 passes, frame not fused; tests/test_gpu_parity.py::test_tracked_ben
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,31 +48,147 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md), ~6300 achievable
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed windows; value = their median")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--voxel-size", type=float, default=0.01)
     ap.add_argument("--trunc", type=float, default=10.0)
     ap.add_argument("--hash-capacity-log2", type=int, default=22)
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="timed frames of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--c4-frames", type=int, default=250,
+                    help="frames PER RANK of the sharded GT-pose flavour (8 ranks x 250 = the 2000 frames of BASELINE configs[3]); 0 = skip")
+    ap.add_argument("--raycast-reps", type=int, default=10, help="raycasts of the bench map timed for roofline.raycast (0 = skip)")
+    ap.add_argument("--only-main", action="store_true", help="fused+tracked windows and the roofline replays only (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--single-device", action="store_true",
-                    help="dry run of the N>1 code path on a 1-GPU box: every rank uses device 0")
-    args = ap.parse_args()
+                    help="dry run of the N>1 code path on a 1-GPU box: every rank uses device 0, the exchange goes through "
+                         "gsdf_merge_allreduce_with over torch.distributed (RCCL refuses two ranks on one device)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch path only (CPU test of --gpus N): the ranks rendezvous over gloo, barrier, max-reduce, rank 0 prints a stub line")
+    ap.add_argument("--rank-timeout", type=float, default=1500.0, help="seconds after which the self-started ranks are stopped")
+    return ap.parse_args()
 
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start N rank processes of this script (one per GPU) and wait for them.  The first rank that
+    fails takes the others with it (exact pids), so a broken rank cannot leave its peers inside a collective forever."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    deadline = time.time() + args.rank_timeout
+    worst = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = worst or rc
+                for q in live:                                  # exact pids, never a pattern
+                    q.terminate()
+        if live and time.time() > deadline:
+            print("bench.py: ranks still running after %.0f s, stopping them" % args.rank_timeout, file=sys.stderr)
+            for q in live:
+                q.kill()
+            worst = worst or 124
+        time.sleep(0.05)
+    return worst
+
+
+def render_frames(kind, W, H, indices, seed, **kw):
+    """Synthetic frames (numpy renderer, ~50 ms each) on a few forked workers -- called before torch / HIP are touched."""
+    import __graft_entry__ as graft
+    pkg = graft.package()
+    seq = pkg.synth.Sequence(kind, W, H, seed=seed, **kw)
+    indices = list(indices)
+    workers = max(1, min(8, (os.cpu_count() or 8) // max(1, int(os.environ.get("WORLD_SIZE", "1"))), len(indices)))
+    if workers > 1 and "torch" not in sys.modules:
+        try:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(workers) as pool:
+                return seq, pool.map(seq.frame, indices, chunksize=max(1, len(indices) // (4 * workers)))
+        except Exception:                                       # noqa: BLE001 -- any pool trouble: render serially
+            pass
+    return seq, [seq.frame(i) for i in indices]
+
+
+def quat_to_R(q):
+    x, y, z, w = [np.float32(v) for v in q]
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    return np.array([[1 - (ty * y + tz * z), ty * x - tz * w, tz * x + ty * w],
+                     [ty * x + tz * w, 1 - (tx * x + tz * z), tz * y - tx * w],
+                     [tz * x - ty * w, tz * y + tx * w, 1 - (tx * x + ty * y)]], np.float32)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    if args.single_device:
+        local_rank = 0
+    if args.dry_run:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": float(t.item()), "local_rank": local_rank}))
+        return
+    if args.only_main:
+        args.c4_frames = 0
+        args.raycast_reps = 0
+        args.cpu_frames = 0
+
+    W, H = args.width, args.height
+    K, Wm = args.steps, args.warmup
+    n_frames = 1 + Wm + K
+    vs = np.float32(args.voxel_size)
+    T = np.float32(args.trunc) * vs
+    # ---- synthetic inputs first (forked render workers must not inherit a HIP runtime) ---------------------------
+    seq, frames = render_frames("tum", W, H, range(n_frames), seed=rank, n_frames=n_frames)
+    c4 = None
+    if args.c4_frames > 0:
+        F = args.c4_frames
+        total = F * world
+        c4_seq, c4_frames = render_frames("spheres", W, H, range(rank * F, (rank + 1) * F), seed=0, n_frames=total,
+                                          step_deg=360.0 * 4 / 2000)       # 2000 frames = 4 orbits (tools/run_c4.py)
+        c4 = {"seq": c4_seq, "frames": c4_frames, "F": F, "total": total}
 
     # torch first: libgsdf binds to the HIP runtime already in the process (gradient-sdf_amd/binding.py)
     import torch
     import torch.distributed as dist
-    if args.single_device:
-        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -68,17 +196,10 @@ def main():
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
 
     import __graft_entry__ as graft
     pkg = graft.package()
-
-    W, H = args.width, args.height
-    K, Wm = args.steps, args.warmup
-    n_frames = 1 + Wm + K
-    seq = pkg.synth.Sequence("tum", W, H, n_frames=n_frames, seed=rank)
-    vs = np.float32(args.voxel_size)
-    T = np.float32(args.trunc) * vs
-    frames = [seq.frame(i) for i in range(n_frames)]
 
     g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=args.hash_capacity_log2, device=local_rank)
     dev = [g.upload(f[0]) for f in frames]          # inputs resident in HBM before the timed region
@@ -86,43 +207,45 @@ def main():
     def q_from_R(R):
         return pkg.synth.R_to_quat_np(R).astype(np.float32)
 
-    def quat_to_R(q):
-        x, y, z, w = [np.float32(v) for v in q]
-        tx, ty, tz = 2 * x, 2 * y, 2 * z
-        return np.array([[1 - (ty * y + tz * z), ty * x - tz * w, tz * x + ty * w],
-                         [ty * x + tz * w, 1 - (tx * x + tz * z), tz * y - tx * w],
-                         [tz * x - ty * w, tz * y + tx * w, 1 - (tx * x + ty * y)]], np.float32)
-
-    def sync_all():
-        g.sync()
+    def sync_all(ctx=None):
+        (ctx or g).sync()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    def run_stream(first, last):
-        for i in range(first, last):
-            g.track_and_fuse_dev(dev[i])
+    def max_over_ranks(values):
+        if world == 1:
+            return [float(v) for v in values]
+        tt = torch.tensor(list(values), dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return [float(v) for v in tt.tolist()]
 
-    # frame 0: setup at the ground-truth pose (main_scan_3d.cpp:242), then W untimed warm-up steps
     d0, R0, t0 = frames[0]
     p0 = np.concatenate([t0, q_from_R(R0)]).astype(np.float32)
-    g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
-    g.set_pose(p0)
-    run_stream(1, 1 + Wm)
-    sync_all()
-    st_w = g.stats()
 
-    # ---- timed region: exactly K steps --------------------------------------------------------
-    sync_all()
-    t_start = time.perf_counter()
-    run_stream(1 + Wm, 1 + Wm + K)
-    sync_all()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def start_stream():
+        """frame 0: setup at the ground-truth pose (main_scan_3d.cpp:242), then W untimed warm-up steps"""
+        g.reset()
+        g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
+        g.set_pose(p0)
+        for i in range(1, 1 + Wm):
+            g.track_and_fuse_dev(dev[i])
+
+    # ---- timed region: exactly K steps, `repeats` times ----------------------------------------------------------
+    runs = []
+    st_w = None
+    for rep in range(max(1, args.repeats)):
+        start_stream()
+        sync_all()
+        st_w = g.stats()
+        sync_all()
+        t_start = time.perf_counter()
+        for i in range(1 + Wm, 1 + Wm + K):
+            g.track_and_fuse_dev(dev[i])
+        sync_all()
+        runs.append(max_over_ranks([time.perf_counter() - t_start])[0])
+    elapsed = float(np.median(runs))
 
     st = g.stats()
     log = g.frame_log()
@@ -139,6 +262,7 @@ def main():
     # recording timing events switches the HIP queue to a slower, profiled dispatch for the rest of the process.
     # Two rounds, the second one counts: the first long run of back-to-back launches in a process makes the HIP runtime grow
     # its launch resources once (one launch call of ~40 ms).
+    fused_fps = 0.0
     for rnd in range(2):
         g.reset()
         sync_all()
@@ -149,7 +273,7 @@ def main():
                 g.sync()             # hundreds of launches queued without a sync make the HIP runtime throttle the host
         t_enq = time.perf_counter() - tf
         sync_all()
-        fused_fps = K / (time.perf_counter() - tf)
+        fused_fps = K / max_over_ranks([time.perf_counter() - tf])[0]
     if os.environ.get("GSDF_BENCH_DEBUG"):
         print("fused-only: enqueue %.1f us/frame, total %.1f us/frame" % (t_enq / K * 1e6, 1e6 / fused_fps), file=sys.stderr)
 
@@ -180,11 +304,7 @@ def main():
 
     # ---- the tracker's roofline entry: replay the tracked stream with HIP events around every k_track_pass launch ---
     # one pass moves 4 N_pix (depth) + 32 N_hit (one voxel record per hit) bytes
-    g.reset()
-    g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
-    g.set_pose(p0)
-    for i in range(1, 1 + Wm):
-        g.track_and_fuse_dev(dev[i])
+    start_stream()
     g.sync()
     st_c = g.stats()
     g.profile(1)
@@ -200,50 +320,96 @@ def main():
     trk_ms = prof_t["track_pass"]["ms"]
     trk_achieved = trk_bytes / (trk_ms * 1e-3) / 1e9 if trk_ms > 0 else 0.0
 
-    g.close()
+    # ---- the raycaster's roofline entry: render the bench map (all 1 + W + K frames tracked and fused) from the last pose ---
+    # bytes per render = 8 per sample the definition evaluates (one block-key probe) + 32 per voxel record read + 16 per pixel
+    # written (depth + normal); samples / records counted on the device (gsdf_raycast_counters)
+    raycast = None
+    if args.raycast_reps > 0:
+        import ctypes
+        N = W * H
+        buf = ctypes.c_void_p()
+        g._chk(g.L.gsdf_dev_alloc(g.h, ctypes.byref(buf), 4 * N * 4))
+        g._dev.append(buf)
+        nrm = ctypes.c_void_p(buf.value + 4 * N)
+        pose_last = g.get_pose()
+        Rl, tl = quat_to_R(pose_last[3:]), pose_last[:3]
+        g.raycast_dev(Rl, tl, buf, nrm)
+        g.sync()
+        g.raycast_counters(reset=True)
+        g.profile(1)
+        for _ in range(args.raycast_reps):
+            g.raycast_dev(Rl, tl, buf, nrm)
+        g.sync()
+        pr = g.profile_read_all()["raycast"]
+        g.profile(0)
+        samples, records = g.raycast_counters(reset=True)
+        rc_us = pr["ms"] * 1e3 / max(pr["launches"], 1)
+        rc_bytes = (8.0 * samples + 32.0 * records) / max(args.raycast_reps, 1) + 16.0 * N
+        depth_r = g.download(buf, (H, W), np.float32)
+        hit = depth_r > 0
+        raycast = {"kernel": "k_raycast", "avg_launch_us": round(rc_us, 2), "launches": int(pr["launches"]),
+                   "algorithmic_bytes_per_launch": round(rc_bytes), "achieved": round(rc_bytes / (rc_us * 1e-6) / 1e9, 1) if rc_us > 0 else 0.0,
+                   "frac": round(rc_bytes / (rc_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rc_us > 0 else 0.0,
+                   "samples_per_launch": int(samples // max(args.raycast_reps, 1)), "records_per_launch": int(records // max(args.raycast_reps, 1)),
+                   "hit_fraction": round(float(hit.mean()), 4),
+                   "median_abs_diff_to_input_depth_mm": round(float(np.median(np.abs(depth_r - frames[-1][0])[hit])) * 1e3, 3) if hit.any() else None}
 
-    # ---- CPU baseline: the oracle (port of the reference's serial path) on a bounded sample --------
+    # device n_upd against the oracle's, on the CPU-sample frames at the oracle's poses (filled in below)
+    def device_n_upd(i, R, t):
+        g.reset()
+        g.update_dev(dev[i], R, t)
+        return g.stats()["n_upd"]
+
+    # ---- CPU baseline: the oracle (port of the reference's serial path) on the frames `value` is timed on ----------
     cpu = None
-    if rank == 0 and args.cpu_frames > 0:
+    n_upd_checked = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
         O = graft.oracle_module()
-        nc = min(args.cpu_frames, n_frames)
+        nc = min(args.cpu_frames, K)
+        first = 1 + Wm                                     # first timed frame of `value`
         o = O.Oracle(vs, T, W, H, seq.K)
-        tc = time.perf_counter()
         o.update(frames[0][0], quat_to_R(p0[3:]), t0)
         pose = p0.copy()
-        for i in range(1, nc):
+        for i in range(1, first):                          # the warm-up frames: tracked and fused, untimed
             conv, pose, _, _, _ = o.track(frames[i][0], pose)
             if conv:
                 o.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3])
-        dt = time.perf_counter() - tc
-        # the reference's OMP-structured variant (critical-section fusion, 4-thread tracker reduction,
-        # MapGradPixelSdfOmp.cpp:82,112 / RigidPointOptimizerOmp.cpp:68-69) on a shorter sample
-        no = min(4, nc)
-        o2 = O.Oracle(vs, T, W, H, seq.K, threads=4)
+        warm_keys, warm_pay = o.export()
+        pose_w = pose.copy()
+        cpu_passes, fused = [], []
         tc = time.perf_counter()
-        o2.update(frames[0][0], quat_to_R(p0[3:]), t0, omp=True)
-        pose = p0.copy()
-        for i in range(1, no):
-            conv, pose, _, _, _ = o2.track(frames[i][0], pose, omp=True)
+        for i in range(first, first + nc):
+            conv, pose, used, _, _ = o.track(frames[i][0], pose)
+            cpu_passes.append(int(used))
             if conv:
-                o2.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3], omp=True)
-        dto = time.perf_counter() - tc
+                nu, _ = o.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3])
+                fused.append((i, O.quat_to_R(pose[3:]).copy(), pose[:3].copy(), int(nu)))
+        dt = time.perf_counter() - tc
+        # N_upd of the roofline comes from the device counter; here it is checked against the oracle's on these frames
+        n_upd_checked = bool(fused) and all(device_n_upd(i, R, t) == nu for i, R, t, nu in fused)
+        # the reference's OMP-structured variant (critical-section fusion, 4-thread tracker reduction,
+        # MapGradPixelSdfOmp.cpp:82,112 / RigidPointOptimizerOmp.cpp:68-69) on a shorter sample, from the same warm map
+        no = min(4, nc)
+
+        def omp_leg(track_threads):
+            o2 = O.Oracle(vs, T, W, H, seq.K, threads=4)
+            o2.set_map(warm_keys, warm_pay)
+            pose = pose_w.copy()
+            tc = time.perf_counter()
+            for i in range(first, first + no):
+                o2.set_threads(track_threads)
+                conv, pose, _, _, _ = o2.track(frames[i][0], pose, omp=True)
+                o2.set_threads(4)
+                if conv:
+                    o2.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3], omp=True)
+            return time.perf_counter() - tc
+        dto = omp_leg(4)
         # ... and with every host core in the tracker's parallel-for.  Only the tracker: the fusion keeps
         # the 4 threads the reference's tracker leaves set (omp_set_num_threads(4), RigidPointOptimizerOmp.cpp:68) -- its
         # `omp critical` (MapGradPixelSdfOmp.cpp:112) serialises the map update whatever the thread count, and with hundreds
         # of threads the contention makes a frame take minutes.
         ncores = os.cpu_count() or 1
-        o3 = O.Oracle(vs, T, W, H, seq.K, threads=4)
-        tc = time.perf_counter()
-        o3.update(frames[0][0], quat_to_R(p0[3:]), t0, omp=True)
-        pose = p0.copy()
-        for i in range(1, no):
-            o3.set_threads(ncores)
-            conv, pose, _, _, _ = o3.track(frames[i][0], pose, omp=True)
-            o3.set_threads(4)
-            if conv:
-                o3.update(frames[i][0], O.quat_to_R(pose[3:]), pose[:3], omp=True)
-        dta = time.perf_counter() - tc
+        dta = omp_leg(ncores)
         model = "unknown"
         try:
             with open("/proc/cpuinfo") as f:
@@ -253,14 +419,25 @@ def main():
                         break
         except OSError:
             pass
-        cpu = {"value": round((nc - 1) / dt, 3) if nc > 1 else 0.0, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "first %d frames of the same stream (1 setup + %d tracked+fused), serial oracle, %s host cores present"
-                         % (nc, nc - 1, os.cpu_count()),
+        cpu = {"value": round(nc / dt, 3) if nc else 0.0, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "frames %d..%d of the same stream = the first %d frames `value` is timed on (frames 0..%d tracked + fused "
+                         "untimed first), serial oracle, %s host cores present" % (first, first + nc - 1, nc, first - 1, os.cpu_count()),
+               "passes_per_frame": cpu_passes, "gpu_passes_per_frame": [int(v) for v in timed[:nc, 8]],
                "cpu_model": model,
-               "omp4_value": round((no - 1) / dto, 3) if no > 1 else 0.0,
-               "omp4_note": "reference's OMP structure (fusion inside omp critical, 4-thread tracker), first %d frames" % no,
-               "omp_all_value": round((no - 1) / dta, 3) if no > 1 else 0.0,
-               "omp_all_note": "the same with %d threads (all host cores) in the tracker's parallel-for, 4 in the fusion, first %d frames" % (ncores, no)}
+               "omp4_value": round(no / dto, 3) if no else 0.0,
+               "omp4_note": "reference's OMP structure (fusion inside omp critical, 4-thread tracker), first %d timed frames" % no,
+               "omp_all_value": round(no / dta, 3) if no else 0.0,
+               "omp_all_note": "the same with %d threads (all host cores) in the tracker's parallel-for, 4 in the fusion, first %d timed frames" % (ncores, no)}
+
+    g.close()
+
+    # ---- the flavour that shards: GT-pose fusion of frame shards + ONE all-reduce of the per-voxel sums (configs[3]) ------
+    sharded = None
+    if c4 is not None:
+        try:
+            sharded = sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, W, H, coll_dev)
+        except Exception as e:                                  # noqa: BLE001 -- the headline line must still be printed
+            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # HBM traffic of one k_fuse launch: PMC counters cannot be read from inside the process, so they come from the committed
     # rocprofv3 --pmc passes over this very command (profiles/pmc_latest.json names file and command); reported only for
@@ -298,10 +475,15 @@ def main():
                 "width": W, "height": H, "voxel_size_m": float(vs), "trunc_voxels": args.trunc,
                 "hash_capacity_log2": args.hash_capacity_log2, "tracker": "25 iters, conv 1e-3, damping 1",
                 "parallelism": "replicas x%d (tracked path does not shard)" % world,
+                "value_is": "median of %d timed windows" % len(runs),
+                "value_runs": [round(total_frames / r, 1) for r in runs],
                 "converged_frames": n_conv, "mean_tracker_passes": round(passes, 2),
                 "max_abs_translation_error_m": round(trans_err, 5), "voxels": voxels,
                 "n_upd_per_frame": round(n_upd_timed / max(n_conv, 1)), "n_hit_per_pass": round(n_hit_timed / max(passes * K, 1)),
+                "n_upd_oracle_checked": n_upd_checked,
                 "fused_only_fps": round(fused_fps * world, 1),
+                "raycast_us": raycast["avg_launch_us"] if raycast else None,
+                "sharded": sharded,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_fuse", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -313,12 +495,126 @@ def main():
                             "algorithmic_bytes": round(trk_bytes), "passes": int(trk_passes),
                             "launches": prof_t["track_pass"]["launches"],
                             "avg_launch_us": round(trk_ms * 1e3 / max(prof_t["track_pass"]["launches"], 1), 2)},
+                "raycast": raycast,
             },
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+    # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which would otherwise be
+    # flushed behind it at exit
     if world > 1:
         dist.destroy_process_group()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                           # noqa: BLE001
+        pass
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+
+
+def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, W, H, coll_dev):
+    """BASELINE configs[3] on N ranks: every rank fuses its contiguous shard of ONE sphere-orbit stream with the ground-truth
+    poses (main_scan_3d.cpp:250-254) into its own map, then ONE exchange -- gsdf_merge_allreduce over an RCCL communicator that
+    exists before the timed region -- after which every rank holds the map of all frames; rank 0 extracts the mesh.
+    Weak scaling: --c4-frames per rank.  Two rounds, the second one is reported (the first one warms RCCL's channels)."""
+    seq, frames, F, total = c4["seq"], c4["frames"], c4["F"], c4["total"]
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=23, device=local_rank)
+    dev = [g.upload(f[0]) for f in frames]
+
+    def barrier():
+        g.sync()
+        if world > 1:
+            dist.barrier()
+
+    def vmax(values):
+        if world == 1:
+            return [float(v) for v in values]
+        tt = torch.tensor(list(values), dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return [float(v) for v in tt.tolist()]
+
+    # ---- transport, outside the timed region ----
+    comm, transport, rccl_ranks = None, None, None
+    use_rccl = not args.single_device and (world == 1 or args.dist_backend == "nccl")
+    if use_rccl:
+        ok = 1.0
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(pkg.binding.rccl_unique_id()), dtype=torch.uint8).clone()
+            if world > 1:
+                idt = idt.cuda()
+                dist.broadcast(idt, src=0)
+            comm = pkg.binding.rccl_comm_init(world, bytes(idt.cpu().numpy().tobytes()), rank, local_rank)
+            rccl_ranks = pkg.binding.rccl_comm_count(comm)
+        except Exception as e:                                   # noqa: BLE001
+            print("bench.py rank %d: RCCL communicator: %s" % (rank, e), file=sys.stderr)
+            ok = 0.0
+        # every rank takes the same route
+        ok = -vmax([-ok])[0] if world > 1 else ok
+        if ok > 0:
+            transport = "rccl (gsdf_merge_allreduce: pack -> ncclAllReduce -> unpack on the context's stream)"
+        else:
+            if comm is not None:
+                pkg.binding.rccl_comm_destroy(comm)
+                comm = None
+            use_rccl = False
+    if not use_rccl:
+        transport = "torch.distributed %s through gsdf_merge_allreduce_with (host staging)" % args.dist_backend
+
+    def ag(send):
+        if world == 1:
+            return send
+        t = torch.from_numpy(send).to(coll_dev)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return torch.cat(out).cpu().numpy()
+
+    def ar(buf):
+        if world == 1:
+            return buf
+        t = torch.from_numpy(buf).to(coll_dev)
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    res = {}
+    for rnd in range(2):
+        g.reset()
+        barrier()
+        t0 = time.perf_counter()
+        for j, (d, f) in enumerate(zip(dev, frames)):
+            g.update_dev(d, f[1], f[2])
+            if j % 32 == 31:
+                g.sync()
+        g.sync()
+        t_fuse = time.perf_counter() - t0
+        own = g.count()
+        barrier()
+        t1 = time.perf_counter()
+        if use_rccl:
+            nb, nbytes = g.merge_allreduce_rccl(comm)
+        else:
+            nb, nbytes = g.merge_allreduce_with(ag, ar, world)
+        g.sync()
+        t_exch = time.perf_counter() - t1
+        t_fuse, t_exch, t_both = vmax([t_fuse, t_exch, t_fuse + t_exch])
+        res = {"frames_per_rank": F, "frames_total": total, "ranks": world, "rccl_ranks": rccl_ranks, "transport": transport,
+               "sharded_fused_fps": round(total / t_fuse, 1), "sharded_fused_fps_incl_exchange": round(total / t_both, 1),
+               "fuse_ms": round(t_fuse * 1e3, 3), "exchange_ms": round(t_exch * 1e3, 3), "exchange_bytes": int(nbytes),
+               "exchange_blocks": int(nb), "voxels_own_shard": int(own)}
+    res["voxels_merged"] = int(g.count())
+    res["frames_counter_after_merge"] = int(g.stats()["frames"])
+    if rank == 0:
+        t2 = time.perf_counter()
+        tris = g.extract_mesh()
+        res["mesh_faces"] = int(len(tris))
+        res["export_ms"] = round((time.perf_counter() - t2) * 1e3, 2)
+    barrier()
+    if comm is not None:
+        pkg.binding.rccl_comm_destroy(comm)
+    g.close()
+    return res
 
 
 if __name__ == "__main__":

@@ -130,7 +130,11 @@ def load(path=None):
         "gsdf_merge_allreduce_with": (C.c_int, [vp, vp, i64p, i64p]),
         "gsdf_rccl_unique_id": (C.c_int, [C.c_char_p]),
         "gsdf_rccl_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.c_int, C.c_int]),
+        "gsdf_rccl_comm_count": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "gsdf_rccl_comm_destroy": (C.c_int, [vp]),
+        "gsdf_raycast_dev": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),
+        "gsdf_raycast_counters": (C.c_int, [vp, i64p, i64p, C.c_int]),
+        "gsdf_profile_read_n": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), i64p]),
         "gsdf_raycast": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]),
         "gsdf_extract_mesh": (C.c_int, [vp, C.c_float, C.POINTER(C.c_int8), fp, C.c_int64, C.POINTER(C.c_int64)]),
         "gsdf_dev_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_int64]),
@@ -164,11 +168,12 @@ ABI_SYMBOLS = [
     "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
-    "gsdf_merge_allreduce", "gsdf_merge_allreduce_with", "gsdf_rccl_unique_id", "gsdf_rccl_comm_init", "gsdf_rccl_comm_destroy",
-    "gsdf_query", "gsdf_get_voxels", "gsdf_raycast", "gsdf_extract_mesh",
+    "gsdf_merge_allreduce", "gsdf_merge_allreduce_with", "gsdf_rccl_unique_id", "gsdf_rccl_comm_init", "gsdf_rccl_comm_count",
+    "gsdf_rccl_comm_destroy",
+    "gsdf_query", "gsdf_get_voxels", "gsdf_raycast", "gsdf_raycast_dev", "gsdf_raycast_counters", "gsdf_extract_mesh",
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_dev_download", "gsdf_timer_start", "gsdf_timer_stop_ms",
     "gsdf_host_alloc", "gsdf_host_free", "gsdf_dev_upload_async", "gsdf_mark", "gsdf_mark_wait", "gsdf_mark_reached",
-    "gsdf_profile", "gsdf_profile_read",
+    "gsdf_profile", "gsdf_profile_read", "gsdf_profile_read_n",
 ]
 
 
@@ -189,6 +194,16 @@ def rccl_comm_init(nranks, unique_id, rank, device):
     if rc != GSDF_OK:
         raise GsdfError(rc, L.gsdf_last_error().decode())
     return comm
+
+
+def rccl_comm_count(comm):
+    """ncclCommCount of the communicator."""
+    L = load()
+    n = C.c_int(0)
+    rc = L.gsdf_rccl_comm_count(comm, C.byref(n))
+    if rc != GSDF_OK:
+        raise GsdfError(rc, L.gsdf_last_error().decode())
+    return n.value
 
 
 def rccl_comm_destroy(comm):
@@ -483,6 +498,19 @@ class GradSdf:
                                       _fp(n) if normals else None))
         return d, n
 
+    def raycast_dev(self, R, t, depth_dev, normals_dev=None, zmin=0.5, zmax=3.5):
+        """gsdf_raycast_dev: enqueue only, output into device buffers (W*H floats, 3*W*H floats or None)."""
+        R = _f32(R).reshape(9)
+        t = _f32(t).reshape(3)
+        self._chk(self.L.gsdf_raycast_dev(self.h, _fp(self.K), _fp(R), _fp(t), self.W, self.H, C.c_float(zmin), C.c_float(zmax),
+                                          depth_dev, normals_dev))
+
+    def raycast_counters(self, reset=False):
+        """(samples the raycasts' definition evaluated, voxel records read) since the last reset."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.gsdf_raycast_counters(self.h, C.byref(a), C.byref(b), int(reset)))
+        return a.value, b.value
+
     def extract_mesh(self, tri_table=None, iso=0.0):
         """GPU marching cubes: float32 [n, 3, 3] triangles in the reference's sweep order
         (tri_table: None = the reference's classic triTable, or int8 [256,16])."""
@@ -516,3 +544,11 @@ class GradSdf:
         self._chk(self.L.gsdf_profile_read(self.h, ms, n))
         names = ("normals", "fusion", "track_pass")
         return {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(3)}
+
+    def profile_read_all(self):
+        """All slots (gsdf_profile_read_n): normals, fusion, track_pass, raycast, track_opt."""
+        names = ("normals", "fusion", "track_pass", "raycast", "track_opt")
+        ms = (C.c_double * len(names))()
+        n = (C.c_int64 * len(names))()
+        self._chk(self.L.gsdf_profile_read_n(self.h, len(names), ms, n))
+        return {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(len(names))}

@@ -15,12 +15,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 static int fail(int code, const std::string& msg) { return gsdf_fail(code, msg); }
@@ -49,7 +51,7 @@ struct prof_scope {
 };
 
 void prof_collect(gsdf_ctx* c) {
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < GSDF_PROF_SLOTS; ++k) {
         for (auto& pr : c->prof_events[k]) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k] += 1; }
@@ -131,15 +133,18 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
 
 /* 1 = optimize() ended, 0 = the head of launch `last` ran and it has not ended, -1 = gave up waiting */
 int follow_progress(gsdf_ctx* c, unsigned int serial, int last) {
-    for (long spin = 0; spin < 200000000L; ++spin) {
+    /* a batch takes ~50 us: spin briefly, then yield the core between looks; bounded by TIME (2 s), not by iterations */
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spin = 0;; ++spin) {
         const unsigned int w = c->progress[0];
         if ((w >> 16) == serial) {
             if (w & 0x8000u) return 1;
             if ((int)(w & 0x7FFFu) >= last) return 0;
         }
-        __builtin_ia32_pause();
+        if (spin < 4096) { __builtin_ia32_pause(); continue; }
+        if ((spin & 63) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) return -1;
+        std::this_thread::yield();
     }
-    return -1;
 }
 
 int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, float damping, bool fuse_after) {
@@ -240,6 +245,13 @@ int gsdf_debug_trace(gsdf_ctx* c, unsigned long long* out, int n_wg) {
     if (hipMemcpy(out, c->trace, (size_t)n_wg * GSDF_TRACE_COLS * 8, hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
     return GSDF_OK;
 }
+/* the raycaster's per-workgroup rows (8 values each, see gsdf_launch_raycast), tools/raycast_bench.py */
+int gsdf_debug_raycast_rows(gsdf_ctx* c, unsigned long long* out, int n_rows) {
+    if (!c || !out || !c->rc_counts || (size_t)n_rows > c->rc_rows) return GSDF_ERR_INVALID;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
+    if (hipMemcpy(out, c->rc_counts, (size_t)n_rows * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
+    return GSDF_OK;
+}
 int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[24]) {
     if (!c || !out) return GSDF_ERR_INVALID;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
@@ -279,6 +291,8 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void**)&c->tab.vox, c->n_slots * sizeof(gsdf_payload))) != hipSuccess ||
         (e = hipMalloc((void**)&c->tab.bkeys, (c->n_slots / GSDF_BLOCK_VOX) * sizeof(unsigned long long))) != hipSuccess ||
+        /* block filter (64 bits per block entry) followed by the cell filter (1 bit per block entry, at least one word) */
+        (e = hipMalloc((void**)&c->tab.occ, c->n_slots / 8 + std::max<size_t>(c->n_slots / GSDF_BLOCK_VOX / 8, 4))) != hipSuccess ||
         (e = hipMalloc((void**)&c->st, sizeof(gsdf_dev_state))) != hipSuccess ||
         (e = hipMalloc((void**)&c->counter, sizeof(unsigned long long))) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
@@ -287,6 +301,9 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         return fail(GSDF_ERR_HIP, m);
     }
     c->tab.block_mask = (uint32_t)(c->n_slots / GSDF_BLOCK_VOX - 1);
+    c->tab.occ_mask = (uint32_t)(c->n_slots - 1);
+    c->tab.occ2 = c->tab.occ + c->n_slots / 32;
+    c->tab.occ2_mask = (uint32_t)(std::max<size_t>(c->n_slots / GSDF_BLOCK_VOX, 32) - 1);
     {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
@@ -310,14 +327,14 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
 
 void gsdf_destroy(gsdf_ctx* c) {
     if (!c) return;
-    if (c->trace) { (void)hipFree(c->trace); c->trace = nullptr; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->trace) { (void)hipFree(c->trace); c->trace = nullptr; }      /* after the sync: a running kernel may still write stamps */
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->mark_pool) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.second);
-    void* ptrs[] = { c->tab.vox, c->tab.bkeys, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
+    void* ptrs[] = { c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -334,11 +351,17 @@ int gsdf_reset(gsdf_ctx* c) {
     gsdf_launch_table_clear(c->stream, c->tab, c->n_slots);
     if (c->vis) HIP_TRY(hipMemsetAsync(c->vis, 0, c->n_slots * (size_t)c->vis_words * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->st, 0, sizeof(gsdf_dev_state), c->stream));
+    if (c->trace) {                                          /* test build: the memset cleared the trace pointer kept in dbg[23] */
+        const unsigned long long ptr = (unsigned long long)(uintptr_t)c->trace;
+        HIP_TRY(hipMemcpyAsync(&c->st->dbg[23], &ptr, 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));            /* `ptr` is a stack variable */
+    }
     const float ident[7] = { 0, 0, 0, 0, 0, 0, 1 };          /* pose_ = SE3() -- RigidOptimizer.h:64 */
     gsdf_launch_set_pose(c->stream, c->st, nullptr, ident);
     if (c->blk_counters)
         HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->merged = false;
     return GSDF_OK;
 }
 
@@ -495,7 +518,8 @@ int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9
     HIP_TRY(hipSetDevice(c->device));
     rc = enqueue_track(c, depth_dev, num_iterations, conv_threshold, damping, true);   /* main_scan_3d.cpp:258-265 */
     if (rc) return rc;
-    HIP_TRY(hipGetLastError());                                                   /* log row: written by k_fuse_resolve */
+    HIP_TRY(hipGetLastError());                  /* the frame's log row is written on the device: by the last workgroup of the
+                                                    k_fuse that fused it, or by the gated k_fuse that found it not converged */
     return GSDF_OK;
 }
 
@@ -877,6 +901,38 @@ int gsdf_get_voxels(gsdf_ctx* c, const int32_t* keys_host, int64_t n, float* pay
     return GSDF_OK;
 }
 
+static int raycast_enqueue(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
+                           float* depth_dev, float* normals_dev) {
+    gsdf_pose_arg pose;
+    std::memcpy(pose.R, R, sizeof(pose.R));
+    std::memcpy(pose.t, t, sizeof(pose.t));
+    /* per-workgroup counter rows (samples, records): sized for the largest grid seen, kept until reset */
+    const size_t n_wg = (size_t)((W + 15) / 16) * (size_t)((H + 15) / 16);
+    if (n_wg > c->rc_rows) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->rc_counts) (void)hipFree(c->rc_counts);
+        c->rc_counts = nullptr; c->rc_rows = 0;
+        HIP_TRY(hipMalloc((void**)&c->rc_counts, n_wg * 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(c->rc_counts, 0, n_wg * 8 * sizeof(unsigned long long), c->stream));
+        c->rc_rows = n_wg;
+    }
+    prof_scope ps(c, 3);
+    gsdf_launch_raycast(c->stream, c->tab, c->voxel_size, c->voxel_size_inv, c->factor, W, H, K, pose, zmin, zmax, depth_dev,
+                        normals_dev, c->rc_counts, c->debug & 0xFFFF);
+    return GSDF_OK;
+}
+
+int gsdf_raycast_dev(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
+                     float* depth_dev, float* normals_dev) {
+    if (!c || !K || !R || !t || !depth_dev) return fail(GSDF_ERR_INVALID, "null argument");
+    if (W <= 0 || H <= 0 || !(zmax > zmin) || !(zmin > 0.f)) return fail(GSDF_ERR_INVALID, "W,H > 0 and 0 < zmin < zmax required");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = raycast_enqueue(c, K, R, t, W, H, zmin, zmax, depth_dev, normals_dev);
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return GSDF_OK;
+}
+
 int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
                  float* depth_out, float* normals_out) {
     if (!c || !K || !R || !t || !depth_out) return fail(GSDF_ERR_INVALID, "null argument");
@@ -885,17 +941,30 @@ int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[
     const size_t N = (size_t)W * H;
     float* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, 4 * N * sizeof(float)));
-    gsdf_pose_arg pose;
-    std::memcpy(pose.R, R, sizeof(pose.R));
-    std::memcpy(pose.t, t, sizeof(pose.t));
-    gsdf_launch_raycast(c->stream, c->tab, c->voxel_size, c->voxel_size_inv, c->factor, W, H, K, pose, zmin, zmax, d,
-                        normals_out ? d + N : nullptr);
+    if (int rc = raycast_enqueue(c, K, R, t, W, H, zmin, zmax, d, normals_out ? d + N : nullptr)) { (void)hipFree(d); return rc; }
     hipError_t e = hipMemcpyAsync(depth_out, d, N * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && normals_out)
         e = hipMemcpyAsync(normals_out, d + N, 3 * N * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
+    return GSDF_OK;
+}
+
+int gsdf_raycast_counters(gsdf_ctx* c, int64_t* samples, int64_t* records, int reset) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long tot[4] = { 0, 0, 0, 0 };
+    if (c->rc_counts) {
+        std::vector<unsigned long long> h(c->rc_rows * 8);
+        HIP_TRY(hipMemcpyAsync(h.data(), c->rc_counts, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < c->rc_rows; ++i) for (int k = 0; k < 4; ++k) tot[k] += h[8 * i + k];
+        if (reset) HIP_TRY(hipMemsetAsync(c->rc_counts, 0, h.size() * sizeof(unsigned long long), c->stream));
+    }
+    if (samples) *samples = (int64_t)tot[0];
+    if (records) *records = (int64_t)tot[1];
+    c->rc_iters[0] = (long long)tot[2]; c->rc_iters[1] = (long long)tot[3];
     return GSDF_OK;
 }
 
@@ -1073,7 +1142,7 @@ int gsdf_profile(gsdf_ctx* c, int enable) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     prof_collect(c);
     c->profiling = enable != 0;
-    if (enable) for (int k = 0; k < 3; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    if (enable) for (int k = 0; k < GSDF_PROF_SLOTS; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
     return GSDF_OK;
 }
 int gsdf_profile_read(gsdf_ctx* c, double ms[3], int64_t launches[3]) {
@@ -1082,6 +1151,14 @@ int gsdf_profile_read(gsdf_ctx* c, double ms[3], int64_t launches[3]) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     prof_collect(c);
     for (int k = 0; k < 3; ++k) { ms[k] = c->prof_ms[k]; launches[k] = c->prof_n[k]; }
+    return GSDF_OK;
+}
+int gsdf_profile_read_n(gsdf_ctx* c, int n, double* ms, int64_t* launches) {
+    if (!c || !ms || !launches || n < 0 || n > GSDF_PROF_SLOTS) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    for (int k = 0; k < n; ++k) { ms[k] = c->prof_ms[k]; launches[k] = c->prof_n[k]; }
     return GSDF_OK;
 }
 

@@ -14,6 +14,8 @@
 #include <utility>
 #include <vector>
 
+#define GSDF_PROF_SLOTS 5     /* gsdf_profile: 0 normals, 1 fusion, 2 tracking launches, 3 raycast, 4 tracker (whole optimize) */
+
 inline thread_local std::string g_gsdf_err;
 
 inline int gsdf_fail(int code, const std::string& msg) {
@@ -37,7 +39,7 @@ struct gsdf_ctx {
     /* table */
     int capacity_log2 = 0;
     size_t n_slots = 0;
-    gsdf_table tab{ nullptr, 0 };
+    gsdf_table tab{ nullptr, nullptr, 0, nullptr, 0, nullptr, 0 };
     /* normal estimator + frame scratch */
     int W = 0, H = 0, win = 0;
     float K[9] = { 0 };
@@ -60,6 +62,10 @@ struct gsdf_ctx {
     uint32_t* tile_order = nullptr;                /* launch order of the fusion tiles (gsdf_fuse_tile_order) */
     uint32_t* vis = nullptr;                       /* optional vis_ bit-vectors, n_slots x vis_words */
     int vis_words = 0;
+    unsigned long long* rc_counts = nullptr;       /* raycaster: per-workgroup rows of (samples, records, fast / slow iterations of wave 0) */
+    size_t rc_rows = 0;
+    long long rc_iters[2] = { 0, 0 };              /* loop iterations of the workgroups' wave 0 as of the last gsdf_raycast_counters */
+    bool merged = false;                           /* gsdf_merge_allreduce has run: the map is the sum of all ranks (one-shot) */
     /* PhotoBA (PhotometricOptimizer) */
     int ba_n = 0;
     float ba_reg = 10.f;
@@ -85,14 +91,14 @@ struct gsdf_ctx {
     unsigned long long* counter = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[3];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[GSDF_PROF_SLOTS];
     std::vector<hipEvent_t> event_pool;
     /* gsdf_mark: events recorded on the stream, retired in order */
     std::deque<std::pair<long long, hipEvent_t>> marks;
     std::vector<hipEvent_t> mark_pool;
     long long mark_serial = 0;
-    double prof_ms[3] = { 0, 0, 0 };
-    long long prof_n[3] = { 0, 0, 0 };
+    double prof_ms[GSDF_PROF_SLOTS] = { 0 };
+    long long prof_n[GSDF_PROF_SLOTS] = { 0 };
 
     gsdf_frame_geom geom() const {
         gsdf_frame_geom g;

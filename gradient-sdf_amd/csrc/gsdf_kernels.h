@@ -137,7 +137,9 @@ void gsdf_launch_query(hipStream_t s, gsdf_table tab, float vs, float inv_vs, co
 void gsdf_launch_get_voxels(hipStream_t s, gsdf_table tab, const int32_t* keys, long long n, float* payload, int32_t* found);
 
 void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, int factor /* band half-width in voxels */, int W, int H, const float K[9],
-                         const gsdf_pose_arg& pose, float zmin, float zmax, float* depth_dev, float* normals_dev_or_null);
+                         const gsdf_pose_arg& pose, float zmin, float zmax, float* depth_dev, float* normals_dev_or_null,
+                         unsigned long long* wg_counts /* nullable: [workgroups of the 16x16-pixel grid][8]: samples, records, fast / slow loop iterations of wave 0 (added to); start / end tick of the workgroup */,
+                         int debug /* test build: 16384 = the sample-at-a-time kernel */);
 
 /* iso-surface: bounding-box minimum (mn_dev preset to INT_MAX x3), then triangles + sort keys appended through `counter` */
 void gsdf_launch_mesh(hipStream_t s, gsdf_table tab, size_t n_slots, float vs, float iso, int* mn_dev, const signed char* tri_table_dev,
@@ -149,6 +151,14 @@ void gsdf_launch_block_keys(hipStream_t s, gsdf_table tab, size_t n_blocks, unsi
 void gsdf_launch_pack_blocks(hipStream_t s, gsdf_table tab, const unsigned long long* keys_dev, long long n, float* dense_dev);
 void gsdf_launch_unpack_blocks(hipStream_t s, gsdf_table tab, const unsigned long long* keys_dev, long long n, const float* dense_dev,
                                gsdf_dev_state* st);
+
+/* vis_ bit-vectors of the exchange: this rank's vectors shifted by `bit_offset` frames into a dense buffer (vw words per voxel of
+ * every listed block) / the combined vectors stored; Sdf::counter_ := frames of all ranks */
+void gsdf_launch_pack_vis(hipStream_t s, gsdf_table tab, const uint32_t* vis, int vw, long long bit_offset,
+                          const unsigned long long* keys_dev, long long n, uint32_t* dense_dev);
+void gsdf_launch_unpack_vis(hipStream_t s, gsdf_table tab, uint32_t* vis, int vw, const unsigned long long* keys_dev, long long n,
+                            const uint32_t* dense_dev);
+void gsdf_launch_set_frames(hipStream_t s, gsdf_dev_state* st, long long frames);
 
 /* PhotoBA (gsdf_ba.hip): device-side problem description, same layout as the kernels' ba_args */
 struct gsdf_ba_dev {

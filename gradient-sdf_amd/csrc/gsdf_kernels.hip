@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256) void k_table_clear(gsdf_table tab, size_t n_bl
     uint4* p = reinterpret_cast<uint4*>(tab.vox);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += stride) tab.bkeys[i] = GSDF_KEY_EMPTY;
+    const size_t n_occ = ((size_t)tab.occ_mask + 1) / 32, n_occ2 = ((size_t)tab.occ2_mask + 1) / 32;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_occ; i += stride) tab.occ[i] = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_occ2; i += stride) tab.occ2[i] = 0u;
 }
 void gsdf_launch_table_clear(hipStream_t s, gsdf_table tab, size_t n_slots) {
     hipLaunchKernelGGL(k_table_clear, dim3(2048), dim3(256), 0, s, tab, n_slots / GSDF_BLOCK_VOX);
@@ -252,27 +255,32 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 /* ------------------------------------------------------------------------------------------------
  * MapGradPixelSdf::update -- fusion.
  *
- * Work decomposition: one workgroup = one 16x16 pixel tile, 512 lanes = 4 waves (each an 8x8
- * sub-tile, so a wave's 64 rays stay spatially compact) x 2 halves of the ray walk.  Each lane walks
- * its ray's samples.  Neighbouring pixels and consecutive samples hit the same voxels (~4.5 updates
- * per distinct voxel per frame), so updates are first combined in a workgroup-private hash table in
- * LDS; only the distinct voxels of the tile are flushed to the HBM map.  Far tiles / small voxels
- * (more distinct voxels than the table holds) are walked as 2 or 4 row bands, each flushed on its own.
+ * Work decomposition: one workgroup = one 16x16 pixel tile, 512 lanes = 8 waves.  A wave takes 32 pixels of the tile --
+ * every 2nd in x, every 4th in y (wave w has phase (w & 1, w >> 1)) -- and BOTH halves of their ray walk (lanes 0-31 the
+ * first half of k = -factor..factor, lanes 32-63 the second), so neighbouring lanes are >= 2 pixels or half a ray apart
+ * and rarely hit one voxel in the same instruction.  Neighbouring pixels and consecutive samples do hit the same voxels
+ * (~4.5 updates per distinct voxel per frame), so updates are first combined in a workgroup-private hash table in LDS;
+ * only the distinct voxels of the tile are flushed to the HBM map.  Far tiles / small voxels (more distinct voxels than
+ * the table holds) are walked as 2 or 4 row bands, each flushed on its own.
  *
- * What the MI355X measurements (tools/atomics_bench.hip, tools/fuse_ablate.py, profiles/) dictated:
- *  - ds_add_f32 is lane-serial (~190 cycles per wave instruction), ds_add_u64 costs 8-29: the
- *    LDS accumulators are 64-bit FIXED POINT (2^-40); sums are exact and order-independent, one
- *    rounding to float happens at the flush.
- *  - the LDS lookup dominated: 32-bit TILE-LOCAL keys (one ds_read_b128 per bucket of 4) and a
- *    LATTICE hash of the local coordinates bring it to ~1 probe iteration per wave-sample (a random
- *    hash of 64-bit keys needed 2.8); three samples per lane are in flight, and samples no lane still
- *    waits for are skipped with wave-uniform branches.
- *  - device-scope atomics run at only ~20-50 G/s chip-wide: the flush uses NONE.  Tiles hand their
- *    voxels on in colour order with plain read-modify-write (see the flush); only tiles that are too
- *    near for that, timed-out waits and LDS overflow go through a deferred list that k_fuse_resolve
- *    adds with float atomics after the launch.
- *  - the kernel is VALU-issue / latency bound at 2 workgroups (16 waves) per CU: instruction count
- *    matters more than bytes (double-rate fixed-point conversion, packed f32 math, uniform skips).
+ * What the MI355X measurements (tools/atomics_bench.hip, tools/fuse_ablate.py, tools/fuse_trace.py, profiles/) dictated:
+ *  - ds_add_f32 is lane-serial (~190 cycles per wave instruction), ds_add_u64 costs 7-29: the LDS accumulators are
+ *    FIXED POINT, three 64-bit words per entry that several sums share (layout below), each word in its own array so that
+ *    a wave's scattered adds use all banks.  Sums are exact and order-independent; one rounding to float at the flush.
+ *  - the LDS lookup dominated: 32-bit TILE-LOCAL keys (one ds_read_b128 per bucket of 4) and a LATTICE hash of the local
+ *    coordinates bring it to ~1 probe per sample (a random hash of 64-bit keys needed 2.8).  ONE sample per lane is in
+ *    flight (2, 3, 4 and 6 were measured slower: registers); the probe loop ends with a wave-uniform branch as soon as no
+ *    lane is pending.
+ *  - the walk is bound by VALU issue and LDS cycles when two workgroups share a CU, so it is written for instruction
+ *    count: packed 2 x f32 arithmetic for x / y, a 3-operation round (exhaustively checked against roundf), one v_med3 for
+ *    the clamp, shift-adds and 24-bit multiply-adds for keys / hash / addresses, and the weight goes to fixed point with a
+ *    plain float multiply + convert (w 2^24 is an integer), the distance through the double-add trick of f2fix.
+ *  - device-scope atomics run at only ~20-50 G/s chip-wide: the flush uses NONE.  Tiles hand their voxels on in colour
+ *    order with plain read-modify-write (see the flush); only tiles that are too near for that, timed-out waits and LDS
+ *    overflow go through a deferred list, which the LAST workgroup of the launch adds with float atomics (k_fuse_resolve
+ *    is queued only while recent launches reported long lists).
+ *  - two workgroups (16 waves) per CU; a third one does not pay (the CU's issue and LDS throughput are the limit, not
+ *    occupancy).  The kernel exists with two table sizes (FUSE_LCAP below), chosen per launch by the host.
  * ---------------------------------------------------------------------------------------------- */
 #define FUSE_T 16
 #ifndef FUSE_ZSPLIT
@@ -1012,6 +1020,9 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     if (GSDF_EXPERIMENT(a.debug, 64) && tid == 0) tr[13] = (unsigned long long)n_pass;
     /* per-workgroup counters (plain stores into this workgroup's own row: no hot atomics) */
     if (lane == 0) { L.cnt[0][wave] = n_upd_w; L.cnt[1][wave] = n_val_w; }
+    /* every wave drains what it stored -- deferred-list entries among it -- before the barrier behind which thread 0 releases
+     * them to the last workgroup of the launch (the record stores were drained above already; normally nothing is pending) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
         unsigned long long nu = 0ull, nv = 0ull;
@@ -1218,7 +1229,7 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
         gsdf_v3 p[TRK_PPT];
         int vx[TRK_PPT], vy[TRK_PPT], vz[TRK_PPT];
         unsigned long long key[TRK_PPT], bkey[TRK_PPT], k0[TRK_PPT];
-        uint32_t home[TRK_PPT];
+        uint32_t home[TRK_PPT], obit[TRK_PPT], oword[TRK_PPT];
 #pragma unroll
         for (int j = 0; j < TRK_PPT; ++j) {
             const int pix = base + j * nthreads;
@@ -1237,6 +1248,10 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
             bkey[j] = gsdf_block_key(key[j]);
             home[j] = gsdf_hash(bkey[j]) & tab.block_mask;
             k0[j] = ok[j] ? tab.bkeys[home[j]] : GSDF_KEY_EMPTY;
+            /* the block filter, requested together with the home entry: pixels that look past the map (~1 in 6 on the bench
+             * stream) would otherwise walk their probe sequence to an empty entry, and the wave waits for its longest chain */
+            obit[j] = ok[j] ? gsdf_occ_bit_vox(tab, vx[j], vy[j], vz[j]) : 0u;
+            oword[j] = ok[j] ? tab.occ[obit[j] >> 5] : 0u;
         }
         /* stage C: the voxel record (neighbouring pixels share lines: 4 x-adjacent voxels per line) */
         const gsdf_payload* P[TRK_PPT];
@@ -1245,7 +1260,7 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
         {
             uint32_t want = 0u;
 #pragma unroll
-            for (int j = 0; j < TRK_PPT; ++j) want |= ok[j] ? 1u << j : 0u;
+            for (int j = 0; j < TRK_PPT; ++j) want |= (ok[j] && gsdf_occ_test(oword[j], obit[j])) ? 1u << j : 0u;
             gsdf_block_lookup_n<TRK_PPT, false>(tab, bkey, home, k0, want, blk);   /* the pixels' probe chains overlap */
         }
 #pragma unroll
@@ -1607,75 +1622,219 @@ void gsdf_launch_get_voxels(hipStream_t s, gsdf_table tab, const int32_t* keys, 
  * 1-voxel steps inside the band; hit = first sign change phi_prev < 0 <= phi of two consecutive existing samples (the SDF
  * is negative in front of a surface); depth by linear interpolation, normal = R^T grad/|grad| of the sample behind the
  * surface.  The test infrastructure holds the CPU statement of the same definition.
- * One lane per pixel, 16x16-pixel workgroups (neighbouring rays walk the same blocks: the block keys
- * are L2 hits, records share lines).  The walk is a chain of dependent lookups per ray: 4-voxel steps
- * through empty space (one key probe each), 1-voxel steps inside the band.
+ *
+ * Design (measured on the bench map, tools/raycast_bench.py + tools/raycast_pmc.sh).  A ray is ~45 coarse samples
+ * through empty space and ~15 fine ones in the band.  The sample-at-a-time walk of rounds 1-2 (k_raycast_v1, kept in the test
+ * build) pays a block-key probe -- key packing, a 64-bit hash, a chain of dependent loads to the first empty entry -- for
+ * every one of them: 129 wave instructions per sample.  The kernel is bound by VALU issue as much as by latency (a wave64
+ * instruction occupies its SIMD for 4 cycles: 35 M wave instructions = 57 us of the 121 us), so the design is about NOT
+ * computing, in three levels:
+ *  1. cell filter (gsdf_table::occ2, one hashed bit per 32^3-voxel cell that holds a block, 8 KB): a sample in an empty cell
+ *     is missing, and so is every further sample up to the cell's far face -- the ray's exit distance is three multiplies,
+ *     the skipped samples cost one float add each (s advances by the same repeated additions as in the definition, so the
+ *     positions stay bit-identical);
+ *  2. block filter (gsdf_table::occ, one hashed bit per existing block): in a cell that holds blocks a sample whose block
+ *     bit is clear is missing -- one load, no key packing, no hash, no probe chain;
+ *  3. only samples whose block bit is set are looked up (probe + 32-byte record), the filter word and the home entry of the
+ *     key array requested together.
+ *  Same samples, same arithmetic, same results bit for bit as the sample-at-a-time walk.  A wave is an 8x8-pixel patch: its
+ *  64 rays cross the same one or two blocks at every depth, so a wave instruction's loads coalesce into a few requests and
+ *  its lanes enter the band at about the same depth.  Few registers: all 4800 waves of a 640x480 render are resident at once.
+ *  Measured and rejected: looking RC_B samples ahead per lane (their lookups issued together, the state machine consuming
+ *  them while the predicted positions hold): 8x fewer dependent round trips, but 20 % MORE instructions (speculative work
+ *  beyond a hit or a change of step), 118-136 registers (two rounds of waves) -- 138-200 us against 121.
+ * Counters (for the roofline entry): samples the definition evaluated and records it read, one row per workgroup.
  * ---------------------------------------------------------------------------------------------- */
+struct rc_ray_state {
+    float s, fine_until, s_coarse_from, phi_prev, s_prev, out_z;
+    gsdf_v3 out_n;
+    bool prev_ok, done;
+};
+/* one step of the definition with the sample at st.s already looked up: p = its position, (vx, vy, vz) its voxel,
+ * w0 = the voxel's weight (0: missing), (sd, gx, gy, gz) its record */
+__device__ __forceinline__ void rc_step(rc_ray_state& st, const gsdf_v3& p, int vx, int vy, int vz, const gsdf_pose_arg& pose, float vs,
+                                        float fine, float coarse, float w0, float sd, float gx, float gy, float gz) {
+    const float* R = pose.R;
+    const float s = st.s;
+    if (w0 > 0.f && st.s_coarse_from >= 0.f) {                /* entered the band by a coarse step: walk that stretch again */
+        st.fine_until = s;
+        st.s = st.s_coarse_from + fine;
+        st.s_coarse_from = -1.f;
+        st.prev_ok = false;
+        return;
+    }
+    if (w0 > 0.f) {
+        const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ gx, gy, gz });
+        const gsdf_v3 g = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };
+        const gsdf_v3 c = { vs * (float)vx - p.x, vs * (float)vy - p.y, vs * (float)vz - p.z };
+        const float phi = sd / w0 + gsdf_dot3(g, c);
+        if (st.prev_ok && st.phi_prev < 0.f && phi >= 0.f) {   /* the stored SDF is negative in front of the surface */
+            st.out_z = st.s_prev + (s - st.s_prev) * (st.phi_prev / (st.phi_prev - phi));
+            st.out_n = gsdf_v3{ gsdf_sum3(R[0] * gn.x, R[3] * gn.y, R[6] * gn.z), gsdf_sum3(R[1] * gn.x, R[4] * gn.y, R[7] * gn.z),
+                                gsdf_sum3(R[2] * gn.x, R[5] * gn.y, R[8] * gn.z) };
+            st.done = true;
+            return;
+        }
+        st.prev_ok = true; st.phi_prev = phi; st.s_prev = s;
+        st.s = s + fine;
+    } else if (st.prev_ok && s - st.s_prev < 1.5f * fine) {
+        st.s = s + fine;                                       /* one missing sample inside the band is bridged */
+    } else {
+        st.prev_ok = false;
+        if (s < st.fine_until) st.s = s + fine;
+        else { st.s_coarse_from = s; st.s = s + coarse; }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float inv_vs, int factor, int W, int H, float fx, float fy,
                                                   float cx, float cy, gsdf_pose_arg pose, float zmin, float zmax,
-                                                  float* __restrict__ depth, float* __restrict__ normals) {
-    const int u = blockIdx.x * 16 + (threadIdx.x & 15), v = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (u >= W || v >= H) return;
-    const float* R = pose.R;
+                                                  float* __restrict__ depth, float* __restrict__ normals,
+                                                  unsigned long long* __restrict__ wg_counts) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long t_begin = wall_clock64();
+    const int u = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7), v = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const bool live = u < W && v < H;
     const float fx_inv = 1.f / fx, fy_inv = 1.f / fy;
     const float x0 = ((float)u - cx) * fx_inv, y0 = ((float)v - cy) * fy_inv;
-    const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ x0, y0, 1.f });
-    /* coarse steps of min(4, factor - 1) voxels of depth across missing voxels; the first existing voxel found after
-     * one sends the walk back to the start of that step, which is then walked in fine steps (the step may have jumped the
-     * front of the band); one missing sample between two existing ones is bridged -- definition: DESIGN.md (f4) */
+    const gsdf_v3 d = gsdf_matvec(pose.R, gsdf_v3{ x0, y0, 1.f });
     const float fine = vs, coarse = (float)(factor < 2 ? 1 : (factor > 5 ? 4 : factor - 1)) * vs;
-    float out_z = 0.f;
-    gsdf_v3 out_n = { 0.f, 0.f, 0.f };
-    bool prev_ok = false;
-    float phi_prev = 0.f, s_prev = 0.f;
-    float fine_until = zmin, s_coarse_from = -1.f;
-    for (float s = zmin; s < zmax;) {
+    /* for the cell skip: depth per voxel of travel along each axis, and coarse steps per unit of depth (estimates with
+     * margin, no parity items) */
+    const float rdx = vs * __builtin_amdgcn_rcpf(d.x), rdy = vs * __builtin_amdgcn_rcpf(d.y), rdz = vs * __builtin_amdgcn_rcpf(d.z);
+    const float inv_coarse = __builtin_amdgcn_rcpf(coarse);
+    constexpr int CELL = 1 << GSDF_CELL_SHIFT;
+    rc_ray_state st;
+    st.s = zmin; st.fine_until = zmin; st.s_coarse_from = -1.f; st.phi_prev = 0.f; st.s_prev = 0.f; st.out_z = 0.f;
+    st.out_n = gsdf_v3{ 0.f, 0.f, 0.f };
+    st.prev_ok = false; st.done = !live;
+    unsigned int n_samp = 0u, n_rec = 0u;
+    unsigned int it_fast = 0u, it_slow = 0u;                          /* wave-uniform loop counts: cell skips taken / all iterations */
+    for (;;) {
+        const bool active = !st.done && st.s < zmax;
+        if (!__any(active)) break;
+        ++it_slow;
+        const float s = st.s;
         const gsdf_v3 p = { s * d.x + pose.t[0], s * d.y + pose.t[1], s * d.z + pose.t[2] };
+        const float qx = inv_vs * p.x, qy = inv_vs * p.y, qz = inv_vs * p.z;
+        const int vx = (int)gsdf_roundf(qx), vy = (int)gsdf_roundf(qy), vz = (int)gsdf_roundf(qz);           /* gsdf_float2vox1 */
+        const bool inr = gsdf_key_in_range(vx, vy, vz);
+        /* in empty space a missing sample is followed by a coarse step */
+        const bool in_coarse = active && (st.s_coarse_from >= 0.f || (!st.prev_ok && !(s < st.fine_until)));
+        /* (Measured and rejected: lanes in empty space first, lanes already in a band waiting for them, so that an iteration is
+         * either the short empty-space step or the full band step -- rays that run along a surface in occupied cells make
+         * their whole wave wait for hundreds of single steps: 302 us.) */
+        const bool mine = active;
+        bool missing = !inr;
+        int n_skip = 0;
+        float w0 = 0.f, sd = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+        if (mine) {
+            /* 1. + 2. cell filter and block filter, both words requested together (in a band only the block filter) */
+            const uint32_t cb = inr && in_coarse ? gsdf_occ2_bit_vox(tab, vx, vy, vz) : 0u;
+            const uint32_t ob = inr ? gsdf_occ_bit_vox(tab, vx, vy, vz) : 0u;
+            const uint32_t cw = inr && in_coarse ? tab.occ2[cb >> 5] : 0xFFFFFFFFu;
+            const uint32_t ow = inr ? tab.occ[ob >> 5] : 0u;
+            if (in_coarse && inr && !gsdf_occ_test(cw, cb)) {
+                missing = true;
+                /* every sample whose position stays >= half a voxel inside this cell is missing too: depth to the first face */
+                const float lx = (float)((((vx + GSDF_KEY_OFF) >> GSDF_CELL_SHIFT) << GSDF_CELL_SHIFT) - GSDF_KEY_OFF);
+                const float ly = (float)((((vy + GSDF_KEY_OFF) >> GSDF_CELL_SHIFT) << GSDF_CELL_SHIFT) - GSDF_KEY_OFF);
+                const float lz = (float)((((vz + GSDF_KEY_OFF) >> GSDF_CELL_SHIFT) << GSDF_CELL_SHIFT) - GSDF_KEY_OFF);
+                const float hi = (float)CELL - 1.5f;
+                const float tx = d.x > 0.f ? (lx + hi - qx) * rdx : (d.x < 0.f ? (lx + 0.5f - qx) * rdx : 3.0e38f);
+                const float ty = d.y > 0.f ? (ly + hi - qy) * rdy : (d.y < 0.f ? (ly + 0.5f - qy) * rdy : 3.0e38f);
+                const float tz = d.z > 0.f ? (lz + hi - qz) * rdz : (d.z < 0.f ? (lz + 0.5f - qz) * rdz : 3.0e38f);
+                const float te = fminf(fminf(tx, ty), tz);
+                n_skip = te > 0.f ? (int)fminf(te * inv_coarse, 64.f) : 0;
+            }
+            if (!gsdf_occ_test(ow, ob)) missing = true;
+            if (!missing) {
+                /* 3. the lookup proper: probe of the key array + the 32-byte record */
+                const unsigned long long key = gsdf_key_pack(vx, vy, vz);
+                const unsigned long long bkey = gsdf_block_key(key);
+                const uint32_t home = gsdf_hash(bkey) & tab.block_mask;
+                const int blk = gsdf_block_find(tab, bkey, home, tab.bkeys[home]);
+                if (blk >= 0) {
+                    const float2* q = reinterpret_cast<const float2*>(tab.vox + ((size_t)blk * GSDF_BLOCK_VOX + gsdf_block_local(key)));
+                    const float2 a = q[0], b = q[1], c = q[2];
+                    w0 = a.x; sd = a.y; gx = b.x; gy = b.y; gz = c.x;
+                    ++n_rec;
+                }
+            }
+            ++n_samp;
+            if (in_coarse && !(w0 > 0.f)) {
+                /* missing, in empty space: a coarse step -- and one for every further sample known to be missing */
+                st.prev_ok = false;
+                st.s_coarse_from = s;
+                st.s = s + coarse;
+                for (int k = 0; k < n_skip && st.s < zmax; ++k) { st.s_coarse_from = st.s; st.s = st.s + coarse; ++n_samp; }
+            } else {
+                rc_step(st, p, vx, vy, vz, pose, vs, fine, coarse, w0, sd, gx, gy, gz);
+            }
+        }
+        if (n_skip > 0) ++it_fast;
+    }
+    if (live) {
+        const size_t i = (size_t)v * W + u;
+        depth[i] = st.out_z;
+        if (normals) { normals[i] = st.out_n.x; normals[(size_t)W * H + i] = st.out_n.y; normals[2 * (size_t)W * H + i] = st.out_n.z; }
+    }
+    /* counters of the roofline entry: one row per workgroup, plain read-modify-write by its thread 0 (launches are ordered
+     * on the stream).  NOT atomics on one word: 2 same-address atomics per wave serialised the whole kernel (measured: +60 us) */
+    __shared__ float rc_cnt[4][2];
+    const float ts = wave_sum((float)n_samp), tr = wave_sum((float)n_rec);           /* < 2^24 per wave: exact */
+    if (lane == 0) { rc_cnt[wave][0] = ts; rc_cnt[wave][1] = tr; }
+    __syncthreads();
+    if (wg_counts && threadIdx.x == 0) {
+        unsigned long long* row = wg_counts + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        row[0] += (unsigned long long)(rc_cnt[0][0] + rc_cnt[1][0] + rc_cnt[2][0] + rc_cnt[3][0]);
+        row[1] += (unsigned long long)(rc_cnt[0][1] + rc_cnt[1][1] + rc_cnt[2][1] + rc_cnt[3][1]);
+        row[2] += it_fast; row[3] += it_slow;                           /* lane 0 of wave 0: cell skips / loop iterations */
+        row[4] = t_begin; row[5] = wall_clock64();                      /* life of the workgroup, 100 MHz ticks (last launch) */
+    }
+}
+
+#ifdef GSDF_EXPERIMENTS
+/* the sample-at-a-time walk of rounds 1 and 2 (one lane per pixel, one dependent lookup per step): kept for the before /
+ * after measurement of tools/raycast_bench.py (debug bit 16384) */
+__global__ __launch_bounds__(256) void k_raycast_v1(gsdf_table tab, float vs, float inv_vs, int factor, int W, int H, float fx, float fy,
+                                                     float cx, float cy, gsdf_pose_arg pose, float zmin, float zmax,
+                                                     float* __restrict__ depth, float* __restrict__ normals) {
+    const int u = blockIdx.x * 16 + (threadIdx.x & 15), v = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (u >= W || v >= H) return;
+    const float fx_inv = 1.f / fx, fy_inv = 1.f / fy;
+    const float x0 = ((float)u - cx) * fx_inv, y0 = ((float)v - cy) * fy_inv;
+    const gsdf_v3 d = gsdf_matvec(pose.R, gsdf_v3{ x0, y0, 1.f });
+    const float fine = vs, coarse = (float)(factor < 2 ? 1 : (factor > 5 ? 4 : factor - 1)) * vs;
+    rc_ray_state st;
+    st.s = zmin; st.fine_until = zmin; st.s_coarse_from = -1.f; st.phi_prev = 0.f; st.s_prev = 0.f; st.out_z = 0.f;
+    st.out_n = gsdf_v3{ 0.f, 0.f, 0.f };
+    st.prev_ok = false; st.done = false;
+    while (!st.done && st.s < zmax) {
+        const gsdf_v3 p = { st.s * d.x + pose.t[0], st.s * d.y + pose.t[1], st.s * d.z + pose.t[2] };
         const int vx = gsdf_float2vox1(inv_vs, p.x), vy = gsdf_float2vox1(inv_vs, p.y), vz = gsdf_float2vox1(inv_vs, p.z);
         const gsdf_payload* sl = gsdf_key_in_range(vx, vy, vz) ? gsdf_find(tab, gsdf_key_pack(vx, vy, vz)) : nullptr;
-        float w0 = 0.f;
         float2 ws = make_float2(0.f, 0.f), gxy = ws, gz_ = ws;
-        if (sl) {
-            const float2* q = reinterpret_cast<const float2*>(sl);
-            ws = q[0]; gxy = q[1]; gz_ = q[2];
-            w0 = ws.x;
-        }
-        if (w0 > 0.f && s_coarse_from >= 0.f) {
-            fine_until = s;
-            s = s_coarse_from + fine;
-            s_coarse_from = -1.f;
-            prev_ok = false;
-            continue;
-        }
-        if (w0 > 0.f) {
-            const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ gxy.x, gxy.y, gz_.x });
-            const gsdf_v3 g = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };
-            const gsdf_v3 c = { vs * (float)vx - p.x, vs * (float)vy - p.y, vs * (float)vz - p.z };
-            const float phi = ws.y / w0 + gsdf_dot3(g, c);
-            if (prev_ok && phi_prev < 0.f && phi >= 0.f) {   /* the stored SDF is negative in front of the surface */
-                out_z = s_prev + (s - s_prev) * (phi_prev / (phi_prev - phi));
-                out_n = gsdf_v3{ gsdf_sum3(R[0] * gn.x, R[3] * gn.y, R[6] * gn.z), gsdf_sum3(R[1] * gn.x, R[4] * gn.y, R[7] * gn.z),
-                                 gsdf_sum3(R[2] * gn.x, R[5] * gn.y, R[8] * gn.z) };
-                break;
-            }
-            prev_ok = true; phi_prev = phi; s_prev = s;
-            s += fine;
-        } else if (prev_ok && s - s_prev < 1.5f * fine) {
-            s += fine;                                          /* one missing sample inside the band is bridged */
-        } else {
-            prev_ok = false;
-            if (s < fine_until) s += fine;
-            else { s_coarse_from = s; s += coarse; }
-        }
+        if (sl) { const float2* q = reinterpret_cast<const float2*>(sl); ws = q[0]; gxy = q[1]; gz_ = q[2]; }
+        rc_step(st, p, vx, vy, vz, pose, vs, fine, coarse, ws.x, ws.y, gxy.x, gxy.y, gz_.x);
     }
     const size_t i = (size_t)v * W + u;
-    depth[i] = out_z;
-    if (normals) { normals[i] = out_n.x; normals[(size_t)W * H + i] = out_n.y; normals[2 * (size_t)W * H + i] = out_n.z; }
+    depth[i] = st.out_z;
+    if (normals) { normals[i] = st.out_n.x; normals[(size_t)W * H + i] = st.out_n.y; normals[2 * (size_t)W * H + i] = st.out_n.z; }
 }
+#endif
 void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, int factor, int W, int H, const float K[9],
-                         const gsdf_pose_arg& pose, float zmin, float zmax, float* depth, float* normals) {
+                         const gsdf_pose_arg& pose, float zmin, float zmax, float* depth, float* normals, unsigned long long* wg_counts,
+                         int debug) {
+#ifdef GSDF_EXPERIMENTS
+    if (debug & 16384) {
+        hipLaunchKernelGGL(k_raycast_v1, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, s, tab, vs, inv_vs, factor, W, H, K[0], K[4],
+                           K[2], K[5], pose, zmin, zmax, depth, normals);
+        return;
+    }
+#endif
+    (void)debug;
     hipLaunchKernelGGL(k_raycast, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, s, tab, vs, inv_vs, factor, W, H, K[0], K[4], K[2],
-                       K[5], pose, zmin, zmax, depth, normals);
+                       K[5], pose, zmin, zmax, depth, normals, wg_counts);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1837,6 +1996,61 @@ __global__ __launch_bounds__(256) void k_unpack_blocks(gsdf_table tab, const uns
     gsdf_payload p;
     p.w = v[0]; p.s = v[1]; p.gx = v[2]; p.gy = v[3]; p.gz = v[4]; p.aux = 0u; p.pad[0] = 0u; p.pad[1] = 0u;
     tab.vox[(size_t)blk * GSDF_BLOCK_VOX + lane] = p;
+}
+/* vis_ of the exchange (MapGradPixelSdf.cpp:113-115: bit f of a voxel = "updated by integrated frame f"): every rank numbers
+ * its own frames from 0, so its bit-vectors are shifted by the frames of the ranks before it (contiguous frame shards in rank
+ * order); the shifted vectors of different ranks have no bit in common, so their SUM as unsigned words is their OR.
+ * One wavefront per block of the union, lane = voxel, `vw` words per voxel. */
+__global__ __launch_bounds__(256) void k_pack_vis(gsdf_table tab, const uint32_t* __restrict__ vis, int vw, long long bit_offset,
+                                                   const unsigned long long* __restrict__ keys, long long n, uint32_t* __restrict__ dense) {
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bk = keys[b];
+    const uint32_t h = gsdf_hash(bk) & tab.block_mask;
+    const int blk = gsdf_block_find(tab, bk, h, tab.bkeys[h]);
+    uint32_t* o = dense + ((size_t)b * GSDF_BLOCK_VOX + lane) * vw;
+    const uint32_t* in = blk >= 0 ? vis + ((size_t)blk * GSDF_BLOCK_VOX + lane) * vw : nullptr;
+    const int q = (int)(bit_offset >> 5), sh = (int)(bit_offset & 31);
+    for (int w = 0; w < vw; ++w) {
+        uint32_t v = 0u;
+        if (in) {
+            if (w - q >= 0) v = in[w - q] << sh;
+            if (sh && w - q - 1 >= 0) v |= in[w - q - 1] >> (32 - sh);
+        }
+        o[w] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_unpack_vis(gsdf_table tab, uint32_t* __restrict__ vis, int vw,
+                                                     const unsigned long long* __restrict__ keys, long long n,
+                                                     const uint32_t* __restrict__ dense) {
+    const long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bk = keys[b];
+    const uint32_t h = gsdf_hash(bk) & tab.block_mask;
+    const int blk = gsdf_block_find(tab, bk, h, tab.bkeys[h]);       /* inserted by k_unpack_blocks */
+    if (blk < 0) return;
+    const uint32_t* in = dense + ((size_t)b * GSDF_BLOCK_VOX + lane) * vw;
+    uint32_t* o = vis + ((size_t)blk * GSDF_BLOCK_VOX + lane) * vw;
+    for (int w = 0; w < vw; ++w) o[w] = in[w];
+}
+/* Sdf::counter_ after the exchange = frames integrated by all ranks */
+__global__ void k_set_frames(gsdf_dev_state* st, long long frames) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->frames = frames; st->frame_cur = frames; }
+}
+void gsdf_launch_pack_vis(hipStream_t s, gsdf_table tab, const uint32_t* vis, int vw, long long bit_offset,
+                          const unsigned long long* keys, long long n, uint32_t* dense) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_pack_vis, dim3((unsigned int)((n + 3) / 4)), dim3(256), 0, s, tab, vis, vw, bit_offset, keys, n, dense);
+}
+void gsdf_launch_unpack_vis(hipStream_t s, gsdf_table tab, uint32_t* vis, int vw, const unsigned long long* keys, long long n,
+                            const uint32_t* dense) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_unpack_vis, dim3((unsigned int)((n + 3) / 4)), dim3(256), 0, s, tab, vis, vw, keys, n, dense);
+}
+void gsdf_launch_set_frames(hipStream_t s, gsdf_dev_state* st, long long frames) {
+    hipLaunchKernelGGL(k_set_frames, dim3(1), dim3(64), 0, s, st, frames);
 }
 void gsdf_launch_block_keys(hipStream_t s, gsdf_table tab, size_t n_blocks, unsigned long long* out, unsigned long long* counter,
                             long long max_n) {

@@ -24,9 +24,12 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <random>
 
 namespace {
 
@@ -79,6 +82,8 @@ struct transport {
     /* recv[r * bytes .. (r + 1) * bytes) = rank r's send buffer; on the context's stream */
     virtual int allgather(gsdf_ctx* c, const void* send_dev, void* recv_dev, size_t bytes) = 0;
     virtual int allreduce_sum_f32(gsdf_ctx* c, float* buf_dev, size_t n) = 0;
+    /* bitwise OR of unsigned words whose set bits are disjoint between the ranks (so a sum does it too) */
+    virtual int allreduce_or_u32(gsdf_ctx* c, uint32_t* buf_dev, size_t n) = 0;
     virtual ~transport() {}
 };
 
@@ -90,6 +95,10 @@ struct rccl_transport : transport {
     }
     int allreduce_sum_f32(gsdf_ctx* c, float* buf_dev, size_t n) override {
         RCCL_TRY(rccl().AllReduce(buf_dev, buf_dev, n, ncclFloat32, ncclSum, comm, c->stream));
+        return GSDF_OK;
+    }
+    int allreduce_or_u32(gsdf_ctx* c, uint32_t* buf_dev, size_t n) override {
+        RCCL_TRY(rccl().AllReduce(buf_dev, buf_dev, n, ncclUint32, ncclSum, comm, c->stream));   /* disjoint bits: sum == or */
         return GSDF_OK;
     }
 };
@@ -116,6 +125,24 @@ struct host_transport : transport {
         HIP_TRY(hipStreamSynchronize(c->stream));
         return GSDF_OK;
     }
+    /* the callback interface has no integer reduction: gather every rank's words and OR them here (the host transport is
+     * for tests and small worlds) */
+    int allreduce_or_u32(gsdf_ctx* c, uint32_t* buf_dev, size_t n) override {
+        const size_t bytes = n * sizeof(uint32_t);
+        a.resize(bytes); b.resize(bytes * (size_t)nranks);
+        HIP_TRY(hipMemcpyAsync(a.data(), buf_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (ops->allgather(ops->user, a.data(), b.data(), (int64_t)bytes) != 0) return gsdf_fail(GSDF_ERR_INVALID, "gsdf_collective.allgather failed");
+        uint32_t* acc = (uint32_t*)a.data();
+        std::memset(acc, 0, bytes);
+        for (int r = 0; r < nranks; ++r) {
+            const uint32_t* src = (const uint32_t*)(b.data() + (size_t)r * bytes);
+            for (size_t i = 0; i < n; ++i) acc[i] |= src[i];
+        }
+        HIP_TRY(hipMemcpyAsync(buf_dev, a.data(), bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return GSDF_OK;
+    }
 };
 
 struct dev_buf {
@@ -133,35 +160,110 @@ int read_status(gsdf_ctx* c) {
     return GSDF_OK;
 }
 
+/* What every rank tells the others before anything is exchanged.  `err` makes local failures collective: a rank that could
+ * not prepare (allocation, launch) still takes part in this all-gather, and then ALL ranks return an error together instead
+ * of one leaving its peers inside a collective. */
+struct merge_hdr {
+    long long n_blocks;          /* blocks of this rank's map */
+    long long frames;            /* Sdf::counter_ of this rank: frames it integrated */
+    long long vis_words;         /* words per voxel of its vis_ bit-vectors, 0 = not enabled */
+    long long err;               /* GSDF_ERR_* of its preparation, 0 = fine */
+    unsigned long long token;    /* random: a rank finds its own position in the gathered list by it (the callback transport
+                                    does not tell a rank its number) */
+};
+
+/* second agreement point: every rank reports whether its buffers for the exchange exist */
+int agree(gsdf_ctx* c, transport& tr, long long* scratch_dev /* R + 1 words */, int local_rc, const char* what) {
+    const int R = tr.nranks;
+    const long long mine = local_rc;
+    HIP_TRY(hipMemcpyAsync(scratch_dev + R, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+    int rc = tr.allgather(c, scratch_dev + R, scratch_dev, sizeof(long long));
+    if (rc) return rc;
+    std::vector<long long> all((size_t)R);
+    HIP_TRY(hipMemcpyAsync(all.data(), scratch_dev, (size_t)R * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (local_rc) return local_rc;                                    /* g_gsdf_err already says why */
+    for (int r = 0; r < R; ++r)
+        if (all[(size_t)r]) return gsdf_fail((int)all[(size_t)r], std::string("gsdf_merge_allreduce: rank ") + std::to_string(r) + " failed to " + what);
+    return GSDF_OK;
+}
+
+unsigned long long random_token(const gsdf_ctx* c) {
+    std::random_device rd;
+    unsigned long long t = ((unsigned long long)rd() << 32) ^ (unsigned long long)rd();
+    t ^= gsdf_hash64((unsigned long long)(uintptr_t)c ^ ((unsigned long long)getpid() << 32));
+    return t ? t : 1ull;
+}
+
 int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes_out) {
     HIP_TRY(hipSetDevice(c->device));
+    if (c->merged && tr.nranks > 1)
+        return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: this map already holds the sum of all ranks (the exchange is one-shot: "
+                                           "a second one would count every rank's frames again); gsdf_reset starts over");
     const size_t cap = c->n_slots / GSDF_BLOCK_VOX;
     const int R = tr.nranks;
-    /* 1. this rank's block ids */
-    dev_buf local, counts_dev;
-    HIP_TRY(local.alloc(cap * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
-    gsdf_launch_block_keys(c->stream, c->tab, cap, (unsigned long long*)local.p, c->counter, (long long)cap);
+    /* 1. this rank's block ids and frame count.  Failures up to the first all-gather travel in the header. */
+    dev_buf local, hdr_dev, scratch;
     unsigned long long n_local = 0;
-    HIP_TRY(hipMemcpyAsync(&n_local, c->counter, sizeof(n_local), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    /* the ranks' counts, then the id lists padded to the longest one */
-    HIP_TRY(counts_dev.alloc((size_t)(R + 1) * sizeof(long long)));
-    long long* cd = (long long*)counts_dev.p;
-    const long long mine = (long long)n_local;
-    HIP_TRY(hipMemcpyAsync(cd + R, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
-    int rc = tr.allgather(c, cd + R, cd, sizeof(long long));
+    gsdf_dev_state st_host;
+    std::memset(&st_host, 0, sizeof(st_host));
+    auto prepare = [&]() -> int {
+        HIP_TRY(local.alloc(cap * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
+        gsdf_launch_block_keys(c->stream, c->tab, cap, (unsigned long long*)local.p, c->counter, (long long)cap);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&n_local, c->counter, sizeof(n_local), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&st_host, c->st, sizeof(st_host), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return GSDF_OK;
+    };
+    const int prep = prepare();
+    if (prep) n_local = 0;
+    /* two small buffers are needed to talk at all: without them this rank cannot even report its failure */
+    HIP_TRY(hdr_dev.alloc((size_t)(R + 1) * sizeof(merge_hdr)));
+    HIP_TRY(scratch.alloc((size_t)(R + 1) * sizeof(long long)));
+    merge_hdr* hd = (merge_hdr*)hdr_dev.p;
+    const merge_hdr mine = { (long long)n_local, (long long)st_host.frames, (long long)(c->vis ? c->vis_words : 0), (long long)prep,
+                             random_token(c) };
+    HIP_TRY(hipMemcpyAsync(hd + R, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+    int rc = tr.allgather(c, hd + R, hd, sizeof(merge_hdr));
     if (rc) return rc;
-    std::vector<long long> counts((size_t)R);
-    HIP_TRY(hipMemcpyAsync(counts.data(), cd, (size_t)R * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    std::vector<merge_hdr> hdr((size_t)R);
+    HIP_TRY(hipMemcpyAsync(hdr.data(), hd, (size_t)R * sizeof(merge_hdr), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    long long m = 1;
-    for (long long v : counts) { if (v < 0 || (size_t)v > ((size_t)1 << 40)) return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: inconsistent block count from a rank"); m = std::max(m, v); }
+    if (prep) return prep;
+    /* from here on every decision is taken from the gathered headers, i.e. identically on all ranks */
+    long long m = 1, frames_total = 0, frames_before = 0;
+    int me = -1, dup = 0;
+    for (int r = 0; r < R; ++r) {
+        const merge_hdr& h = hdr[(size_t)r];
+        if (h.err) return gsdf_fail((int)h.err, "gsdf_merge_allreduce: rank " + std::to_string(r) + " failed to list its blocks");
+        if (h.n_blocks < 0 || (size_t)h.n_blocks > ((size_t)1 << 40) || h.frames < 0)
+            return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: inconsistent header from rank " + std::to_string(r));
+        if (h.vis_words != hdr[0].vis_words)
+            return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: gsdf_enable_vis must be called with the same frame count on every rank (or on none)");
+        for (int q = 0; q < r; ++q) dup |= hdr[(size_t)q].token == h.token;
+        if (h.token == mine.token) me = r;
+        m = std::max(m, h.n_blocks);
+        frames_total += h.frames;
+    }
+    if (dup || me < 0) return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: rank tokens collide (retry)");   /* seen by all ranks */
+    for (int r = 0; r < me; ++r) frames_before += hdr[(size_t)r].frames;
+    const int vw = (int)hdr[0].vis_words;
+    if (vw && frames_total > 32ll * vw)
+        return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: the ranks integrated " + std::to_string(frames_total) +
+                                           " frames, gsdf_enable_vis reserved " + std::to_string(32ll * vw) + " bits per voxel");
+    /* 2. the ranks' id lists, padded to the longest one */
     dev_buf padded, all;
-    HIP_TRY(padded.alloc((size_t)m * sizeof(unsigned long long)));
-    HIP_TRY(all.alloc((size_t)m * (size_t)R * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(padded.p, 0xFF, (size_t)m * sizeof(unsigned long long), c->stream));
-    if (n_local) HIP_TRY(hipMemcpyAsync(padded.p, local.p, (size_t)n_local * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+    auto alloc_lists = [&]() -> int {
+        HIP_TRY(padded.alloc((size_t)m * sizeof(unsigned long long)));
+        HIP_TRY(all.alloc((size_t)m * (size_t)R * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(padded.p, 0xFF, (size_t)m * sizeof(unsigned long long), c->stream));
+        if (n_local) HIP_TRY(hipMemcpyAsync(padded.p, local.p, (size_t)n_local * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+        return GSDF_OK;
+    };
+    rc = agree(c, tr, (long long*)scratch.p, alloc_lists(), "allocate its id list");
+    if (rc) return rc;
     rc = tr.allgather(c, padded.p, all.p, (size_t)m * sizeof(unsigned long long));
     if (rc) return rc;
     /* sorted union: a few 10^4 .. 10^5 ids (8 B each), host sort; every rank computes the same list */
@@ -170,24 +272,42 @@ int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<unsigned long long> uni;
     uni.reserve(ids.size());
-    for (int r = 0; r < R; ++r) uni.insert(uni.end(), ids.begin() + (size_t)r * m, ids.begin() + (size_t)r * m + (size_t)counts[(size_t)r]);
+    for (int r = 0; r < R; ++r) uni.insert(uni.end(), ids.begin() + (size_t)r * m, ids.begin() + (size_t)r * m + (size_t)hdr[(size_t)r].n_blocks);
     std::sort(uni.begin(), uni.end());
     uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
     const size_t nu = uni.size();
+    const size_t vis_count = nu * GSDF_BLOCK_VOX * (size_t)vw;
     if (n_blocks_out) *n_blocks_out = (int64_t)nu;
-    if (bytes_out) *bytes_out = (int64_t)(nu * GSDF_BLOCK_VOX * 5 * sizeof(float));
-    if (nu == 0) return GSDF_OK;
-    /* 2.-4. pack, all-reduce, unpack */
-    dev_buf union_dev, dense;
-    HIP_TRY(union_dev.alloc(nu * sizeof(unsigned long long)));
-    HIP_TRY(dense.alloc(nu * GSDF_BLOCK_VOX * 5 * sizeof(float)));
-    HIP_TRY(hipMemcpyAsync(union_dev.p, uni.data(), nu * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-    gsdf_launch_pack_blocks(c->stream, c->tab, (const unsigned long long*)union_dev.p, (long long)nu, (float*)dense.p);
-    HIP_TRY(hipGetLastError());
-    rc = tr.allreduce_sum_f32(c, (float*)dense.p, nu * GSDF_BLOCK_VOX * 5);
+    if (bytes_out) *bytes_out = (int64_t)(nu * GSDF_BLOCK_VOX * 5 * sizeof(float) + vis_count * sizeof(uint32_t));
+    /* 3. pack, all-reduce, unpack -- the sums, then the vis_ bit-vectors */
+    dev_buf union_dev, dense, dense_vis;
+    auto alloc_dense = [&]() -> int {
+        HIP_TRY(union_dev.alloc(nu * sizeof(unsigned long long)));
+        HIP_TRY(dense.alloc(nu * GSDF_BLOCK_VOX * 5 * sizeof(float)));
+        if (vw) HIP_TRY(dense_vis.alloc(vis_count * sizeof(uint32_t)));
+        if (nu) HIP_TRY(hipMemcpyAsync(union_dev.p, uni.data(), nu * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        return GSDF_OK;
+    };
+    rc = agree(c, tr, (long long*)scratch.p, alloc_dense(), "allocate the exchange buffers");
     if (rc) return rc;
-    gsdf_launch_unpack_blocks(c->stream, c->tab, (const unsigned long long*)union_dev.p, (long long)nu, (const float*)dense.p, c->st);
+    if (nu) {
+        const unsigned long long* uk = (const unsigned long long*)union_dev.p;
+        gsdf_launch_pack_blocks(c->stream, c->tab, uk, (long long)nu, (float*)dense.p);
+        if (vw) gsdf_launch_pack_vis(c->stream, c->tab, c->vis, vw, frames_before, uk, (long long)nu, (uint32_t*)dense_vis.p);
+        HIP_TRY(hipGetLastError());
+        rc = tr.allreduce_sum_f32(c, (float*)dense.p, nu * GSDF_BLOCK_VOX * 5);
+        if (rc) return rc;
+        if (vw) {
+            rc = tr.allreduce_or_u32(c, (uint32_t*)dense_vis.p, vis_count);
+            if (rc) return rc;
+        }
+        gsdf_launch_unpack_blocks(c->stream, c->tab, uk, (long long)nu, (const float*)dense.p, c->st);
+        if (vw) gsdf_launch_unpack_vis(c->stream, c->tab, c->vis, vw, uk, (long long)nu, (const uint32_t*)dense_vis.p);
+    }
+    /* Sdf::counter_ of the merged map: the frames of all ranks (frame f of rank r is integrated frame frames_before(r) + f) */
+    gsdf_launch_set_frames(c->stream, c->st, frames_total);
     HIP_TRY(hipGetLastError());
+    c->merged = R > 1;
     return read_status(c);                                    /* synchronises: the buffers above may go */
 }
 
@@ -214,6 +334,13 @@ int gsdf_rccl_comm_init(void** comm, int nranks, const char id128[128], int rank
     ncclComm_t cm = nullptr;
     RCCL_TRY(rccl().CommInitRank(&cm, nranks, id, rank));
     *comm = (void*)cm;
+    return GSDF_OK;
+}
+
+int gsdf_rccl_comm_count(void* comm, int* nranks) {
+    if (!comm || !nranks) return gsdf_fail(GSDF_ERR_INVALID, "null argument");
+    if (!rccl().ok) return gsdf_fail(GSDF_ERR_INVALID, rccl().why);
+    RCCL_TRY(rccl().CommCount((ncclComm_t)comm, nranks));
     return GSDF_OK;
 }
 

@@ -52,7 +52,21 @@ struct gsdf_table {
     unsigned long long* bkeys;        /* [block_mask + 1] */
     gsdf_payload* vox;                /* [(block_mask + 1) * 64] */
     uint32_t block_mask;              /* number of blocks - 1 (power of two) */
+    /* Block filter: one bit per block KEY, at a hashed position among 64 x n_blocks bits (512 KB at the 2^22-voxel default),
+     * set when the block is inserted.  A clear bit proves the block absent with ONE load; without it an unsuccessful lookup
+     * walks its probe sequence to the first empty entry (1.7 entries at 40 % load -- and a wave waits for the longest of its
+     * lanes' chains: 5-8 dependent L2 round trips per sample of the raycaster's empty-space walk, measured).  A set bit
+     * (present, or 1 in ~150 absent blocks at that load) is followed by the normal probe.  Lookups that mostly succeed
+     * (fusion flush) do not use it. */
+    uint32_t* occ;                    /* [(occ_mask + 1) / 32] */
+    uint32_t occ_mask;                /* number of filter bits - 1 (power of two) */
+    /* The same one level up: one bit per CELL of 8x8x8 blocks (32^3 voxels) that holds a block, among n_blocks bits (8 KB at
+     * the default: L1-resident).  A ray crossing empty space tests the cell of its sample and, when the bit is clear, knows
+     * every sample up to the cell's far face to be missing without looking at any of them (the raycaster's empty-space skip). */
+    uint32_t* occ2;                   /* [(occ2_mask + 1) / 32] */
+    uint32_t occ2_mask;
 };
+#define GSDF_CELL_SHIFT 5             /* voxels per cell edge = 32 */
 
 __host__ __device__ __forceinline__ bool gsdf_key_in_range(int x, int y, int z) {
     return x >= -GSDF_KEY_OFF && x < GSDF_KEY_OFF && y >= -GSDF_KEY_OFF && y < GSDF_KEY_OFF &&
@@ -99,7 +113,42 @@ __host__ __device__ __forceinline__ uint32_t gsdf_probe_step(unsigned long long 
     return (uint32_t)(gsdf_hash64(bk) >> 32) | 1u;
 }
 
+/* Position of a block in the filter, from its biased block coordinates ((v + 2^20) >> 2, 19 bits each -- the fields of a block
+ * key): a LATTICE hash, bx + C2 by + C3 bz (24-bit odd constants: two full-rate 24-bit multiply-adds; the walk through empty
+ * space evaluates it once per sample).  Neighbouring blocks never share a bit; blocks far apart alias at random, which only
+ * costs a wasted probe (a set bit is always followed by the real lookup). */
+__host__ __device__ __forceinline__ uint32_t gsdf_occ_index(const gsdf_table& T, uint32_t bx, uint32_t by, uint32_t bz) {
+    return (bx + by * 0x9E3779u + bz * 0x85EBCBu) & T.occ_mask;
+}
+__host__ __device__ __forceinline__ uint32_t gsdf_occ_bit(const gsdf_table& T, unsigned long long bk) {
+    return gsdf_occ_index(T, (uint32_t)(bk & 0x7FFFFull), (uint32_t)((bk >> 19) & 0x7FFFFull), (uint32_t)((bk >> 38) & 0x7FFFFull));
+}
+/* the same from voxel indices that passed gsdf_key_in_range */
+__host__ __device__ __forceinline__ uint32_t gsdf_occ_bit_vox(const gsdf_table& T, int x, int y, int z) {
+    return gsdf_occ_index(T, (uint32_t)(x + GSDF_KEY_OFF) >> 2, (uint32_t)(y + GSDF_KEY_OFF) >> 2, (uint32_t)(z + GSDF_KEY_OFF) >> 2);
+}
+
+/* position of a cell in the cell filter, from its biased cell coordinates ((v + 2^20) >> 5, 16 bits each) */
+__host__ __device__ __forceinline__ uint32_t gsdf_occ2_index(const gsdf_table& T, uint32_t cx, uint32_t cy, uint32_t cz) {
+    return (cx + cy * 0x6C8E95u + cz * 0xB5297Bu) & T.occ2_mask;
+}
+__host__ __device__ __forceinline__ uint32_t gsdf_occ2_bit_vox(const gsdf_table& T, int x, int y, int z) {
+    return gsdf_occ2_index(T, (uint32_t)(x + GSDF_KEY_OFF) >> GSDF_CELL_SHIFT, (uint32_t)(y + GSDF_KEY_OFF) >> GSDF_CELL_SHIFT,
+                           (uint32_t)(z + GSDF_KEY_OFF) >> GSDF_CELL_SHIFT);
+}
+
 #if defined(__HIPCC__)
+/* a block has been inserted: its bit in the block filter and its cell's bit in the cell filter */
+__device__ __forceinline__ void gsdf_occ_set(const gsdf_table& T, unsigned long long bk) {
+    const uint32_t bx = (uint32_t)(bk & 0x7FFFFull), by = (uint32_t)((bk >> 19) & 0x7FFFFull), bz = (uint32_t)((bk >> 38) & 0x7FFFFull);
+    const uint32_t b = gsdf_occ_index(T, bx, by, bz);
+    atomicOr(&T.occ[b >> 5], 1u << (b & 31u));
+    const uint32_t c = gsdf_occ2_index(T, bx >> (GSDF_CELL_SHIFT - 2), by >> (GSDF_CELL_SHIFT - 2), bz >> (GSDF_CELL_SHIFT - 2));
+    atomicOr(&T.occ2[c >> 5], 1u << (c & 31u));
+}
+/* false: the block is certainly absent */
+__device__ __forceinline__ bool gsdf_occ_test(uint32_t word, uint32_t bit) { return (word >> (bit & 31u)) & 1u; }
+
 /* Looks N block keys up TOGETHER: every round evaluates probe r of all pending keys and then issues probe r + 1 of those
  * still pending back to back, so a lane's N chains of dependent loads overlap (a wave's round count is the longest
  * chain of any of its lanes, not the sum over the N keys).  k[e] = the key already loaded from the home entry h[e]
@@ -121,7 +170,7 @@ __device__ __forceinline__ void gsdf_block_lookup_n(const gsdf_table& T, const u
             unsigned long long kk = k[e];
             if (INSERT && kk == GSDF_KEY_EMPTY) {
                 kk = atomicCAS(&T.bkeys[h[e]], GSDF_KEY_EMPTY, bk[e]);
-                if (kk == GSDF_KEY_EMPTY) kk = bk[e];
+                if (kk == GSDF_KEY_EMPTY) { kk = bk[e]; gsdf_occ_set(T, bk[e]); }      /* a new block: rare */
             }
             if (kk == bk[e]) { b[e] = (int)h[e]; pend &= ~(1u << e); }
             else if (!INSERT && kk == GSDF_KEY_EMPTY) pend &= ~(1u << e);   /* entries are never freed: an empty one ends the chain */

@@ -56,7 +56,7 @@ void FramePipeline::worker() {
         {
             std::lock_guard<std::mutex> lk(mu_);
             s->state = ok ? FILLED : FAILED;
-            if (!ok && error_.empty()) error_ = err;
+            if (!ok) s->error = err;                   /* reported when THIS frame is delivered, not before (the frames ahead of it are fine) */
         }
         cv_.notify_all();
     }
@@ -100,7 +100,12 @@ const float* FramePipeline::next(size_t* index) {
         }
         cv_.wait_for(lk, std::chrono::milliseconds(2));
     }
-    if (s.state == FAILED) { next_deliver_ = entries_.size(); return nullptr; }
+    if (s.state == FAILED) {
+        std::lock_guard<std::mutex> lk(mu_);
+        error_ = s.error;
+        next_deliver_ = entries_.size();
+        return nullptr;
+    }
     if (gsdf_dev_upload_async(ctx_, s.dev, s.host, (int64_t)W_ * H_ * (int64_t)sizeof(float)) != GSDF_OK) {
         error_ = std::string("upload: ") + gsdf_last_error();
         return nullptr;

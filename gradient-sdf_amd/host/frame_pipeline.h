@@ -46,7 +46,7 @@ public:
 
 private:
     enum State { FREE, DECODING, FILLED, FAILED, INFLIGHT };
-    struct Slot { float* host = nullptr; float* dev = nullptr; State state = FREE; size_t frame = 0; int64_t mark = 0; };
+    struct Slot { float* host = nullptr; float* dev = nullptr; State state = FREE; size_t frame = 0; int64_t mark = 0; std::string error; };
     void worker();
     void reclaim(bool block_oldest);
 
@@ -62,7 +62,7 @@ private:
     size_t next_deliver_ = 0;    /* next frame next() returns */
     long last_slot_ = -1;
     bool stop_ = false;
-    std::string error_;
+    std::string error_;          /* written and read by the consumer thread only (decode errors wait in their slot) */
 };
 
 #endif

@@ -18,6 +18,7 @@
  *   --transport shm   the exchange through host shared memory instead of RCCL: N ranks on ONE device (test boxes).
  * Only --scan-type grad-sdf exists here: base-sdf is the comparison method, out of scope.
  */
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -109,12 +110,28 @@ int launch_ranks(int argc, char** argv, const Options& opt) {
         if (pid < 0) { std::perror("fork"); return 1; }
         kids.push_back(pid);
     }
+    /* Wait for the ranks.  The first one that fails takes the others with it: the abort flag releases ranks that wait in a
+     * shared-memory barrier, and ranks that are stuck inside an RCCL collective (whose peer is gone) are killed after a short
+     * grace period -- by their exact pids. */
     int worst = 0;
-    for (pid_t pid : kids) {
+    size_t left = kids.size();
+    while (left > 0) {
         int st = 0;
-        waitpid(pid, &st, 0);
+        const pid_t pid = waitpid(-1, &st, 0);
+        if (pid < 0) break;
+        for (pid_t& k : kids) if (k == pid) { k = -1; --left; }
         const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
         if (code > worst) worst = code;
+        if (code != 0 && left > 0) {
+            std::cerr << "a rank exited with code " << code << ": stopping the other ranks" << std::endl;
+            ShmCollective::abort_all(name);
+            for (int t = 0; t < 40 && left > 0; ++t) {                       /* 2 s to leave on their own */
+                const pid_t q = waitpid(-1, &st, WNOHANG);
+                if (q > 0) { for (pid_t& k : kids) if (k == q) { k = -1; --left; } }
+                else std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            }
+            for (pid_t k : kids) if (k > 0) kill(k, SIGKILL);
+        }
     }
     ShmCollective::destroy(name);
     std::remove(("/dev/shm/" + name + ".id").c_str());
@@ -136,51 +153,74 @@ void write_pose_line(std::ofstream& f, const std::string& ts, const Mat4f& p) {
     f << ts << " " << p(0, 3) << " " << p(1, 3) << " " << p(2, 3) << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
 }
 
+/* --gpus N: what the exchange needs, set up BEFORE the frame loop (outside anything timed, and so that a rank that cannot
+ * join fails before its peers have fused their shards): the rendezvous segment, and for RCCL the communicator -- rank 0
+ * publishes the id as a file next to the segment first thing, the other ranks poll for it (giving up when the abort flag
+ * is raised or after the barrier timeout). */
+struct Exchange {
+    std::unique_ptr<ShmCollective> seg;
+    void* comm = nullptr;
+    ~Exchange() { if (comm) gsdf_rccl_comm_destroy(comm); }
+};
+bool exchange_prepare(Exchange& ex, const Options& opt, int device) {
+    ex.seg.reset(new ShmCollective(opt.rendezvous, opt.gpus, opt.rank));
+    if (!ex.seg->ok()) { std::cerr << "rank " << opt.rank << ": rendezvous segment missing" << std::endl; return false; }
+    if (opt.transport == "shm") return true;
+    const std::string idf = "/dev/shm/" + opt.rendezvous + ".id";
+    char id[128];
+    if (opt.rank == 0) {
+        if (gsdf_rccl_unique_id(id) != GSDF_OK) { std::cerr << "RCCL: " << gsdf_last_error() << std::endl; return false; }
+        { std::ofstream f(idf + ".tmp", std::ios::binary); f.write(id, 128); }
+        std::rename((idf + ".tmp").c_str(), idf.c_str());
+    } else {
+        bool got = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!got && !ex.seg->aborted() && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 300.0) {
+            std::ifstream f(idf, std::ios::binary);
+            got = (bool)f.read(id, 128);
+            if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        if (!got) { std::cerr << "rank " << opt.rank << ": no RCCL id from rank 0" << std::endl; return false; }
+    }
+    if (gsdf_rccl_comm_init(&ex.comm, opt.gpus, id, opt.rank, device) != GSDF_OK) { std::cerr << "RCCL: " << gsdf_last_error() << std::endl; return false; }
+    return true;
+}
+
 /* the exchange step of --gpus N */
-bool exchange(gsdf_ctx* ctx, const Options& opt, int device) {
+bool exchange(Exchange& ex, gsdf_ctx* ctx, const Options& opt) {
     int64_t n_blocks = 0, bytes = 0;
     if (opt.transport == "shm") {
-        ShmCollective sc(opt.rendezvous, opt.gpus, opt.rank);
-        if (!sc.ok()) { std::cerr << "rank " << opt.rank << ": rendezvous segment missing" << std::endl; return false; }
-        gsdf_collective ops = sc.ops();
+        gsdf_collective ops = ex.seg->ops();
         if (gsdf_merge_allreduce_with(ctx, &ops, &n_blocks, &bytes) != GSDF_OK) { std::cerr << "exchange: " << gsdf_last_error() << std::endl; return false; }
     } else {
-        /* rank 0 creates the RCCL id and publishes it as a file next to the rendezvous segment */
-        const std::string idf = "/dev/shm/" + opt.rendezvous + ".id";
-        char id[128];
-        if (opt.rank == 0) {
-            if (gsdf_rccl_unique_id(id) != GSDF_OK) { std::cerr << "RCCL: " << gsdf_last_error() << std::endl; return false; }
-            { std::ofstream f(idf + ".tmp", std::ios::binary); f.write(id, 128); }
-            std::rename((idf + ".tmp").c_str(), idf.c_str());
-        } else {
-            bool got = false;
-            for (int t = 0; t < 60000 && !got; ++t) {
-                std::ifstream f(idf, std::ios::binary);
-                got = (bool)f.read(id, 128);
-                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(1));
-            }
-            if (!got) { std::cerr << "rank " << opt.rank << ": no RCCL id from rank 0" << std::endl; return false; }
-        }
-        void* comm = nullptr;
-        if (gsdf_rccl_comm_init(&comm, opt.gpus, id, opt.rank, device) != GSDF_OK) { std::cerr << "RCCL: " << gsdf_last_error() << std::endl; return false; }
         Timer T;
         T.tic();
-        const int rc = gsdf_merge_allreduce(ctx, comm, &n_blocks, &bytes);
+        const int rc = gsdf_merge_allreduce(ctx, ex.comm, &n_blocks, &bytes);
         if (opt.rank == 0) T.toc("Exchange without communicator set-up");
-        gsdf_rccl_comm_destroy(comm);
         if (rc != GSDF_OK) { std::cerr << "exchange: " << gsdf_last_error() << std::endl; return false; }
     }
     if (opt.rank == 0)
         std::cout << "Exchanged " << n_blocks << " voxel blocks (" << bytes / 1048576.0 << " MiB all-reduced) among " << opt.gpus << " ranks" << std::endl;
     return true;
 }
+
+int run(int argc, char* argv[], Options& opt);
 } // namespace
 
 int main(int argc, char* argv[]) {
-    Timer T;
     Options opt;
     if (!parse(argc, argv, opt)) return 1;
     if (opt.gpus > 1 && opt.rank < 0) return launch_ranks(argc, argv, opt);      /* the launcher itself never touches the GPU */
+    const int rc = run(argc, argv, opt);
+    /* a rank that leaves early must not leave its peers waiting for it (barriers see the flag; the launcher stops ranks
+     * that hang inside RCCL) */
+    if (rc != 0 && opt.gpus > 1 && !opt.rendezvous.empty()) ShmCollective::abort_all(opt.rendezvous);
+    return rc;
+}
+
+namespace {
+int run(int, char**, Options& opt) {
+    Timer T;
     const bool sharded = opt.gpus > 1;
     const bool lead = !sharded || opt.rank == 0;                                  /* writes the outputs */
     if (sharded && opt.transport != "shm") opt.device = opt.rank;                 /* one GPU per rank */
@@ -288,6 +328,8 @@ int main(int argc, char* argv[]) {
         if (all.empty()) { std::cerr << " -> Frame " << opt.first << " could not be loaded!" << std::endl << "no frame was processed" << std::endl; return 1; }
         size_t lo = 0, hi = all.size();
         if (sharded) shard_range(all.size(), opt.rank, opt.gpus, &lo, &hi);
+        Exchange ex;
+        if (sharded && !exchange_prepare(ex, opt, opt.device)) return 1;
         T.tic();
         tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device));
         if (lead) T.toc("Create Sdf");
@@ -333,7 +375,7 @@ int main(int argc, char* argv[]) {
         }
         if (sharded) {
             T.tic();
-            if (!exchange(ctx, opt, opt.device)) return 1;
+            if (!exchange(ex, ctx, opt)) return 1;
             if (lead) T.toc("Exchange voxel sums between the ranks");
         }
         if (lead) {
@@ -370,3 +412,4 @@ int main(int argc, char* argv[]) {
     }
     return 0;
 }
+} // namespace

@@ -22,7 +22,11 @@ public:
     ~ShmCollective();
     bool ok() const { return seg_ != nullptr; }
     gsdf_collective ops();                       /* callbacks bound to this object */
+    /* false = aborted: a rank raised the flag (it failed), or a peer did not arrive within GSDF_SHM_TIMEOUT_S (default 300 s) */
     bool barrier();
+    void abort();                                /* this rank gives up: release every rank that waits in a barrier */
+    bool aborted() const;
+    static void abort_all(const std::string& name);   /* the same from the launcher */
 
 private:
     static int allgather_cb(void* user, const void* send, void* recv, int64_t bytes);

@@ -173,12 +173,20 @@ int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t 
  * GT-pose branch, main_scan_3d.cpp:250-254); on return every rank's map is the sum of all maps.  Steps: all-gather of the
  * block ids, sorted union, gsdf pack, ONE ncclAllReduce (sum, float32, 1280 B per block of the union) on the context's own
  * stream, gsdf unpack.  nccl_comm: an ncclComm_t of the RCCL already in the process (RCCL is resolved at run time, it is
- * not a link dependency of libgsdf.so).  n_blocks / bytes (nullable): size of the union / of the all-reduced buffer. */
+ * not a link dependency of libgsdf.so).  n_blocks / bytes (nullable): size of the union / of the all-reduced buffers.
+ * Also exchanged: Sdf::counter_ (Sdf.h:65) -- afterwards the frames integrated by ALL ranks -- and, when gsdf_enable_vis was
+ * called (on every rank, with the frame count of the WHOLE job), the vis_ bit-vectors (MapGradPixelSdf.cpp:113-115): the
+ * frame shards are contiguous in rank order, so frame f of rank r becomes integrated frame (frames of the ranks < r) + f and
+ * the ranks' shifted vectors are OR-ed (a second all-reduce, unsigned words): the merged map is what PhotoBA needs (C4 -> C5).
+ * ONE-SHOT: after the call every map IS the sum, so a second exchange over more than one rank is refused (GSDF_ERR_INVALID)
+ * until gsdf_reset.  Failures are collective: a rank that cannot prepare its part reports that through the first all-gather
+ * and every rank returns the error, none is left waiting inside a collective. */
 int gsdf_merge_allreduce(gsdf_ctx* c, void* nccl_comm, int64_t* n_blocks, int64_t* bytes);
 /* communicator plumbing for hosts that do not link RCCL themselves (the Scan3D CLI): ncclGetUniqueId / ncclCommInitRank
  * (on `device`) / ncclCommDestroy.  Create the communicator once, outside any timed region. */
 int gsdf_rccl_unique_id(char id128[128]);
 int gsdf_rccl_comm_init(void** nccl_comm, int nranks, const char id128[128], int rank, int device);
+int gsdf_rccl_comm_count(void* nccl_comm, int* nranks);       /* ncclCommCount: ranks of the communicator */
 int gsdf_rccl_comm_destroy(void* nccl_comm);
 /* The same exchange over a caller-provided transport: two collectives on HOST buffers (libgsdf stages the device data).
  * Used where RCCL cannot run (two ranks on one GPU in the tests) or where the host has its own communication layer.
@@ -208,6 +216,14 @@ int gsdf_get_voxels(gsdf_ctx* c, const int32_t* keys_host, int64_t n, float* pay
  * tracker's back-projection (RigidPointOptimizer.cpp:46-47,67-70); DESIGN.md states the definition. */
 int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
                  float* depth_out, float* normals_out);
+
+/* the same with DEVICE output buffers (depth W*H floats, normals 3*W*H floats or NULL); enqueue only */
+int gsdf_raycast_dev(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
+                     float* depth_dev, float* normals_dev);
+/* what the raycasts since the last reset did: samples their definition evaluated (one block-key probe each) and voxel records
+ * read -- the algorithmic bytes of the raycaster's roofline entry are 8 B per sample + 32 B per record + 16 B per pixel.
+ * Synchronises; reset != 0 clears the counters. */
+int gsdf_raycast_counters(gsdf_ctx* c, int64_t* samples, int64_t* records, int reset);
 
 /* Iso-surface of the map on the device -- LayeredMarchingCubesNoColor::computeIsoSurface + computeLutIndex + interpolate +
  * computeTriangles (mesh/LayeredMarchingCubesNoColor.cpp:354-712), called by MapGradPixelSdf::extract_mesh
@@ -241,6 +257,8 @@ int gsdf_timer_stop_ms(gsdf_ctx* c, float* ms);          /* synchronises */
  * index 0 normals, 1 fusion, 2 tracking pass.  Enabled by gsdf_profile(c, 1). */
 int gsdf_profile(gsdf_ctx* c, int enable);
 int gsdf_profile_read(gsdf_ctx* c, double ms[3], int64_t launches[3]);
+/* the first n <= 5 slots: 0 normals, 1 fusion, 2 tracking pass launches, 3 raycast, 4 reserved */
+int gsdf_profile_read_n(gsdf_ctx* c, int n, double* ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

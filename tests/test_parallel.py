@@ -118,6 +118,7 @@ def _gpu_worker(rank, world, port, out_dir):
     seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=9, step_deg=3.0)
     vs = np.float32(0.02)
     g = pkg.GradSdf(vs, np.float32(5) * vs, W, H, seq.K, capacity_log2=20, device=0)
+    g.enable_vis(40)                                     # vis_ takes part in the exchange (bits = frames of ALL ranks)
     lo, hi = pkg.parallel.shard_range(n, rank, world)
     for i in range(lo, hi):
         g.update(*seq.frame(i))
@@ -136,7 +137,15 @@ def _gpu_worker(rank, world, port, out_dir):
     own = g.count()
     n_blocks, nbytes = g.merge_allreduce_with(allgather, allreduce, world)
     keys, pay = g.export(sorted=True, raw=True)
-    np.savez(os.path.join(out_dir, "gpu_rank%d.npz" % rank), keys=keys, pay=pay, own=own, n_blocks=n_blocks, nbytes=nbytes)
+    kv, vis = g.export_vis()
+    frames = g.stats()["frames"]
+    again = ""
+    try:
+        g.merge_allreduce_with(allgather, allreduce, world)          # one-shot: a second exchange would double every sum
+    except pkg.binding.GsdfError as e:
+        again = str(e)
+    np.savez(os.path.join(out_dir, "gpu_rank%d.npz" % rank), keys=keys, pay=pay, own=own, n_blocks=n_blocks, nbytes=nbytes,
+             vis_keys=kv, vis=vis, frames=frames, again=again)
     g.close()
     dist.destroy_process_group()
 
@@ -151,7 +160,7 @@ def test_merge_allreduce_c_entry_world2_on_one_gpu(pkg, O, tmp_path):
     a = np.load(tmp_path / "gpu_rank0.npz")
     b = np.load(tmp_path / "gpu_rank1.npz")
     assert np.array_equal(a["keys"], b["keys"]) and np.array_equal(a["pay"], b["pay"])   # every rank holds the same sums
-    assert int(a["n_blocks"]) == int(b["n_blocks"]) > 100 and int(a["nbytes"]) == int(a["n_blocks"]) * 64 * 5 * 4
+    assert int(a["n_blocks"]) == int(b["n_blocks"]) > 100 and int(a["nbytes"]) == int(a["n_blocks"]) * 64 * (5 * 4 + 2 * 4)
     assert int(a["own"]) < len(a["keys"]) and int(b["own"]) < len(a["keys"])             # the shards really differed
     W, H, n = 320, 240, 8
     seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=9, step_deg=3.0)
@@ -166,13 +175,21 @@ def test_merge_allreduce_c_entry_world2_on_one_gpu(pkg, O, tmp_path):
     assert (np.abs(w - pay[:, 4]) / scale).max() <= 1e-4
     assert np.abs(a["pay"][:, 0] / w - pay[:, 0]).max() <= 1e-4
     assert (np.abs(a["pay"][:, 1:4] - pay[:, 1:4]).max(axis=1) / scale).max() <= 1e-4
+    # vis_ and Sdf::counter_ are part of the exchange (MapGradPixelSdf.cpp:113-115, SURVEY.md 8e "vis = OR of frame bits"):
+    # rank 1's frames 0..3 are integrated frames 4..7 of the merged map; both ranks end with the oracle's bit-vectors
+    assert int(a["frames"]) == int(b["frames"]) == n == o.frame_counter()
+    assert np.array_equal(a["vis_keys"], keys) and np.array_equal(b["vis_keys"], keys)
+    vo = o.export_vis(2)
+    assert np.array_equal(a["vis"], vo) and np.array_equal(b["vis"], vo)
+    assert (vo[:, 0] >> 4).any() and (vo[:, 0] & 0xF).any()                              # bits of both shards are present
+    assert "one-shot" in str(a["again"]) and "one-shot" in str(b["again"])               # re-merging is refused on every rank
 
 
 @pytest.mark.gpu
 def test_merge_allreduce_over_rccl_one_rank(pkg):
     """gsdf_merge_allreduce over a real RCCL communicator (gsdf_rccl_comm_init; one rank -- the box has one GPU): block ids,
     pack, ncclAllGather / ncclAllReduce on the context's stream, unpack.  With one rank the map must come back unchanged,
-    bit for bit; a second call finds the same union."""
+    bit for bit; a second call finds the same union (with ONE rank the exchange is the identity, so it may be repeated)."""
     W, H = 320, 240
     seq = pkg.synth.Sequence("tum", W, H, n_frames=4, seed=1)
     vs = np.float32(0.01)
@@ -193,3 +210,51 @@ def test_merge_allreduce_over_rccl_one_rank(pkg):
     finally:
         pkg.binding.rccl_comm_destroy(comm)
     g.close()
+
+
+# ---- bench.py --gpus N: the launch path ---------------------------------------------------------------------------------
+
+def _run_bench(extra, timeout=900):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_n_starts_n_ranks_dry():
+    """`python bench.py --gpus N` without a launcher starts N rank processes itself (the driver's command shape); each rank
+    checks WORLD_SIZE == --gpus, they rendezvous, and only rank 0 prints."""
+    out = _run_bench(["--gpus", "3", "--dry-run"], timeout=300)
+    assert out == {"dry_run": True, "n_gpus": 3, "max_over_ranks": 3.0, "local_rank": 0}
+
+
+def test_bench_rejects_world_size_mismatch():
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=2 but --gpus 4" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(pkg):
+    """The N > 1 path of bench.py end to end on a one-GPU box: two self-started ranks share device 0, replicas of the tracked
+    stream + the sharded GT-pose flavour with ONE exchange (gsdf_merge_allreduce_with over gloo: RCCL refuses two ranks on one
+    device), one JSON line from rank 0."""
+    out = _run_bench(["--gpus", "2", "--single-device", "--dist-backend", "gloo", "--steps", "6", "--warmup", "3", "--repeats", "2",
+                      "--c4-frames", "12", "--raycast-reps", "2", "--cpu-frames", "0"])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "weak" and out["value"] > 0
+    assert len(out["config"]["value_runs"]) == 2
+    sh = out["config"]["sharded"]
+    assert "error" not in sh, sh
+    assert sh["ranks"] == 2 and sh["frames_total"] == 24 and sh["frames_counter_after_merge"] == 24
+    assert sh["exchange_blocks"] > 100 and sh["exchange_bytes"] == sh["exchange_blocks"] * 64 * 5 * 4
+    assert sh["voxels_merged"] > sh["voxels_own_shard"] and sh["mesh_faces"] > 1000
+    assert out["roofline"]["raycast"]["avg_launch_us"] > 0 and out["roofline"]["raycast"]["hit_fraction"] > 0.5
+    assert out["cpu_baseline"] is None                               # rank 0 at N = 1 only

@@ -18,7 +18,7 @@ for root in args:
             acc[r["Kernel_Name"].split("(")[0].replace("void ", "")[:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
-    if not (k.startswith("k_fuse") or k.startswith("k_track") or k.startswith("k_normals")):
+    if not (k.startswith("k_fuse") or k.startswith("k_track") or k.startswith("k_normals") or k.startswith("k_raycast")):
         continue
     res[k] = {}
     for c, v in sorted(d.items()):
