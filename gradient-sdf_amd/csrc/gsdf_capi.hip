@@ -65,6 +65,9 @@ void prof_collect(gsdf_ctx* c) {
 int status_to_code(int status) {
     if (status & GSDF_STATUS_TABLE_FULL) return fail(GSDF_ERR_TABLE_FULL, "voxel hash table full (probe budget exhausted)");
     if (status & GSDF_STATUS_KEY_RANGE) return fail(GSDF_ERR_KEY_RANGE, "voxel index outside the packable +-2^20 range");
+    if (status & GSDF_STATUS_TRACK_ABORT)
+        return fail(GSDF_ERR_HIP, "tracking: the workgroups of the one-launch optimize() were not co-resident (GPU shared with another "
+                                  "process?); that optimize() was abandoned -- set GSDF_PERSIST=0 to use one launch per pass");
     return GSDF_OK;
 }
 
@@ -175,6 +178,24 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     tp.progress = adaptive ? c->progress_dev : nullptr;
     tp.debug = c->debug >> 16;
     tp.n_track_blocks = c->track_blocks;
+    if (c->persist && c->track_rows && c->track_blocks <= 2 * GSDF_TRACK_MAXBLK) {
+        /* the whole optimize() as one launch; the frame's fusion, gated on the device by done && converged, right behind it */
+        tp.pass_index = 0;
+        tp.rot = 0;
+        tp.progress = c->progress_dev;
+        {
+            prof_scope ps(c, 2);
+            gsdf_launch_track_all(c->stream, g, depth_dev, c->tab, c->st, c->track_rows, c->track_abort, c->track_blocks, tp,
+                                  fuse_after ? &nj : nullptr);
+        }
+        if (fuse_after) {
+            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true);               /* main_scan_3d.cpp:261-265 */
+            if (rc) return rc;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("tracking launch: ") + hipGetErrorString(e));
+        return GSDF_OK;
+    }
     int k = 0;
     int batch = adaptive ? c->first_batch : iters + 1;
     while (k <= iters) {
@@ -317,6 +338,7 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         if (env) c->adaptive = atoi(env);
         if ((env = getenv("GSDF_FIRST_BATCH")) && atoi(env) >= 2) c->first_batch = atoi(env);
         if ((env = getenv("GSDF_NEXT_BATCH")) && atoi(env) >= 1) c->next_batch = atoi(env);
+        if ((env = getenv("GSDF_PERSIST"))) c->persist = atoi(env);
         if ((env = getenv("GSDF_FAR_TABLE"))) c->far_table = atoi(env);       /* experiments: 0 / 1 pin the fusion kernel's table size */
     }
     int rc = gsdf_reset(c);
@@ -334,7 +356,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->mark_pool) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.second);
-    void* ptrs[] = { c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
+    void* ptrs[] = { c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -378,8 +400,9 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     void* old[] = { c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log, c->deferred,
-                    c->deferred_count, c->tile_flags, c->tile_order, c->fuse_ticket };
+                    c->deferred_count, c->tile_flags, c->tile_order, c->fuse_ticket, c->track_rows, c->track_abort };
     for (void* p : old) if (p) (void)hipFree(p);
+    c->track_rows = nullptr; c->track_abort = nullptr;
     c->tile_flags = nullptr; c->tile_order = nullptr;
     c->planes = c->depth_stage = c->normals = nullptr; c->partials = nullptr;
     c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr; c->fuse_ticket = nullptr;
@@ -395,6 +418,12 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipMalloc((void**)&c->partials, (size_t)3 * GSDF_TRACK_ROWSET * sizeof(double)));
     HIP_TRY(hipMemsetAsync(c->partials, 0, (size_t)3 * GSDF_TRACK_ROWSET * sizeof(double), c->stream));
     c->track_rot = 0;
+    if (c->track_blocks <= 2 * GSDF_TRACK_MAXBLK) {
+        HIP_TRY(hipMalloc(&c->track_rows, gsdf_track_all_rows_bytes(c->track_blocks)));
+        HIP_TRY(hipMemsetAsync(c->track_rows, 0, gsdf_track_all_rows_bytes(c->track_blocks), c->stream));
+        HIP_TRY(hipMalloc((void**)&c->track_abort, sizeof(unsigned int)));
+        HIP_TRY(hipMemsetAsync(c->track_abort, 0, sizeof(unsigned int), c->stream));
+    }
     c->fuse_blocks = gsdf_fuse_grid_blocks(W, H);
     HIP_TRY(hipMalloc((void**)&c->blk_counters, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));

@@ -51,6 +51,9 @@ struct gsdf_ctx {
     double* partials = nullptr;                    /* 3 rotating buffers of tracker partial sums */
     unsigned int track_rot = 0;                    /* tracker launches issued so far, mod 3 (selects the sum buffers) */
     int track_blocks = 0;
+    void* track_rows = nullptr;                    /* k_track_all: the workgroups' rows of sums, two buffers (pass parity) */
+    unsigned int* track_abort = nullptr;           /* k_track_all: abort word */
+    int persist = 0;                               /* optimize() as one launch (k_track_all) instead of one launch per pass */
     unsigned long long* blk_counters = nullptr;
     int fuse_blocks = 0;
     gsdf_deferred* deferred = nullptr;

@@ -11,6 +11,7 @@
 
 #define GSDF_STATUS_TABLE_FULL 1
 #define GSDF_STATUS_KEY_RANGE  2
+#define GSDF_STATUS_TRACK_ABORT 4   /* k_track_all: the workgroups of the one-launch optimize() were not co-resident (GPU shared with another process) */
 
 #ifndef GSDF_TRACK_BLOCK
 #define GSDF_TRACK_BLOCK   512
@@ -123,6 +124,12 @@ void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st);
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
                             gsdf_dev_state* st, double* partials /* 3 * GSDF_TRACK_ROWSET, zeroed */, int n_blocks,
                             const gsdf_track_params& tp, const gsdf_normals_job* normals /* nullable */);
+/* optimize() as ONE launch (k_track_all): n_blocks co-resident workgroups exchange their sums through `rows`
+ * (gsdf_track_all_rows_bytes(n_blocks), zeroed once); n_blocks <= 2 * GSDF_TRACK_MAXBLK */
+void gsdf_launch_track_all(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab, gsdf_dev_state* st,
+                           void* rows, unsigned int* abort_word /* device word, zeroed once */, int n_blocks,
+                           const gsdf_track_params& tp, const gsdf_normals_job* normals /* nullable */);
+size_t gsdf_track_all_rows_bytes(int n_blocks);
 void gsdf_launch_set_pose(hipStream_t s, gsdf_dev_state* st, const float* pose7_dev_or_null,
                           const float pose7_host[7]);
 void gsdf_launch_export(hipStream_t s, gsdf_table tab, size_t n_slots, unsigned long long* keys_out,

@@ -1472,6 +1472,226 @@ void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float
     hipLaunchKernelGGL(k_track_pass, dim3(n_blocks + extra), dim3(GSDF_TRACK_BLOCK), dyn, s, g, depth, tab, st, partials, tp, nj);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * RigidPointOptimizer::optimize_sampled as ONE launch: k_track_all.
+ *
+ * The per-pass launches above pay, per Gauss-Newton pass, the launch gap (1.4 us), the head's memory round trip for the
+ * group sums (1.5-2 us), the f64 atomics of the previous pass (1.5 us) and a gather from cold L2s (the per-XCD L2s are
+ * invalidated at every kernel boundary).  Here the 256 workgroups (one per CU, co-resident) stay for the whole optimize():
+ *  - a lane keeps the depth of its pixels in registers; voxel records and block keys stay in the XCD's L2 between passes;
+ *  - the exchange of a pass uses NO atomics and NO separate flag: every workgroup stores its 29 sums as ONE ROW of ten
+ *    16-byte chunks {sum, sum, sum, tag} (tag = optimize() serial and pass number; one wave instruction, agent scope) and
+ *    then reads ALL rows (5 chunks per lane) until every chunk carries the tag of this pass.  A 16-byte chunk is written
+ *    and read whole, so a chunk with the right tag holds the right sums: no ordering between data and flag is needed, which
+ *    is what made the atomics-and-ticket variants of rounds 1-2 slower than relaunching (each ordering point is a 1.5 us
+ *    round trip).  One hop: the last workgroup's store -> everybody's next poll.
+ *  - every workgroup then adds the rows in the same fixed order (double), solves the 6x6 system and updates the pose:
+ *    bit-identical everywhere, so no result has to be broadcast.  Rows are double-buffered by pass parity (a workgroup can
+ *    be at most one pass ahead of the slowest one).
+ * The wait for rows is bounded (the workgroups must be co-resident: guaranteed on an otherwise idle GPU, 256 workgroups
+ * of 512 lanes on 256 CUs; another process on the same GPU can break it): a workgroup that waits longer than 50 ms raises
+ * the abort word, everybody leaves, and the sticky status bit GSDF_STATUS_TRACK_ABORT makes gsdf_sync fail loudly.
+ * The normals of the frame are computed by extra workgroups of the same launch, as in the per-pass path.
+ * ---------------------------------------------------------------------------------------------- */
+#define TRK_ROW_CHUNKS 10                 /* 29 sums + 1 spare in chunks of 3 + tag */
+__device__ __forceinline__ gsdf_u32x4 trk_load_chunk(const gsdf_u32x4* p) {
+    gsdf_u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int MAXB>       /* workgroups the row exchange is sized for: a lane reads MAXB * 10 / 512 chunks per poll */
+__global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_all(gsdf_frame_geom g, const float* __restrict__ depth, gsdf_table tab,
+                                                                gsdf_dev_state* st, gsdf_u32x4* rows /* [2][n_track_blocks][TRK_ROW_CHUNKS] */,
+                                                                unsigned int* abort_word, gsdf_track_params tp, gsdf_normals_job nj) {
+    if ((int)blockIdx.x >= tp.n_track_blocks) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+        const int t = (int)blockIdx.x - tp.n_track_blocks;
+        if (t == 0 && threadIdx.x == 0) {
+            *nj.deferred_count = 0u;                            /* fresh list for the k_fuse of this frame */
+            st->frame_cur = st->frames;                         /* counter_ seen by every workgroup of k_fuse */
+        }
+        normals_tile(*reinterpret_cast<nrm_lds*>(dyn_lds), t % nj.ntx, t / nj.ntx, g.W, g.H, nj.r, nj.nc, depth, nj.nx, nj.ny, nj.nz);
+        return;
+    }
+    constexpr int NW = GSDF_TRACK_BLOCK / 64;
+    __shared__ float wsum[NW][32];
+    __shared__ double part[16][32];
+    /* the rows of a pass as floats, [n_track_blocks][30]: in the dynamic LDS region (the normals workgroups of this launch
+     * use the same region for their tile; static LDS would be charged to both roles and keep them from sharing a CU) */
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds_t[];
+    float (*rowv)[3 * TRK_ROW_CHUNKS] = reinterpret_cast<float (*)[3 * TRK_ROW_CHUNKS]>(dyn_lds_t);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = tp.n_track_blocks;
+    const int n_chunks = nb * TRK_ROW_CHUNKS;
+    unsigned long long* trk_tr = nullptr;
+    if (GSDF_EXPERIMENT(tp.debug, 64) && blockIdx.x < 512u)
+        trk_tr = reinterpret_cast<unsigned long long*>(st->dbg[23]) + 16 * (2048 + (size_t)blockIdx.x);
+    /* the depth of this lane's (first) pixels: loaded once, kept across the passes */
+    float z_pre[TRK_PPT];
+    {
+        const int N = g.W * g.H, base0 = (int)blockIdx.x * GSDF_TRACK_BLOCK + tid, nthreads = nb * GSDF_TRACK_BLOCK;
+#pragma unroll
+        for (int j = 0; j < TRK_PPT; ++j) {
+            const int pix = base0 + j * nthreads;
+            z_pre[j] = pix < N ? depth[pix] : 0.f;
+        }
+    }
+    float pose[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = st->pose7[i];                    /* RigidOptimizer::pose_ (kept in st->pose7 between frames) */
+    int done = 0, converged = 0, passes = 0;
+    float hits = 0.f;
+    unsigned long long hit_total = 0ull;
+    bool aborted = false;
+    for (int k = 0; k < tp.max_passes && !done; ++k) {
+        if (trk_tr && tid == 0 && k < 12) trk_tr[16 * 512 * k + 0] = wall_clock64();
+        /* ---- gather + normal-equation sums of pass k with the current pose ---- */
+        float acc[GSDF_TRACK_NSUM];
+#pragma unroll
+        for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
+        trk_gather(g, tab, depth, z_pre, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, nb * GSDF_TRACK_BLOCK, acc);
+        if (trk_tr && tid == 0 && k < 12) trk_tr[16 * 512 * k + 1] = wall_clock64();        /* wave 0: gather done */
+        wave_sum_to_lane63(acc);
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < GSDF_TRACK_NSUM; ++i) wsum[wave][i] = acc[i];
+        }
+        __syncthreads();
+        /* ---- this workgroup's row: ten chunks {3 sums, tag}, one store instruction ---- */
+        const uint32_t tag = (tp.serial << 8) | (uint32_t)(k + 1);
+        gsdf_u32x4* buf = rows + (size_t)(k & 1) * (size_t)n_chunks;
+        if (tid < TRK_ROW_CHUNKS) {
+            float v3[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int i = 3 * tid + q;
+                float v = 0.f;
+                if (i < GSDF_TRACK_NSUM) {
+                    v = wsum[0][i];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) v += wsum[w][i];           /* float, fixed order */
+                }
+                v3[q] = v;
+            }
+            const gsdf_u32x4 c = { __float_as_uint(v3[0]), __float_as_uint(v3[1]), __float_as_uint(v3[2]), tag };
+            gsdf_u32x4* dst = buf + (size_t)blockIdx.x * TRK_ROW_CHUNKS + tid;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(c) : "memory");
+        }
+        if (trk_tr && tid == 0 && k < 12) trk_tr[16 * 512 * k + 2] = wall_clock64();        /* row stored */
+        /* ---- all rows of pass k: poll until every chunk this lane reads carries the tag ---- */
+        constexpr int PER = (MAXB * TRK_ROW_CHUNKS + GSDF_TRACK_BLOCK - 1) / GSDF_TRACK_BLOCK;   /* chunks per lane at most */
+        gsdf_u32x4 ch[PER];
+        const unsigned long long t0 = wall_clock64();
+        unsigned int rounds = 0u;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int c = tid + GSDF_TRACK_BLOCK * i;
+                ch[i] = gsdf_u32x4{ 0u, 0u, 0u, tag };
+                if (c < n_chunks) ch[i] = trk_load_chunk(buf + c);
+            }
+            /* hipcc does not track the loads issued from inline asm: each wait statement names a destination register, so
+             * no use of it can be scheduled before the data has arrived (the first wait drains all, the others cost nothing) */
+#pragma unroll
+            for (int i = 0; i < PER; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ch[i]) :: "memory");
+#pragma unroll
+            for (int i = 0; i < PER; ++i) ok = ok && ch[i].w == tag;
+            ++rounds;
+            if (__syncthreads_and(ok ? 1 : 0)) break;
+            /* bounded: co-residency is a property of the launch environment, not of this code */
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tp.serial || wall_clock64() - t0 > 5000000ull) {
+                aborted = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (aborted) {
+            if (tid == 0) {
+                __hip_atomic_store(abort_word, tp.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(&st->status, GSDF_STATUS_TRACK_ABORT);
+            }
+            break;
+        }
+        if (trk_tr && tid == 0 && k < 12) { trk_tr[16 * 512 * k + 3] = wall_clock64(); trk_tr[16 * 512 * k + 6] = rounds; }   /* rows complete */
+        /* ---- the same fixed-order sum everywhere: 16 groups of rows in double, then the groups ---- */
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + GSDF_TRACK_BLOCK * i;
+            if (c < n_chunks) {
+                const int r = c / TRK_ROW_CHUNKS, q = c - r * TRK_ROW_CHUNKS;
+                rowv[r][3 * q] = __uint_as_float(ch[i].x); rowv[r][3 * q + 1] = __uint_as_float(ch[i].y); rowv[r][3 * q + 2] = __uint_as_float(ch[i].z);
+            }
+        }
+        __syncthreads();
+        {
+            const int v = tid & 31, grp = tid >> 5;                           /* 16 groups x 32 values */
+            const int per = (nb + 15) / 16;
+            double sgrp = 0.0;
+            if (v < 3 * TRK_ROW_CHUNKS)
+                for (int r = grp * per; r < (grp + 1) * per && r < nb; ++r) sgrp += (double)rowv[r][v];
+            part[grp][v] = sgrp;
+        }
+        __syncthreads();
+        float tot[GSDF_TRACK_NSUM];
+        {
+            double gs = 0.0;
+            if (lane < GSDF_TRACK_NSUM) {
+                gs = part[0][lane];
+#pragma unroll
+                for (int grp = 1; grp < 16; ++grp) gs += part[grp][lane];
+            }
+            const float totv = (float)gs;
+#pragma unroll
+            for (int i = 0; i < GSDF_TRACK_NSUM; ++i) tot[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(totv), i));
+        }
+        /* ---- one Gauss-Newton step (every wave of every workgroup computes it: identical bits) ---- */
+        passes = k + 1;
+        trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, GSDF_EXPERIMENT(tp.debug, 1), pose, &done, &converged);
+        hits = tot[28];
+        hit_total += (unsigned long long)tot[28];
+        if (trk_tr && tid == 0 && k < 12) trk_tr[16 * 512 * k + 4] = wall_clock64();        /* solved */
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        if (aborted) { done = 1; converged = 0; }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) st->pose7[i] = pose[i];
+        gsdf_quat_to_R(pose + 3, st->R);
+        st->converged = converged;
+        st->done = 1;
+        st->passes = passes;
+        st->last_hits = hits;
+        st->n_hit += hit_total;
+        st->trk[0].done = 1; st->trk[1].done = 1;
+        if (tp.progress)
+            __hip_atomic_store(&tp.progress[0], (tp.serial << 16) | 0x8000u | (unsigned int)(passes & 0x7FFF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+void gsdf_launch_track_all(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab, gsdf_dev_state* st,
+                           void* rows, unsigned int* abort_word, int n_blocks, const gsdf_track_params& tp_in,
+                           const gsdf_normals_job* normals) {
+    gsdf_track_params tp = tp_in;
+    tp.n_track_blocks = n_blocks;
+    gsdf_normals_job nj;
+    memset(&nj, 0, sizeof(nj));
+    int extra = 0;
+    size_t dyn = 0;
+    if (normals) {
+        nj = *normals;
+        nj.ntx = (g.W + NRM_TX - 1) / NRM_TX;
+        extra = nj.ntx * ((g.H + NRM_TY - 1) / NRM_TY);
+        dyn = sizeof(nrm_lds);
+    }
+    dyn = dyn > (size_t)n_blocks * 3 * TRK_ROW_CHUNKS * sizeof(float) ? dyn : (size_t)n_blocks * 3 * TRK_ROW_CHUNKS * sizeof(float);
+    if (n_blocks <= GSDF_TRACK_MAXBLK)
+        hipLaunchKernelGGL(k_track_all<GSDF_TRACK_MAXBLK>, dim3(n_blocks + extra), dim3(GSDF_TRACK_BLOCK), dyn, s, g, depth, tab, st,
+                           reinterpret_cast<gsdf_u32x4*>(rows), abort_word, tp, nj);
+    else
+        hipLaunchKernelGGL(k_track_all<2 * GSDF_TRACK_MAXBLK>, dim3(n_blocks + extra), dim3(GSDF_TRACK_BLOCK), dyn, s, g, depth, tab, st,
+                           reinterpret_cast<gsdf_u32x4*>(rows), abort_word, tp, nj);
+}
+size_t gsdf_track_all_rows_bytes(int n_blocks) { return (size_t)2 * (size_t)n_blocks * TRK_ROW_CHUNKS * sizeof(gsdf_u32x4); }
+
 struct pose7_arg { float p[7]; };
 __global__ void k_set_pose(gsdf_dev_state* st, pose7_arg a) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
