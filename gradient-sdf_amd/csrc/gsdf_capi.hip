@@ -94,10 +94,33 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
     const size_t N = (size_t)c->W * c->H;
     const gsdf_frame_geom g = c->geom();
     const gsdf_ncache nc = c->ncache();
+    float* nrm = c->normals + (size_t)2 * 3 * N;       /* tracked frames: set 2, filled beside the first tracker pass (main stream only) */
     if (!normals_done) {
-        prof_scope ps(c, 0);
-        gsdf_launch_normals(c->stream, g, c->win, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N,
-                            c->deferred_count, c->st);
+        /* MapGradPixelSdf.cpp:60: the normals of a frame depend on its depth only.  They are computed on a SECOND stream into
+         * the other set of planes, so that the normals of frame i + 1 run beside the fusion of frame i instead of in front of
+         * the fusion of frame i + 1 (a 10 us launch on the critical path of every GT-pose frame before):
+         *   stream2: wait (the fusion that last read this set has ended) -> k_normals -> event
+         *   stream : wait (event) -> k_fuse
+         * The depth image must be complete before k_normals reads it: an upload that is still queued on the main stream
+         * (gsdf_update, gsdf_dev_upload_async) is waited for; frames already resident in HBM need no such wait. */
+        const int b = c->nrm_parity;
+        c->nrm_parity ^= 1;
+        nrm = c->normals + (size_t)b * 3 * N;
+        if (c->profiling || !c->stream2) {             /* event-timed replays keep everything on one stream */
+            prof_scope ps(c, 0);
+            gsdf_launch_normals(c->stream, g, c->win, nc, depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr);
+        } else {
+            if (c->upload_pending) {
+                HIP_TRY(hipEventRecord(c->ev_upload, c->stream));
+                HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upload, 0));
+                c->upload_pending = false;
+            }
+            if (c->fuse_done_valid[b]) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fuse_done[b], 0));
+            gsdf_launch_normals(c->stream2, g, c->win, nc, depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr);
+            HIP_TRY(hipEventRecord(c->ev_nrm_ready[b], c->stream2));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_nrm_ready[b], 0));
+        }
+        c->last_nrm_set = b;
     }
     {
         prof_scope ps(c, 1);
@@ -106,7 +129,7 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
             c->fuse_tag = 1;
             HIP_TRY(hipMemsetAsync(c->tile_flags, 0, (size_t)c->fuse_blocks * sizeof(unsigned int), c->stream));
         }
-        gsdf_launch_fuse(c->stream, g, nc, depth_dev, c->normals, c->normals + N, c->normals + 2 * N, pose,
+        gsdf_launch_fuse(c->stream, g, nc, depth_dev, nrm, nrm + N, nrm + 2 * N, pose,
                          use_dev_pose, c->tab, c->st, c->blk_counters, c->deferred, c->deferred_count,
                          c->deferred_cap, c->fuse_tag, c->tile_flags, c->tile_order, c->frame_log, c->frame_log_cap, c->vis, c->vis_words,
                          c->debug & 0xFFFF, c->fuse_ticket,
@@ -115,6 +138,11 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
                          /* many tiles did not fit the small LDS table lately (far geometry): the kernel with the larger one.
                           * Like the note above a hint that lags by a launch or two, never a condition for correctness. */
                          fuse_far_table(c));
+    }
+    if (!normals_done && c->stream2 && !c->profiling) {
+        const int b = c->last_nrm_set;
+        HIP_TRY(hipEventRecord(c->ev_fuse_done[b], c->stream));
+        c->fuse_done_valid[b] = true;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
@@ -163,7 +191,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     if (fuse_after) {                    /* the frame's normals ride along with its first pass */
         const size_t N = (size_t)c->W * c->H;
         nj.nc = c->ncache();
-        nj.nx = c->normals; nj.ny = c->normals + N; nj.nz = c->normals + 2 * N;
+        nj.nx = c->normals + 6 * N; nj.ny = c->normals + 7 * N; nj.nz = c->normals + 8 * N;          /* set 2 */
         nj.deferred_count = c->deferred_count;
         nj.r = c->win / 2; nj.ntx = 0;
     }
@@ -321,6 +349,24 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         gsdf_destroy(c);
         return fail(GSDF_ERR_HIP, m);
     }
+    {
+        hipError_t e2 = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+        for (int b = 0; b < 2 && e2 == hipSuccess; ++b) {
+            e2 = hipEventCreateWithFlags(&c->ev_nrm_ready[b], hipEventDisableTiming);
+            if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_fuse_done[b], hipEventDisableTiming);
+        }
+        if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
+        if (e2 != hipSuccess) {
+            std::string m = std::string("gsdf_create: ") + hipGetErrorString(e2);
+            gsdf_destroy(c);
+            return fail(GSDF_ERR_HIP, m);
+        }
+        /* Measured (bench.py, fused-only flavour): 12 150 frames/s with the second stream against 13 320 without -- the two
+         * cross-stream waits per frame (barrier packets between hardware queues) cost more than the 10 us launch they take
+         * off the critical path.  So the normals stay in front of the fusion on the one stream unless GSDF_NORMALS_STREAM=1. */
+        const char* env = getenv("GSDF_NORMALS_STREAM");
+        if (!(env && atoi(env) == 1)) { (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
+    }
     c->tab.block_mask = (uint32_t)(c->n_slots / GSDF_BLOCK_VOX - 1);
     c->tab.occ_mask = (uint32_t)(c->n_slots - 1);
     c->tab.occ2 = c->tab.occ + c->n_slots / 32;
@@ -351,6 +397,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->trace) { (void)hipFree(c->trace); c->trace = nullptr; }      /* after the sync: a running kernel may still write stamps */
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -363,6 +410,12 @@ void gsdf_destroy(gsdf_ctx* c) {
     if (c->progress) (void)hipHostFree((void*)c->progress);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int b = 0; b < 2; ++b) {
+        if (c->ev_nrm_ready[b]) (void)hipEventDestroy(c->ev_nrm_ready[b]);
+        if (c->ev_fuse_done[b]) (void)hipEventDestroy(c->ev_fuse_done[b]);
+    }
+    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -370,6 +423,8 @@ void gsdf_destroy(gsdf_ctx* c) {
 int gsdf_reset(gsdf_ctx* c) {
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
+    if (c->deferred_count) HIP_TRY(hipMemsetAsync(c->deferred_count, 0, sizeof(unsigned int), c->stream));
     gsdf_launch_table_clear(c->stream, c->tab, c->n_slots);
     if (c->vis) HIP_TRY(hipMemsetAsync(c->vis, 0, c->n_slots * (size_t)c->vis_words * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->st, 0, sizeof(gsdf_dev_state), c->stream));
@@ -411,7 +466,9 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     const size_t N = (size_t)W * H;
     HIP_TRY(hipMalloc((void**)&c->planes, 11 * N * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->depth_stage, N * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&c->normals, 3 * N * sizeof(float)));
+    /* three sets of 3 planes: sets 0 / 1 alternate between GT-pose fusions (the normals of frame i + 1 are computed on a second
+     * stream while frame i is being fused), set 2 belongs to the main stream (tracked frames, gsdf_normals_compute) */
+    HIP_TRY(hipMalloc((void**)&c->normals, 3 * 3 * N * sizeof(float)));
     /* tracker grid: a multiple of the 256 CUs when the frame is large enough, 1-4 pixels per lane */
     c->track_blocks = N >= (size_t)1 << 20 ? 2 * GSDF_TRACK_MAXBLK : N >= (size_t)1 << 18 ? GSDF_TRACK_MAXBLK
                                                 : (int)std::max<size_t>(1, (N + 511) / 512);
@@ -441,8 +498,8 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipMalloc((void**)&c->deferred, (size_t)c->deferred_cap * sizeof(gsdf_deferred)));
     HIP_TRY(hipMalloc((void**)&c->deferred_count, sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(c->deferred_count, 0, sizeof(unsigned int), c->stream));
-    HIP_TRY(hipMalloc((void**)&c->fuse_ticket, sizeof(unsigned int)));
-    HIP_TRY(hipMemsetAsync(c->fuse_ticket, 0, sizeof(unsigned int), c->stream));
+    HIP_TRY(hipMalloc((void**)&c->fuse_ticket, 2 * sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(c->fuse_ticket, 0, 2 * sizeof(unsigned int), c->stream));
     c->frame_log_cap = 1 << 16;
     HIP_TRY(hipMalloc((void**)&c->frame_log, (size_t)c->frame_log_cap * 10 * sizeof(float)));
     gsdf_launch_normals_cache(c->stream, W, H, c->K, win, c->planes);
@@ -466,12 +523,12 @@ int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float*
     HIP_TRY(hipSetDevice(c->device));
     const size_t N = (size_t)c->W * c->H;
     HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, N * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), c->depth_stage, c->normals, c->normals + N,
-                        c->normals + 2 * N, nullptr, nullptr);
+    float* set2 = c->normals + 6 * N;
+    gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), c->depth_stage, set2, set2 + N, set2 + 2 * N, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(nx, c->normals, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(ny, c->normals + N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(nz, c->normals + 2 * N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(nx, set2, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(ny, set2 + N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(nz, set2 + 2 * N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GSDF_OK;
 }
@@ -493,6 +550,7 @@ int gsdf_update(gsdf_ctx* c, const float* depth_host, const float R[9], const fl
     if (!depth_host) return fail(GSDF_ERR_INVALID, "null depth");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, (size_t)c->W * c->H * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    c->upload_pending = true;
     rc = gsdf_update_dev(c, c->depth_stage, R, t);
     if (rc) return rc;
     return gsdf_sync(c);
@@ -1112,6 +1170,7 @@ int gsdf_dev_upload_async(gsdf_ctx* c, void* dev_dst, const void* host_src, int6
     if (!c || !dev_dst || !host_src || bytes < 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    c->upload_pending = true;                      /* a GT-pose fusion's normals (second stream) must wait for it */
     return GSDF_OK;
 }
 int gsdf_mark(gsdf_ctx* c, int64_t* mark) {

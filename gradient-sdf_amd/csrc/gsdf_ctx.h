@@ -32,6 +32,11 @@ inline int gsdf_fail(int code, const std::string& msg) {
 struct gsdf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;                 /* GT-pose fusion: NormalEstimator::compute of the next frame beside the running fusion */
+    hipEvent_t ev_nrm_ready[2] = { nullptr, nullptr }, ev_fuse_done[2] = { nullptr, nullptr }, ev_upload = nullptr;
+    bool fuse_done_valid[2] = { false, false };
+    int nrm_parity = 0, last_nrm_set = 0;          /* which set of normal planes the next / the last GT-pose fusion uses */
+    bool upload_pending = false;                   /* an asynchronous upload was queued on `stream` since the last GT-pose fusion */
     /* MapGradPixelSdf / Sdf members */
     float voxel_size = 0, voxel_size_inv = 0, T = 0, inv_T = 0;
     float zmin = 0.5f, zmax = 3.5f;                /* Sdf.h:67-68 */

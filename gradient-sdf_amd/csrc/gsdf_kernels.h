@@ -97,7 +97,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       float* log_rows /* nullable: frame log, written when use_dev_pose */, long long max_rows,
                       uint32_t* vis /* nullable: per-voxel frame bit-vectors */, int vis_words,
                       int debug /* path-forcing / measurement switches, honoured by -DGSDF_EXPERIMENTS builds only */,
-                      unsigned int* ticket /* device word, zeroed once: arrivals of finished workgroups */,
+                      unsigned int* ticket /* two device words, zeroed once: arrivals of finished workgroups of k_fuse / of k_fuse_resolve */,
                       int resolve_follows /* also queue k_fuse_resolve (long deferred lists) */,
                       unsigned int* host_note /* nullable, 2 pinned host words: length of the deferred list, tiles too big for the small LDS table */,
                       int far_table /* use the kernel with the larger LDS table */);

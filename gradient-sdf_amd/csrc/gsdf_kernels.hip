@@ -1067,6 +1067,10 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         }
         __hip_atomic_store(&a.st->far_tiles, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        /* Sdf::counter_ as the NEXT update() will see it (this launch's increment included: tile (0, 0) arrived before this
+         * workgroup read the ticket).  The normals stage used to take this snapshot; in GT-pose mode it now runs on its own
+         * stream beside this kernel and must not touch state the fusion uses. */
+        a.st->frame_cur = a.st->frames;
         if (a.use_dev_pose) fuse_log_row(a);
     }
 }
@@ -1075,7 +1079,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
  * Queued only while the previous launches reported long lists (gsdf_dev_state::last_deferred, read by the host without
  * waiting); short lists are added by the last workgroup of k_fuse itself, which leaves count = 0 here. */
 __global__ __launch_bounds__(256) void k_fuse_resolve(const gsdf_deferred* list, unsigned int* count, unsigned int cap,
-                                                       const gsdf_dev_state* gate, gsdf_dev_state* st) {
+                                                       const gsdf_dev_state* gate, gsdf_dev_state* st, unsigned int* ticket) {
     if (gate && !(gate->done && gate->converged)) return;
     unsigned int n = *count;
     n = n < cap ? n : cap;
@@ -1088,7 +1092,13 @@ __global__ __launch_bounds__(256) void k_fuse_resolve(const gsdf_deferred* list,
         unsafeAtomicAdd(&d.p->gy, d.gy);
         unsafeAtomicAdd(&d.p->gz, d.gz);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->n_deferred += n;    /* the count itself is cleared by the next normals stage */
+    /* the last block to finish counts the list and empties it for the next fusion (every block has read `count` by then) */
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) + 1u == gridDim.x) {
+        st->n_deferred += n;
+        __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
@@ -1113,7 +1123,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     if (far_table) hipLaunchKernelGGL(k_fuse<FUSE_LCAP_FAR>, dim3(n), dim3(FUSE_THREADS), 0, s, a);
     else hipLaunchKernelGGL(k_fuse<FUSE_LCAP_NEAR>, dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(debug, 4096) ? 81920 : 0, s, a);   /* experiment: 1 workgroup per CU */
     if (resolve_follows)
-        hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st);
+        hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st, ticket + 1);
 }
 int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T); }
 /* Launch order of the fusion tiles.  Colour-major (colour = parity of tile x, y): a tile only ever waits for tiles
