@@ -403,7 +403,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->mark_pool) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.second);
-    void* ptrs[] = { c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
+    void* ptrs[] = { c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -952,7 +952,11 @@ int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float
     if (n <= 0) return GSDF_OK;
     HIP_TRY(hipSetDevice(c->device));
     float* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, (size_t)n * 8 * sizeof(float)));
+    const bool small = (size_t)n * 8 * sizeof(float) <= GSDF_SCRATCH_BYTES;       /* single points / small batches: no allocation per call */
+    if (small) {
+        if (!c->scratch) HIP_TRY(hipMalloc(&c->scratch, GSDF_SCRATCH_BYTES));
+        d = (float*)c->scratch;
+    } else HIP_TRY(hipMalloc((void**)&d, (size_t)n * 8 * sizeof(float)));
     float *dp = d, *dd = d + 3 * n, *dg = d + 4 * n, *dw = d + 7 * n;
     hipError_t e = hipMemcpyAsync(dp, pts_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
@@ -962,7 +966,7 @@ int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float
     if (e == hipSuccess) e = hipMemcpyAsync(grad, dg, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(w, dw, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
+    if (!small) (void)hipFree(d);
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
     return GSDF_OK;
 }
@@ -972,7 +976,11 @@ int gsdf_get_voxels(gsdf_ctx* c, const int32_t* keys_host, int64_t n, float* pay
     if (n <= 0) return GSDF_OK;
     HIP_TRY(hipSetDevice(c->device));
     char* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, (size_t)n * (3 * sizeof(int32_t) + 5 * sizeof(float) + sizeof(int32_t))));
+    const bool small = (size_t)n * 36 <= GSDF_SCRATCH_BYTES;
+    if (small) {
+        if (!c->scratch) HIP_TRY(hipMalloc(&c->scratch, GSDF_SCRATCH_BYTES));
+        d = (char*)c->scratch;
+    } else HIP_TRY(hipMalloc((void**)&d, (size_t)n * (3 * sizeof(int32_t) + 5 * sizeof(float) + sizeof(int32_t))));
     int32_t* dk = (int32_t*)d;
     float* dp = (float*)(d + (size_t)n * 3 * sizeof(int32_t));
     int32_t* df = (int32_t*)(d + (size_t)n * (3 * sizeof(int32_t) + 5 * sizeof(float)));
@@ -983,7 +991,7 @@ int gsdf_get_voxels(gsdf_ctx* c, const int32_t* keys_host, int64_t n, float* pay
     }
     if (e == hipSuccess) e = hipMemcpyAsync(found, df, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
+    if (!small) (void)hipFree(d);
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
     return GSDF_OK;
 }
@@ -1073,28 +1081,38 @@ int gsdf_extract_mesh(gsdf_ctx* c, float iso, const int8_t tri_table[256 * 16], 
     if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tri_table, 256 * 16, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream);
     unsigned long long n = 0;
-    std::vector<unsigned long long> keys;
-    std::vector<float> tris;
     if (e == hipSuccess) {
         gsdf_launch_mesh(c->stream, c->tab, c->n_slots, c->voxel_size, iso, d_mn, d_tab, d_tris, d_keys, c->counter, cap);
         e = hipMemcpyAsync(&n, c->counter, sizeof(n), hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     const size_t got = (size_t)std::min<unsigned long long>(n, (unsigned long long)cap);
-    if (e == hipSuccess && got) {
-        keys.resize(got); tris.resize(got * 9);
-        e = hipMemcpy(keys.data(), d_keys, got * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(tris.data(), d_tris, got * 9 * sizeof(float), hipMemcpyDeviceToHost);
+    /* the reference's order (z-y-x sweep, triangles of a cube in table order) = ascending sort key: radix sort of (key, index)
+     * on the device, the triangles gathered into that order on the device, ONE copy of the sorted list to the caller */
+    unsigned long long* d_keys2 = nullptr; uint32_t *d_idx = nullptr, *d_idx2 = nullptr; float* d_sorted = nullptr; void* d_tmp = nullptr;
+    if (e == hipSuccess && got && n <= (unsigned long long)cap) {
+        size_t tmp_bytes = 0;
+        e = hipMalloc((void**)&d_keys2, got * sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_idx, got * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_idx2, got * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&d_sorted, got * 9 * sizeof(float));
+        if (e == hipSuccess) e = gsdf_sort_pairs_u64(nullptr, &tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, got, c->stream);
+        if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 8);
+        if (e == hipSuccess) {
+            gsdf_launch_iota(c->stream, d_idx, got);
+            e = gsdf_sort_pairs_u64(d_tmp, &tmp_bytes, d_keys, d_keys2, d_idx, d_idx2, got, c->stream);
+        }
+        if (e == hipSuccess) {
+            gsdf_launch_gather_tris(c->stream, d_tris, d_idx2, d_sorted, got);
+            e = hipMemcpyAsync(triangles_out, d_sorted, got * 9 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
     (void)hipFree(d_mn); (void)hipFree(d_tab); (void)hipFree(d_tris); (void)hipFree(d_keys);
+    (void)hipFree(d_keys2); (void)hipFree(d_idx); (void)hipFree(d_idx2); (void)hipFree(d_sorted); (void)hipFree(d_tmp);
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, hipGetErrorString(e));
     *n_tris = (int64_t)n;                                    /* total found, also when it exceeds max_tris */
     if (n > (unsigned long long)cap) return cap ? fail(GSDF_ERR_INVALID, "gsdf_extract_mesh: max_tris too small (n_tris holds the need)") : GSDF_OK;
-    /* the reference's order: z-y-x sweep, triangles of a cube in table order */
-    std::vector<uint32_t> order(got);
-    for (size_t i = 0; i < got; ++i) order[i] = (uint32_t)i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
-    for (size_t i = 0; i < got; ++i) std::memcpy(triangles_out + 9 * i, tris.data() + 9 * (size_t)order[i], 9 * sizeof(float));
     return GSDF_OK;
 }
 

@@ -14,6 +14,7 @@
 #include <utility>
 #include <vector>
 
+#define GSDF_SCRATCH_BYTES (256 * 1024)
 #define GSDF_PROF_SLOTS 5     /* gsdf_profile: 0 normals, 1 fusion, 2 tracking launches, 3 raycast, 4 tracker (whole optimize) */
 
 inline thread_local std::string g_gsdf_err;
@@ -73,6 +74,7 @@ struct gsdf_ctx {
     unsigned long long* rc_counts = nullptr;       /* raycaster: per-workgroup rows of (samples, records, fast / slow iterations of wave 0) */
     size_t rc_rows = 0;
     long long rc_iters[2] = { 0, 0 };              /* loop iterations of the workgroups' wave 0 as of the last gsdf_raycast_counters */
+    void* scratch = nullptr;                       /* device scratch of gsdf_query / gsdf_get_voxels for small batches (GSDF_SCRATCH_BYTES) */
     bool merged = false;                           /* gsdf_merge_allreduce has run: the map is the sum of all ranks (one-shot) */
     /* PhotoBA (PhotometricOptimizer) */
     int ba_n = 0;

@@ -152,6 +152,13 @@ void gsdf_launch_raycast(hipStream_t s, gsdf_table tab, float vs, float inv_vs, 
 void gsdf_launch_mesh(hipStream_t s, gsdf_table tab, size_t n_slots, float vs, float iso, int* mn_dev, const signed char* tri_table_dev,
                       float* tris_dev, unsigned long long* keys_dev, unsigned long long* counter, long long max_tris);
 
+/* mesh export: device radix sort of (64-bit sweep key, triangle index) pairs (rocPRIM; tmp == nullptr: only *tmp_bytes is set),
+ * index fill, and the gather of 9-float triangles into sorted order (gsdf_sort.hip) */
+hipError_t gsdf_sort_pairs_u64(void* tmp, size_t* tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
+                               const uint32_t* vals_in, uint32_t* vals_out, size_t n, hipStream_t s);
+void gsdf_launch_iota(hipStream_t s, uint32_t* idx, size_t n);
+void gsdf_launch_gather_tris(hipStream_t s, const float* tris, const uint32_t* order, float* sorted, size_t n);
+
 /* dense block exchange (frame-sharded fusion): list of block keys; pack / unpack of 64 x 5 raw sums per listed block */
 void gsdf_launch_block_keys(hipStream_t s, gsdf_table tab, size_t n_blocks, unsigned long long* out_dev, unsigned long long* counter,
                             long long max_n);

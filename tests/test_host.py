@@ -113,6 +113,48 @@ def test_scan3d_tracked_mode_writes_tum_poses(pkg, O, tmp_path):
 
 
 @pytest.mark.gpu
+def test_scan3d_c1_thirty_frames_tracked(pkg, O, tmp_path):
+    """BASELINE configs[0] at its full length: Scan3D --scan-type grad-sdf on a 30-frame RenderSpheres-style sequence, 640x480,
+    1 cm voxels, trunc 10, no pose file (every frame tracked, fused when converged), against the oracle's loop on the same
+    files' content: same convergence decisions, poses frame by frame, and the same map at the end."""
+    _build()
+    W, H, n = 640, 480, 30
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=0, step_deg=0.5)
+    ds = pkg.synth.write_dataset(seq, str(tmp_path / "ds"), layout="synth", with_poses=False)
+    res = str(tmp_path / "out") + "/"
+    os.makedirs(res)
+    cmd = [os.path.join(HOST, "Scan3D"), "--input", ds, "--results", res, "--scan-type", "grad-sdf", "--data-type", "synth",
+           "--voxel-size", "0.01", "--trunc", "10", "--save-sdf"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    pf = np.loadtxt(res + "_poses.txt")
+    assert pf.shape == (n, 8)
+    conv_cli = {int(l.split()[1]) for l in out.stdout.split("\n") if l.startswith("frame ") and "Convergence after" in l}
+    vs = np.float32(0.01)
+    o = O.Oracle(vs, np.float32(10) * vs, W, H, seq.K)
+    pose = np.array([0, 0, 0, 0, 0, 0, 1], np.float32)
+    conv_o = set()
+    worst = 0.0
+    for i in range(n):
+        d = seq.depth_u16(i).astype(np.float32) * np.float32(0.001)
+        if i == 0:
+            o.update(d, np.eye(3), np.zeros(3))
+        else:
+            conv, pose, _, _, _ = o.track(d, pose)
+            if conv:
+                conv_o.add(i)
+                o.update(d, O.quat_to_R(pose[3:]), pose[:3])
+        worst = max(worst, float(np.abs(pf[i, 1:4] - pose[:3]).max()), float(np.abs(np.abs(pf[i, 4:8]) - np.abs(pose[3:])).max()))
+    # Gauss-Newton ends within one threshold-sized (1e-3) step of the same point on both sides (see the 4-frame test above)
+    assert worst < 2e-3, worst
+    assert len(conv_cli ^ conv_o) <= 2, (sorted(conv_cli), sorted(conv_o))          # borderline frames may flip
+    assert len(conv_o) >= 20
+    info = open(res + "gradient_sdf_grid_info.txt").read().split("\n")
+    n_vox = len(open(res + "gradient_sdf_sdf_d.txt").read().strip().split("\n"))
+    assert abs(n_vox - o.count()) <= 0.02 * o.count() and "voxel size" in info[0].lower()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,W,H,vs", [("spheres", 160, 120, 0.02), ("tum", 320, 240, 0.01)])
 def test_device_marching_cubes_equals_host_sweep(pkg, kind, W, H, vs):
     """gsdf_extract_mesh (one lane per voxel through the block map) against MarchingCubes::computeIsoSurface, the host

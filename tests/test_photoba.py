@@ -7,10 +7,10 @@ import numpy as np
 import pytest
 
 
-def _scene(pkg, O, W=160, H=120, n=6, vs=0.02, perturb=True):
+def _scene(pkg, O, W=160, H=120, n=6, vs=0.02, perturb=True, trunc=5):
     seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=0, noise=False)
     vs = np.float32(vs)
-    T = np.float32(5) * vs
+    T = np.float32(trunc) * vs
     frames = [seq.frame(i) for i in range(n)]
     imgs = np.stack([pkg.synth.render_color_bgr(seq, i) for i in range(n)])
     P = np.stack([pkg.synth.pose16(*seq.pose(i)) for i in range(n)])
@@ -87,12 +87,12 @@ def test_oracle_photoba_trunc_l2_known_answers(pkg, O):
     assert np.abs(p_mid - p_def).max() > 1e-5 and np.abs(p_mid - Pp).max() > 1e-4
 
 
-def _gpu_and_oracle_on_the_same_map(pkg, O, n=6):
+def _gpu_and_oracle_on_the_same_map(pkg, O, n=6, W=160, H=120, vs=0.02, trunc=5, cap=20):
     """Fuse on the GPU (with vis_), fuse in the oracle, then give the oracle the GPU's voxel values: both BA implementations
     start from identical maps (key sets and vis_ are bit-exact anyway, tests/test_gpu_parity.py)."""
-    seq, vs, T, frames, imgs, P, Pp = _scene(pkg, O, n=n)
+    seq, vs, T, frames, imgs, P, Pp = _scene(pkg, O, n=n, W=W, H=H, vs=vs, trunc=trunc)
     o = _oracle_map(O, seq, vs, T, frames)
-    g = pkg.GradSdf(vs, T, seq.W, seq.H, seq.K, capacity_log2=20)
+    g = pkg.GradSdf(vs, T, seq.W, seq.H, seq.K, capacity_log2=cap)
     g.enable_vis(64)
     for d, R, t in frames:
         g.update(d, R, t)
@@ -102,12 +102,14 @@ def _gpu_and_oracle_on_the_same_map(pkg, O, n=6):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [6, 50])
-def test_gpu_photoba_steps_match_oracle(pkg, O, n):
+@pytest.mark.parametrize("n,W,H,vs,trunc,cap", [(6, 160, 120, 0.02, 5, 20), (50, 160, 120, 0.02, 5, 20), (50, 640, 480, 0.01, 10, 22)],
+                         ids=["6kf-160x120", "50kf-160x120", "C5-50kf-640x480-1cm"])
+def test_gpu_photoba_steps_match_oracle(pkg, O, n, W, H, vs, trunc, cap):
     """Every sweep of PhotometricOptimizer against the oracle FROM IDENTICAL STATE (same voxel values, same poses), at the
     bar of BASELINE.json's north_star (1e-4 on distance and pose; energy to 1e-4 relative): getEnergy, one solvePose, one
-    solveDist.  n = 50 keyframes is the size of BASELINE config C5."""
-    seq, g, o, imgs, P, Pp = _gpu_and_oracle_on_the_same_map(pkg, O, n=n)
+    solveDist.  n = 50 keyframes is the size of BASELINE config C5; the last case is C5 as configured (640x480 frames on the
+    1 cm / trunc 10 map of the bench stream, ~1.6 x 10^6 voxels; the oracle's part takes about a minute)."""
+    seq, g, o, imgs, P, Pp = _gpu_and_oracle_on_the_same_map(pkg, O, n=n, W=W, H=H, vs=vs, trunc=trunc, cap=cap)
     idx = np.arange(n)
     ba = O.PhotoBA(o, imgs, Pp, idx)
     g.ba_setup(imgs, Pp, idx)

@@ -1,4 +1,3 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > gpurun_out/r3_t6.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/r3_bench4.json 2> gpurun_out/r3_bench4.err
-GSDF_NORMALS_STREAM=0 python bench.py --steps 20 --warmup 5 --cpu-frames 0 > gpurun_out/r3_bench4_ns0.json 2> gpurun_out/r3_bench4_ns0.err
-cat gpurun_out/r3_t6.log; tail -2 gpurun_out/r3_bench4.err
+python -m pytest tests -m gpu -x -q --durations=8 2>&1 | tail -25 > gpurun_out/r3_t7.log
+python tools/run_c4.py --frames 2000 --force-exchange > gpurun_out/r3_c4.json 2> gpurun_out/r3_c4.err
+cat gpurun_out/r3_t7.log; tail -2 gpurun_out/r3_c4.json

@@ -8,10 +8,10 @@ src=$root/gradient-sdf_amd/csrc
 out=$src/variants
 tmp=$(mktemp -d)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function"
-for f in gsdf_kernels gsdf_ba gsdf_capi gsdf_merge; do
+for f in gsdf_kernels gsdf_ba gsdf_capi gsdf_merge gsdf_sort; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $src/$f.hip -o $tmp/$f.o &
 done
 wait
-g++ -shared -o $out/libgsdf_$name.so $tmp/gsdf_kernels.o $tmp/gsdf_ba.o $tmp/gsdf_capi.o $tmp/gsdf_merge.o -lstdc++ -ldl -lm
+g++ -shared -o $out/libgsdf_$name.so $tmp/gsdf_kernels.o $tmp/gsdf_ba.o $tmp/gsdf_capi.o $tmp/gsdf_merge.o $tmp/gsdf_sort.o -lstdc++ -ldl -lm
 rm -rf $tmp
 echo built $out/libgsdf_$name.so
