@@ -28,4 +28,25 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum" "
 done
 python $root/tools/pmc_summary.py /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4 /tmp/pmc5 > $out/pmc_counters.txt 2> $out/pmc_summary.err
 python $root/tools/pmc_summary.py --json "$DRV --cpu-frames 0" /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 > $out/pmc_latest.json 2>> $out/pmc_summary.err
+# 4. the raycaster: timing against the sample-at-a-time kernel (test build), per-workgroup lifetimes, PMC counters of both
+python $root/tools/raycast_bench.py > $out/raycast_bench.json 2> $out/raycast_bench.err
+GRAFT_REPO_ROOT=$root bash $root/tools/raycast_pmc.sh $tag > /dev/null 2>&1
+cp $root/gpurun_out/raycast_pmc_$tag.txt $out/raycast_pmc_counters.txt 2>/dev/null
+# 5. the tracker: per-workgroup phase traces of one frame, one launch per pass (default) and the one-launch optimize() (GSDF_PERSIST=1)
+GSDF_PERSIST=0 python $root/tools/track_trace.py 20 > $out/track_trace_per_pass.txt 2>&1
+GSDF_PERSIST=1 python $root/tools/track_all_trace.py 20 > $out/track_trace_one_launch.txt 2>&1
+GSDF_PERSIST=1 python $root/bench.py --steps 20 --warmup 5 --only-main > $out/bench_one_launch_tracker.json 2> /dev/null
+# 6. k_fuse and the number of dispatch rounds: frame sizes with 1040 / 1200 / 1536 / 2048 tiles on the 512 workgroup slots
+for wh in "640 416" "640 480" "768 512" "1024 512"; do set -- $wh
+  python $root/bench.py --steps 20 --warmup 5 --only-main --repeats 2 --width $1 --height $2 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); r=d['roofline']; t=(($1+15)//16)*(($2+15)//16)
+        print('%4d x %3d: %4d tiles = %.2f rounds of 512 workgroups | k_fuse %.1f us = %.1f ns per tile | %d updates -> frac %.3f' % ($1, $2, t, t/512.0, r['avg_launch_us'], 1e3*r['avg_launch_us']/t, d['config']['n_upd_per_frame'], r['frac']))
+"
+done > $out/fuse_rounds.txt
+# 7. what WRITE_SIZE / FETCH_SIZE count for the flush's access pattern (tools/write_calib.hip)
+GRAFT_REPO_ROOT=$root bash $root/tools/write_calib.sh > /dev/null 2>&1
+cp $root/gpurun_out/write_calib.txt $out/write_calibration.txt 2>/dev/null
 ls -la $out
