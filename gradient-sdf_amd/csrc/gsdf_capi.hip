@@ -89,39 +89,12 @@ static int fuse_far_table(const gsdf_ctx* c) {
     return c->progress && c->progress[3] * 16u > (unsigned int)c->fuse_blocks ? 1 : 0;
 }
 
-/* normals_done: the frame's normals were computed beside its first tracker pass (enqueue_track) */
-int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done) {
+/* one k_fuse launch: depth + its normal planes `nrm` (3 x N floats) -> the map.  next_depth (nullable): the launch's extra
+ * workgroups compute the normals of that frame into next_nrm */
+int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsdf_pose_arg& pose, int use_dev_pose,
+                const float* next_depth, float* next_nrm) {
     const size_t N = (size_t)c->W * c->H;
-    const gsdf_frame_geom g = c->geom();
-    const gsdf_ncache nc = c->ncache();
-    float* nrm = c->normals + (size_t)2 * 3 * N;       /* tracked frames: set 2, filled beside the first tracker pass (main stream only) */
-    if (!normals_done) {
-        /* MapGradPixelSdf.cpp:60: the normals of a frame depend on its depth only.  They are computed on a SECOND stream into
-         * the other set of planes, so that the normals of frame i + 1 run beside the fusion of frame i instead of in front of
-         * the fusion of frame i + 1 (a 10 us launch on the critical path of every GT-pose frame before):
-         *   stream2: wait (the fusion that last read this set has ended) -> k_normals -> event
-         *   stream : wait (event) -> k_fuse
-         * The depth image must be complete before k_normals reads it: an upload that is still queued on the main stream
-         * (gsdf_update, gsdf_dev_upload_async) is waited for; frames already resident in HBM need no such wait. */
-        const int b = c->nrm_parity;
-        c->nrm_parity ^= 1;
-        nrm = c->normals + (size_t)b * 3 * N;
-        if (c->profiling || !c->stream2) {             /* event-timed replays keep everything on one stream */
-            prof_scope ps(c, 0);
-            gsdf_launch_normals(c->stream, g, c->win, nc, depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr);
-        } else {
-            if (c->upload_pending) {
-                HIP_TRY(hipEventRecord(c->ev_upload, c->stream));
-                HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_upload, 0));
-                c->upload_pending = false;
-            }
-            if (c->fuse_done_valid[b]) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fuse_done[b], 0));
-            gsdf_launch_normals(c->stream2, g, c->win, nc, depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr);
-            HIP_TRY(hipEventRecord(c->ev_nrm_ready[b], c->stream2));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_nrm_ready[b], 0));
-        }
-        c->last_nrm_set = b;
-    }
+    c->occ_dirty = true;                                      /* new blocks: the raycaster's filters are rebuilt when it next runs */
     {
         prof_scope ps(c, 1);
         c->fuse_tag += 1;
@@ -129,7 +102,7 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
             c->fuse_tag = 1;
             HIP_TRY(hipMemsetAsync(c->tile_flags, 0, (size_t)c->fuse_blocks * sizeof(unsigned int), c->stream));
         }
-        gsdf_launch_fuse(c->stream, g, nc, depth_dev, nrm, nrm + N, nrm + 2 * N, pose,
+        gsdf_launch_fuse(c->stream, c->geom(), c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, pose,
                          use_dev_pose, c->tab, c->st, c->blk_counters, c->deferred, c->deferred_count,
                          c->deferred_cap, c->fuse_tag, c->tile_flags, c->tile_order, c->frame_log, c->frame_log_cap, c->vis, c->vis_words,
                          c->debug & 0xFFFF, c->fuse_ticket,
@@ -137,16 +110,25 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
                          c->progress && c->progress[2] > 8192u ? 1 : 0, c->progress ? c->progress_dev + 2 : nullptr,
                          /* many tiles did not fit the small LDS table lately (far geometry): the kernel with the larger one.
                           * Like the note above a hint that lags by a launch or two, never a condition for correctness. */
-                         fuse_far_table(c));
-    }
-    if (!normals_done && c->stream2 && !c->profiling) {
-        const int b = c->last_nrm_set;
-        HIP_TRY(hipEventRecord(c->ev_fuse_done[b], c->stream));
-        c->fuse_done_valid[b] = true;
+                         fuse_far_table(c),
+                         next_depth, next_nrm, next_nrm ? next_nrm + N : nullptr, next_nrm ? next_nrm + 2 * N : nullptr, c->win);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
     return GSDF_OK;
+}
+
+/* normals (unless the frame's were computed beside its first tracker pass: normals_done) + fusion, in stream order */
+int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done) {
+    const size_t N = (size_t)c->W * c->H;
+    float* nrm = c->normals + (size_t)2 * 3 * N;       /* tracked frames: set 2, filled beside the first tracker pass */
+    if (!normals_done) {
+        nrm = c->normals + (size_t)c->nrm_parity * 3 * N;
+        c->nrm_parity ^= 1;
+        prof_scope ps(c, 0);
+        gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr);
+    }
+    return launch_fuse(c, depth_dev, nrm, pose, use_dev_pose, nullptr, nullptr);
 }
 
 /* RigidPointOptimizer::optimize_sampled as a chain of per-pass launches.  The convergence test, the pose update
@@ -265,6 +247,16 @@ int read_state(gsdf_ctx* c, gsdf_dev_state* out) {
 
 } // namespace
 
+/* launches the GT-pose fusion that waits for its successor (gsdf_update_dev), if any */
+int gsdf_flush_pending(gsdf_ctx* c) {
+    if (!c || !c->pending.valid) return GSDF_OK;
+    c->pending.valid = false;
+    if (hipSetDevice(c->device) != hipSuccess) return fail(GSDF_ERR_HIP, "hipSetDevice");
+    const size_t N = (size_t)c->W * c->H;
+    return launch_fuse(c, c->pending.depth, c->normals + (size_t)c->pending.set * 3 * N, c->pending.pose, 0, nullptr, nullptr);
+}
+#define GSDF_FLUSH(c) do { if ((c) && (c)->pending.valid) { const int rc_ = gsdf_flush_pending(c); if (rc_) return rc_; } } while (0)
+
 extern "C" {
 
 const char* gsdf_last_error(void) { return g_gsdf_err.c_str(); }
@@ -276,6 +268,7 @@ const char* gsdf_last_error(void) { return g_gsdf_err.c_str(); }
 #define GSDF_TRACE_WG 8192
 #define GSDF_TRACE_COLS 16
 int gsdf_debug_flags(gsdf_ctx* c, int flags) {
+    GSDF_FLUSH(c);
     if (!c) return GSDF_ERR_INVALID;
     c->debug = flags;
     if (flags & 64) {                                  /* k_fuse trace: GSDF_TRACE_COLS time stamps per workgroup, pointer in dbg[23] */
@@ -289,6 +282,7 @@ int gsdf_debug_flags(gsdf_ctx* c, int flags) {
 }
 /* the trace of the last k_fuse launch: n_wg rows of GSDF_TRACE_COLS (16) values */
 int gsdf_debug_trace(gsdf_ctx* c, unsigned long long* out, int n_wg) {
+    GSDF_FLUSH(c);
     if (!c || !out || !c->trace || n_wg > GSDF_TRACE_WG) return GSDF_ERR_INVALID;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
     if (hipMemcpy(out, c->trace, (size_t)n_wg * GSDF_TRACE_COLS * 8, hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
@@ -296,12 +290,14 @@ int gsdf_debug_trace(gsdf_ctx* c, unsigned long long* out, int n_wg) {
 }
 /* the raycaster's per-workgroup rows (8 values each, see gsdf_launch_raycast), tools/raycast_bench.py */
 int gsdf_debug_raycast_rows(gsdf_ctx* c, unsigned long long* out, int n_rows) {
+    GSDF_FLUSH(c);
     if (!c || !out || !c->rc_counts || (size_t)n_rows > c->rc_rows) return GSDF_ERR_INVALID;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
     if (hipMemcpy(out, c->rc_counts, (size_t)n_rows * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
     return GSDF_OK;
 }
 int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[24]) {
+    GSDF_FLUSH(c);
     if (!c || !out) return GSDF_ERR_INVALID;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
     gsdf_dev_state h;
@@ -350,27 +346,10 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         return fail(GSDF_ERR_HIP, m);
     }
     {
-        hipError_t e2 = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
-        for (int b = 0; b < 2 && e2 == hipSuccess; ++b) {
-            e2 = hipEventCreateWithFlags(&c->ev_nrm_ready[b], hipEventDisableTiming);
-            if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_fuse_done[b], hipEventDisableTiming);
-        }
-        if (e2 == hipSuccess) e2 = hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
-        if (e2 != hipSuccess) {
-            std::string m = std::string("gsdf_create: ") + hipGetErrorString(e2);
-            gsdf_destroy(c);
-            return fail(GSDF_ERR_HIP, m);
-        }
-        /* Measured (bench.py, fused-only flavour): 12 150 frames/s with the second stream against 13 320 without -- the two
-         * cross-stream waits per frame (barrier packets between hardware queues) cost more than the 10 us launch they take
-         * off the critical path.  So the normals stay in front of the fusion on the one stream unless GSDF_NORMALS_STREAM=1. */
-        const char* env = getenv("GSDF_NORMALS_STREAM");
-        if (!(env && atoi(env) == 1)) { (void)hipStreamDestroy(c->stream2); c->stream2 = nullptr; }
+        const char* env = getenv("GSDF_DEFER");                    /* 0: every gsdf_update_dev launches its normals and its fusion at once */
+        if (env) c->defer = atoi(env);
     }
     c->tab.block_mask = (uint32_t)(c->n_slots / GSDF_BLOCK_VOX - 1);
-    c->tab.occ_mask = (uint32_t)(c->n_slots - 1);
-    c->tab.occ2 = c->tab.occ + c->n_slots / 32;
-    c->tab.occ2_mask = (uint32_t)(std::max<size_t>(c->n_slots / GSDF_BLOCK_VOX, 32) - 1);
     {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
@@ -395,9 +374,9 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
 
 void gsdf_destroy(gsdf_ctx* c) {
     if (!c) return;
+    (void)gsdf_flush_pending(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->trace) { (void)hipFree(c->trace); c->trace = nullptr; }      /* after the sync: a running kernel may still write stamps */
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -410,12 +389,6 @@ void gsdf_destroy(gsdf_ctx* c) {
     if (c->progress) (void)hipHostFree((void*)c->progress);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    for (int b = 0; b < 2; ++b) {
-        if (c->ev_nrm_ready[b]) (void)hipEventDestroy(c->ev_nrm_ready[b]);
-        if (c->ev_fuse_done[b]) (void)hipEventDestroy(c->ev_fuse_done[b]);
-    }
-    if (c->ev_upload) (void)hipEventDestroy(c->ev_upload);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -423,7 +396,7 @@ void gsdf_destroy(gsdf_ctx* c) {
 int gsdf_reset(gsdf_ctx* c) {
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
+    c->pending.valid = false;                              /* a fusion that was never launched is dropped with the map */
     if (c->deferred_count) HIP_TRY(hipMemsetAsync(c->deferred_count, 0, sizeof(unsigned int), c->stream));
     gsdf_launch_table_clear(c->stream, c->tab, c->n_slots);
     if (c->vis) HIP_TRY(hipMemsetAsync(c->vis, 0, c->n_slots * (size_t)c->vis_words * sizeof(uint32_t), c->stream));
@@ -439,16 +412,19 @@ int gsdf_reset(gsdf_ctx* c) {
         HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->merged = false;
+    c->occ_dirty = false;                                    /* the table clear zeroed the filters as well */
     return GSDF_OK;
 }
 
 int gsdf_set_zrange(gsdf_ctx* c, float zmin, float zmax) {
+    GSDF_FLUSH(c);
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     c->zmin = zmin; c->zmax = zmax;
     return GSDF_OK;
 }
 
 int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
+    GSDF_FLUSH(c);
     if (!c || !K) return fail(GSDF_ERR_INVALID, "null argument");
     if (W <= 0 || H <= 0 || win <= 0 || !(win & 1) || win / 2 > 7)
         return fail(GSDF_ERR_INVALID, "W,H > 0 and odd window <= 15 required");
@@ -509,6 +485,7 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
 }
 
 int gsdf_normals_cache(gsdf_ctx* c, float* planes11_host) {
+    GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -518,6 +495,7 @@ int gsdf_normals_cache(gsdf_ctx* c, float* planes11_host) {
 }
 
 int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float* ny, float* nz) {
+    GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -541,22 +519,49 @@ int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const
     gsdf_pose_arg pose;
     std::memcpy(pose.R, R, sizeof(pose.R));
     std::memcpy(pose.t, t, sizeof(pose.t));
-    return enqueue_fuse(c, depth_dev, pose, 0, false);
+    if (!c->defer || c->profiling) {                       /* event-timed replays: normals and fusion as two launches, in order */
+        int rc = gsdf_flush_pending(c);
+        if (rc) return rc;
+        return enqueue_fuse(c, depth_dev, pose, 0, false);
+    }
+    /* MapGradPixelSdf.cpp:60: the normals of a frame depend on its depth only.  A run of GT-pose fusions (the branch
+     * main_scan_3d.cpp:250-254; frame-sharded fusion) is pipelined by ONE call: the k_fuse of frame i is launched when frame
+     * i + 1 arrives, and that launch's last workgroups compute the normals of frame i + 1 -- in the tail of the fusion,
+     * where two thirds of the CUs idle, instead of as a launch of their own in front of the next fusion (10 us + a gap on
+     * the critical path of every frame before).  Anything else the caller does with the context launches the waiting
+     * fusion first (gsdf_flush_pending at the top of every other entry), so the deferral is invisible except in time.
+     * The two sets of normal planes alternate. */
+    const size_t N = (size_t)c->W * c->H;
+    const int set = c->nrm_parity;
+    c->nrm_parity ^= 1;
+    float* nrm = c->normals + (size_t)set * 3 * N;
+    if (!c->pending.valid) {
+        gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr);
+        HIP_TRY(hipGetLastError());
+    } else {
+        const float* pn = c->normals + (size_t)c->pending.set * 3 * N;
+        int rc = launch_fuse(c, c->pending.depth, pn, c->pending.pose, 0, depth_dev, nrm);
+        c->pending.valid = false;
+        if (rc) return rc;
+    }
+    c->pending.valid = true; c->pending.depth = depth_dev; c->pending.pose = pose; c->pending.set = set;
+    return GSDF_OK;
 }
 
 int gsdf_update(gsdf_ctx* c, const float* depth_host, const float R[9], const float t[3]) {
+    GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     if (!depth_host) return fail(GSDF_ERR_INVALID, "null depth");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, (size_t)c->W * c->H * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    c->upload_pending = true;
     rc = gsdf_update_dev(c, c->depth_stage, R, t);
     if (rc) return rc;
     return gsdf_sync(c);
 }
 
 int gsdf_set_pose(gsdf_ctx* c, const float pose7[7]) {
+    GSDF_FLUSH(c);
     if (!c || !pose7) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     gsdf_launch_set_pose(c->stream, c->st, nullptr, pose7);
@@ -565,6 +570,7 @@ int gsdf_set_pose(gsdf_ctx* c, const float pose7[7]) {
 }
 
 int gsdf_get_pose(gsdf_ctx* c, float pose7[7]) {
+    GSDF_FLUSH(c);
     if (!c || !pose7) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     gsdf_dev_state s;
@@ -576,6 +582,7 @@ int gsdf_get_pose(gsdf_ctx* c, float pose7[7]) {
 
 int gsdf_track(gsdf_ctx* c, const float* depth_host, const float K[9], float pose7[7], int num_iterations,
                float conv_threshold, float damping, int* converged, int* passes) {
+    GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     if (!depth_host || !K || !pose7) return fail(GSDF_ERR_INVALID, "null argument");
@@ -597,6 +604,7 @@ int gsdf_track(gsdf_ctx* c, const float* depth_host, const float K[9], float pos
 
 int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9], int num_iterations,
                             float conv_threshold, float damping) {
+    GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     if (!depth_dev || !K) return fail(GSDF_ERR_INVALID, "null argument");
@@ -611,6 +619,7 @@ int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9
 }
 
 int gsdf_read_frame_log(gsdf_ctx* c, float* rows10, int64_t max_rows, int64_t* n_rows) {
+    GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -628,6 +637,7 @@ int gsdf_read_frame_log(gsdf_ctx* c, float* rows10, int64_t max_rows, int64_t* n
 }
 
 int gsdf_sync(gsdf_ctx* c) {
+    GSDF_FLUSH(c);
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     gsdf_dev_state s;
@@ -638,6 +648,7 @@ int gsdf_sync(gsdf_ctx* c) {
 }
 
 int gsdf_get_stats(gsdf_ctx* c, gsdf_stats* out) {
+    GSDF_FLUSH(c);
     if (!c || !out) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     gsdf_dev_state s;
@@ -662,6 +673,7 @@ int gsdf_get_stats(gsdf_ctx* c, gsdf_stats* out) {
 }
 
 int gsdf_count(gsdf_ctx* c, int64_t* n) {
+    GSDF_FLUSH(c);
     if (!c || !n) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
@@ -677,10 +689,12 @@ static int export_impl(gsdf_ctx* c, int32_t* keys, float* payload, uint32_t* vis
                        int sorted, int raw_sums);
 
 int gsdf_export(gsdf_ctx* c, int32_t* keys, float* payload, int64_t max_n, int64_t* n_out, int sorted, int raw_sums) {
+    GSDF_FLUSH(c);
     return export_impl(c, keys, payload, nullptr, max_n, n_out, sorted, raw_sums);
 }
 
 int gsdf_enable_vis(gsdf_ctx* c, int max_frames) {
+    GSDF_FLUSH(c);
     if (!c || max_frames <= 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -694,6 +708,7 @@ int gsdf_enable_vis(gsdf_ctx* c, int max_frames) {
 }
 
 int gsdf_export_vis(gsdf_ctx* c, int32_t* keys, uint32_t* words, int words_per_voxel, int64_t max_n, int64_t* n_out) {
+    GSDF_FLUSH(c);
     if (!c || !words) return fail(GSDF_ERR_INVALID, "null argument");
     if (!c->vis) return fail(GSDF_ERR_INVALID, "gsdf_enable_vis was not called");
     if (words_per_voxel != c->vis_words) return fail(GSDF_ERR_INVALID, "words_per_voxel differs from gsdf_enable_vis");
@@ -752,6 +767,7 @@ static int export_impl(gsdf_ctx* c, int32_t* keys, float* payload, uint32_t* vis
 }
 
 int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, int64_t n) {
+    GSDF_FLUSH(c);
     if (!c || (n > 0 && (!keys || !payload_raw))) return fail(GSDF_ERR_INVALID, "null argument");
     if (n <= 0) return GSDF_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -763,6 +779,7 @@ int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, i
     e = hipMemcpyAsync(dk, keys, (size_t)n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(dp, payload_raw, (size_t)n * 5 * sizeof(float), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
+        c->occ_dirty = true;
         gsdf_launch_merge_raw(c->stream, c->tab, dk, dp, n, c->st);
         e = hipStreamSynchronize(c->stream);
     }
@@ -773,6 +790,7 @@ int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, i
 }
 
 int gsdf_export_raw_dev(gsdf_ctx* c, int32_t* keys_dev, float* payload_dev, int64_t max_n, int64_t* n) {
+    GSDF_FLUSH(c);
     if (!c || !keys_dev || !payload_dev || max_n < 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
@@ -786,9 +804,11 @@ int gsdf_export_raw_dev(gsdf_ctx* c, int32_t* keys_dev, float* payload_dev, int6
 }
 
 int gsdf_merge_raw_dev(gsdf_ctx* c, const int32_t* keys_dev, const float* payload_raw_dev, int64_t n) {
+    GSDF_FLUSH(c);
     if (!c || (n > 0 && (!keys_dev || !payload_raw_dev))) return fail(GSDF_ERR_INVALID, "null argument");
     if (n <= 0) return GSDF_OK;
     HIP_TRY(hipSetDevice(c->device));
+    c->occ_dirty = true;
     gsdf_launch_merge_raw(c->stream, c->tab, keys_dev, payload_raw_dev, n, c->st);
     HIP_TRY(hipGetLastError());
     return gsdf_sync(c);
@@ -825,6 +845,7 @@ int gsdf_ba_set_loss(gsdf_ctx* c, int loss, float lambda) {
 
 int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float* poses16_host, const int* frame_idx,
                   float reg_weight) {
+    GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     if (!c->vis) return fail(GSDF_ERR_INVALID, "PhotoBA needs the vis_ bit-vectors: call gsdf_enable_vis before fusing");
@@ -854,6 +875,7 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
 }
 
 int gsdf_ba_energy(gsdf_ctx* c, float* E) {
+    GSDF_FLUSH(c);
     int rc = ba_require(c);
     if (rc) return rc;
     if (!E) return fail(GSDF_ERR_INVALID, "null argument");
@@ -869,6 +891,7 @@ int gsdf_ba_energy(gsdf_ctx* c, float* E) {
 }
 
 int gsdf_ba_solve_dist(gsdf_ctx* c, float damping) {
+    GSDF_FLUSH(c);
     int rc = ba_require(c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -879,6 +902,7 @@ int gsdf_ba_solve_dist(gsdf_ctx* c, float damping) {
 }
 
 int gsdf_ba_solve_pose(gsdf_ctx* c, float damping) {
+    GSDF_FLUSH(c);
     (void)damping;                                            /* unused by the reference as well (:499) */
     int rc = ba_require(c);
     if (rc) return rc;
@@ -912,6 +936,7 @@ int gsdf_ba_solve_pose(gsdf_ctx* c, float damping) {
 }
 
 int gsdf_ba_optimize(gsdf_ctx* c, int max_it, float* energies, int* n_energies, int* converged) {
+    GSDF_FLUSH(c);
     int rc = ba_require(c);
     if (rc) return rc;
     if (!energies || !n_energies || !converged || max_it < 0) return fail(GSDF_ERR_INVALID, "bad argument");
@@ -948,6 +973,7 @@ int gsdf_ba_get_poses(gsdf_ctx* c, float* poses16_host) {
 }
 
 int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float* grad, float* w) {
+    GSDF_FLUSH(c);
     if (!c || (n > 0 && (!pts_host || !dist || !grad || !w))) return fail(GSDF_ERR_INVALID, "null argument");
     if (n <= 0) return GSDF_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -972,6 +998,7 @@ int gsdf_query(gsdf_ctx* c, const float* pts_host, int64_t n, float* dist, float
 }
 
 int gsdf_get_voxels(gsdf_ctx* c, const int32_t* keys_host, int64_t n, float* payload, int32_t* found) {
+    GSDF_FLUSH(c);
     if (!c || (n > 0 && (!keys_host || !payload || !found))) return fail(GSDF_ERR_INVALID, "null argument");
     if (n <= 0) return GSDF_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -1011,6 +1038,10 @@ static int raycast_enqueue(gsdf_ctx* c, const float K[9], const float R[9], cons
         HIP_TRY(hipMemsetAsync(c->rc_counts, 0, n_wg * 8 * sizeof(unsigned long long), c->stream));
         c->rc_rows = n_wg;
     }
+    if (c->occ_dirty) {                                       /* the map changed since the filters were built */
+        gsdf_launch_occ_rebuild(c->stream, c->tab);
+        c->occ_dirty = false;
+    }
     prof_scope ps(c, 3);
     gsdf_launch_raycast(c->stream, c->tab, c->voxel_size, c->voxel_size_inv, c->factor, W, H, K, pose, zmin, zmax, depth_dev,
                         normals_dev, c->rc_counts, c->debug & 0xFFFF);
@@ -1019,6 +1050,7 @@ static int raycast_enqueue(gsdf_ctx* c, const float K[9], const float R[9], cons
 
 int gsdf_raycast_dev(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
                      float* depth_dev, float* normals_dev) {
+    GSDF_FLUSH(c);
     if (!c || !K || !R || !t || !depth_dev) return fail(GSDF_ERR_INVALID, "null argument");
     if (W <= 0 || H <= 0 || !(zmax > zmin) || !(zmin > 0.f)) return fail(GSDF_ERR_INVALID, "W,H > 0 and 0 < zmin < zmax required");
     HIP_TRY(hipSetDevice(c->device));
@@ -1030,6 +1062,7 @@ int gsdf_raycast_dev(gsdf_ctx* c, const float K[9], const float R[9], const floa
 
 int gsdf_raycast(gsdf_ctx* c, const float K[9], const float R[9], const float t[3], int W, int H, float zmin, float zmax,
                  float* depth_out, float* normals_out) {
+    GSDF_FLUSH(c);
     if (!c || !K || !R || !t || !depth_out) return fail(GSDF_ERR_INVALID, "null argument");
     if (W <= 0 || H <= 0 || !(zmax > zmin) || !(zmin > 0.f)) return fail(GSDF_ERR_INVALID, "W,H > 0 and 0 < zmin < zmax required");
     HIP_TRY(hipSetDevice(c->device));
@@ -1065,6 +1098,7 @@ int gsdf_raycast_counters(gsdf_ctx* c, int64_t* samples, int64_t* records, int r
 
 int gsdf_extract_mesh(gsdf_ctx* c, float iso, const int8_t tri_table[256 * 16], float* triangles_out, int64_t max_tris,
                       int64_t* n_tris) {
+    GSDF_FLUSH(c);
     if (!c || !n_tris || (max_tris > 0 && !triangles_out)) return fail(GSDF_ERR_INVALID, "null argument");
     if (!tri_table) tri_table = GSDF_MC_TRI_TABLE;            /* the reference's triTable (LayeredMarchingCubesNoColor.cpp:96-352) */
     HIP_TRY(hipSetDevice(c->device));
@@ -1117,6 +1151,7 @@ int gsdf_extract_mesh(gsdf_ctx* c, float iso, const int8_t tri_table[256 * 16], 
 }
 
 int gsdf_block_keys_dev(gsdf_ctx* c, uint64_t* keys_dev, int64_t max_n, int64_t* n) {
+    GSDF_FLUSH(c);
     if (!c || !n || (max_n > 0 && !keys_dev)) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
@@ -1128,6 +1163,7 @@ int gsdf_block_keys_dev(gsdf_ctx* c, uint64_t* keys_dev, int64_t max_n, int64_t*
     return GSDF_OK;
 }
 int gsdf_pack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t n, float* dense_dev) {
+    GSDF_FLUSH(c);
     if (!c || (n > 0 && (!block_keys_dev || !dense_dev))) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     gsdf_launch_pack_blocks(c->stream, c->tab, (const unsigned long long*)block_keys_dev, n, dense_dev);
@@ -1136,8 +1172,10 @@ int gsdf_pack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t n,
     return GSDF_OK;
 }
 int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t n, const float* dense_dev) {
+    GSDF_FLUSH(c);
     if (!c || (n > 0 && (!block_keys_dev || !dense_dev))) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    c->occ_dirty = true;
     gsdf_launch_unpack_blocks(c->stream, c->tab, (const unsigned long long*)block_keys_dev, n, dense_dev, c->st);
     HIP_TRY(hipGetLastError());
     return gsdf_sync(c);
@@ -1150,6 +1188,7 @@ int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes) {
     return GSDF_OK;
 }
 int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr) {
+    GSDF_FLUSH(c);
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1157,6 +1196,7 @@ int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr) {
     return GSDF_OK;
 }
 int gsdf_dev_download(gsdf_ctx* c, void* host_dst, const void* dev_src, int64_t bytes) {
+    GSDF_FLUSH(c);
     if (!c || !host_dst || !dev_src || bytes < 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(host_dst, dev_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1188,10 +1228,10 @@ int gsdf_dev_upload_async(gsdf_ctx* c, void* dev_dst, const void* host_src, int6
     if (!c || !dev_dst || !host_src || bytes < 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
-    c->upload_pending = true;                      /* a GT-pose fusion's normals (second stream) must wait for it */
     return GSDF_OK;
 }
 int gsdf_mark(gsdf_ctx* c, int64_t* mark) {
+    GSDF_FLUSH(c);
     if (!c || !mark) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     hipEvent_t e = nullptr;
@@ -1228,12 +1268,14 @@ int gsdf_mark_reached(gsdf_ctx* c, int64_t mark, int* reached) {
 }
 
 int gsdf_timer_start(gsdf_ctx* c) {
+    GSDF_FLUSH(c);
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     return GSDF_OK;
 }
 int gsdf_timer_stop_ms(gsdf_ctx* c, float* ms) {
+    GSDF_FLUSH(c);
     if (!c || !ms) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
@@ -1243,6 +1285,7 @@ int gsdf_timer_stop_ms(gsdf_ctx* c, float* ms) {
 }
 
 int gsdf_profile(gsdf_ctx* c, int enable) {
+    GSDF_FLUSH(c);
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -19,6 +19,9 @@
 
 inline thread_local std::string g_gsdf_err;
 
+struct gsdf_ctx;
+int gsdf_flush_pending(gsdf_ctx* c);               /* gsdf_capi.hip: launch the deferred GT-pose fusion, if one waits */
+
 inline int gsdf_fail(int code, const std::string& msg) {
     g_gsdf_err = msg;
     return code;
@@ -33,11 +36,10 @@ inline int gsdf_fail(int code, const std::string& msg) {
 struct gsdf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;                 /* GT-pose fusion: NormalEstimator::compute of the next frame beside the running fusion */
-    hipEvent_t ev_nrm_ready[2] = { nullptr, nullptr }, ev_fuse_done[2] = { nullptr, nullptr }, ev_upload = nullptr;
-    bool fuse_done_valid[2] = { false, false };
-    int nrm_parity = 0, last_nrm_set = 0;          /* which set of normal planes the next / the last GT-pose fusion uses */
-    bool upload_pending = false;                   /* an asynchronous upload was queued on `stream` since the last GT-pose fusion */
+    /* a GT-pose fusion whose launch waits for the next gsdf_update_dev (its launch then also computes that frame's normals) */
+    struct pending_fuse { bool valid = false; const float* depth = nullptr; gsdf_pose_arg pose; int set = 0; } pending;
+    int defer = 1;                                 /* pipeline runs of gsdf_update_dev that way (GSDF_DEFER=0: launch at once) */
+    int nrm_parity = 0;                            /* which set of normal planes the next GT-pose fusion uses (0 / 1; set 2: tracked frames) */
     /* MapGradPixelSdf / Sdf members */
     float voxel_size = 0, voxel_size_inv = 0, T = 0, inv_T = 0;
     float zmin = 0.5f, zmax = 3.5f;                /* Sdf.h:67-68 */
@@ -45,7 +47,7 @@ struct gsdf_ctx {
     /* table */
     int capacity_log2 = 0;
     size_t n_slots = 0;
-    gsdf_table tab{ nullptr, nullptr, 0, nullptr, 0, nullptr, 0 };
+    gsdf_table tab{ nullptr, nullptr, 0, nullptr };
     /* normal estimator + frame scratch */
     int W = 0, H = 0, win = 0;
     float K[9] = { 0 };
@@ -75,6 +77,7 @@ struct gsdf_ctx {
     size_t rc_rows = 0;
     long long rc_iters[2] = { 0, 0 };              /* loop iterations of the workgroups' wave 0 as of the last gsdf_raycast_counters */
     void* scratch = nullptr;                       /* device scratch of gsdf_query / gsdf_get_voxels for small batches (GSDF_SCRATCH_BYTES) */
+    bool occ_dirty = false;                        /* blocks may have been inserted since the raycaster's filters (gsdf_table::occ) were built */
     bool merged = false;                           /* gsdf_merge_allreduce has run: the map is the sum of all ranks (one-shot) */
     /* PhotoBA (PhotometricOptimizer) */
     int ba_n = 0;

@@ -80,6 +80,7 @@ struct __attribute__((aligned(16))) gsdf_deferred {
 };
 
 void gsdf_launch_table_clear(hipStream_t s, gsdf_table tab, size_t n_slots);
+void gsdf_launch_occ_rebuild(hipStream_t s, gsdf_table tab);      /* block / cell filters of the raycaster from the key array */
 void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int win, float* planes11);
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
                          const float* depth, float* nx, float* ny, float* nz,
@@ -100,7 +101,9 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       unsigned int* ticket /* two device words, zeroed once: arrivals of finished workgroups of k_fuse / of k_fuse_resolve */,
                       int resolve_follows /* also queue k_fuse_resolve (long deferred lists) */,
                       unsigned int* host_note /* nullable, 2 pinned host words: length of the deferred list, tiles too big for the small LDS table */,
-                      int far_table /* use the kernel with the larger LDS table */);
+                      int far_table /* use the kernel with the larger LDS table */,
+                      const float* next_depth /* nullable: the launch also computes the normals of this (the next) frame ... */,
+                      float* next_nx, float* next_ny, float* next_nz /* ... into these planes */, int win);
 int  gsdf_fuse_grid_blocks(int W, int H);
 void gsdf_fuse_tile_order(int W, int H, uint32_t* order_host /* [gsdf_fuse_grid_blocks] */);
 /* per-launch parameters of one Gauss-Newton pass (RigidOptimizer.h:57-62) */

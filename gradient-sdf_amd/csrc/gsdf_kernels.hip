@@ -110,12 +110,24 @@ __global__ __launch_bounds__(256) void k_table_clear(gsdf_table tab, size_t n_bl
     uint4* p = reinterpret_cast<uint4*>(tab.vox);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_blocks; i += stride) tab.bkeys[i] = GSDF_KEY_EMPTY;
-    const size_t n_occ = ((size_t)tab.occ_mask + 1) / 32, n_occ2 = ((size_t)tab.occ2_mask + 1) / 32;
+    const size_t n_occ = ((size_t)gsdf_occ_mask(tab) + 1) / 32 + ((size_t)gsdf_occ2_mask(tab) + 1) / 32;      /* block filter + cell filter */
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_occ; i += stride) tab.occ[i] = 0u;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_occ2; i += stride) tab.occ2[i] = 0u;
 }
 void gsdf_launch_table_clear(hipStream_t s, gsdf_table tab, size_t n_slots) {
     hipLaunchKernelGGL(k_table_clear, dim3(2048), dim3(256), 0, s, tab, n_slots / GSDF_BLOCK_VOX);
+}
+/* block filter + cell filter from the key array (the filters were zeroed by the caller): one lane per entry */
+__global__ __launch_bounds__(256) void k_occ_rebuild(gsdf_table tab, size_t n_blocks) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_blocks) return;
+    const unsigned long long bk = tab.bkeys[i];
+    if (bk != GSDF_KEY_EMPTY) gsdf_occ_set(tab, bk);
+}
+void gsdf_launch_occ_rebuild(hipStream_t s, gsdf_table tab) {
+    const size_t n_blocks = (size_t)tab.block_mask + 1;
+    const size_t bytes = (((size_t)gsdf_occ_mask(tab) + 1) / 32 + ((size_t)gsdf_occ2_mask(tab) + 1) / 32) * sizeof(uint32_t);
+    (void)hipMemsetAsync(tab.occ, 0, bytes, s);
+    hipLaunchKernelGGL(k_occ_rebuild, dim3((unsigned int)((n_blocks + 255) / 256)), dim3(256), 0, s, tab, n_blocks);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -377,6 +389,13 @@ struct fuse_args {
     long long max_rows;
     int resolve_follows;                /* a k_fuse_resolve launch is queued behind this one: leave long lists to it */
     unsigned int* host_note;            /* nullable, pinned host word: length of this launch's deferred list */
+    /* Workgroups beyond the tiles (GT-pose fusion of resident frames, gsdf_update_dev): NormalEstimator::compute of the NEXT
+     * frame, one 32x16 tile each.  They are the last of the grid, so they run in the launch's tail -- 1200 fusion workgroups
+     * on 512 slots leave the last round a third full -- instead of as a 10 us launch in front of the next fusion. */
+    int n_tiles;                        /* fusion workgroups of this launch */
+    const float* nrm_depth;             /* nullable: depth image of the next frame */
+    float *nrm_x, *nrm_y, *nrm_z;       /* its normal planes (the other set) */
+    int nrm_r, nrm_ntx;                 /* window radius, normals tiles per image row */
 };
 #define FUSE_RESOLVE_INLINE 8192u       /* deferred entries the last workgroup adds itself even when a resolve launch follows */
 
@@ -476,10 +495,20 @@ __device__ __forceinline__ void fuse_log_row(const fuse_args& a) {
     st->log_rows = r + 1;
 }
 
-template <int LCAP>
+/* NEXT_NORMALS: the instantiation whose launches carry the normals workgroups of the next frame (GT-pose runs).  The tracked
+ * path uses the one without: the extra role costs the fusion code ~2 us per launch in register allocation (measured). */
+template <int LCAP, bool NEXT_NORMALS>
 __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     __shared__ fuse_lds<LCAP> L;
     const int tid = threadIdx.x;
+    if (NEXT_NORMALS && (int)blockIdx.x >= a.n_tiles) {       /* the next frame's normals, in the tail of this launch */
+        static_assert(sizeof(nrm_lds) <= sizeof(fuse_lds<LCAP>), "the normals tile works in the fusion table's LDS");
+        static_assert(FUSE_THREADS == NRM_THREADS, "normals tiles run in fusion-sized workgroups");
+        const int t = (int)blockIdx.x - a.n_tiles;
+        normals_tile(*reinterpret_cast<nrm_lds*>(&L), t % a.nrm_ntx, t / a.nrm_ntx, a.g.W, a.g.H, a.nrm_r, a.nc, a.nrm_depth, a.nrm_x,
+                     a.nrm_y, a.nrm_z);
+        return;
+    }
     /* main_scan_3d.cpp:261: if (conv) update.  The launch may have been queued before optimize() ended (the host
      * issues it behind every batch of passes): it runs only once the pose iteration is done AND converged; the
      * launch that finds it done but NOT converged only writes the frame's log row. */
@@ -1039,7 +1068,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        L.is_last = atomicAdd(a.ticket, 1u) + 1u == gridDim.x ? 1u : 0u;
+        L.is_last = atomicAdd(a.ticket, 1u) + 1u == (NEXT_NORMALS ? (unsigned int)a.n_tiles : gridDim.x) ? 1u : 0u;
         if (L.is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -1107,7 +1136,8 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
                       unsigned int tag, unsigned int* tile_flags, const uint32_t* tile_order, float* log_rows,
                       long long max_rows, uint32_t* vis, int vis_words, int debug, unsigned int* ticket, int resolve_follows,
-                      unsigned int* host_note, int far_table) {
+                      unsigned int* host_note, int far_table, const float* next_depth, float* next_nx, float* next_ny, float* next_nz,
+                      int win) {
     fuse_args a;
     a.host_note = host_note;
     a.ticket = ticket; a.log_rows = use_dev_pose ? log_rows : nullptr; a.max_rows = max_rows; a.resolve_follows = resolve_follows;
@@ -1120,8 +1150,15 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     gsdf_dev_state* gate = use_dev_pose ? st : nullptr;
     a.tile_flags = tile_flags; a.ntx = ntx; a.nty = nty; a.tile_order = tile_order;
     const int n = ntx * nty;
-    if (far_table) hipLaunchKernelGGL(k_fuse<FUSE_LCAP_FAR>, dim3(n), dim3(FUSE_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(k_fuse<FUSE_LCAP_NEAR>, dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(debug, 4096) ? 81920 : 0, s, a);   /* experiment: 1 workgroup per CU */
+    a.n_tiles = n;
+    a.nrm_depth = next_depth; a.nrm_x = next_nx; a.nrm_y = next_ny; a.nrm_z = next_nz;
+    a.nrm_r = win / 2; a.nrm_ntx = (g.W + NRM_TX - 1) / NRM_TX;
+    const int extra = next_depth ? a.nrm_ntx * ((g.H + NRM_TY - 1) / NRM_TY) : 0;
+    if (extra) {
+        if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
+    } else if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, false>), dim3(n), dim3(FUSE_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, false>), dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(debug, 4096) ? 81920 : 0, s, a);   /* experiment: 1 workgroup per CU */
     if (resolve_follows)
         hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st, ticket + 1);
 }
@@ -1239,7 +1276,7 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
         gsdf_v3 p[TRK_PPT];
         int vx[TRK_PPT], vy[TRK_PPT], vz[TRK_PPT];
         unsigned long long key[TRK_PPT], bkey[TRK_PPT], k0[TRK_PPT];
-        uint32_t home[TRK_PPT], obit[TRK_PPT], oword[TRK_PPT];
+        uint32_t home[TRK_PPT];
 #pragma unroll
         for (int j = 0; j < TRK_PPT; ++j) {
             const int pix = base + j * nthreads;
@@ -1258,10 +1295,6 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
             bkey[j] = gsdf_block_key(key[j]);
             home[j] = gsdf_hash(bkey[j]) & tab.block_mask;
             k0[j] = ok[j] ? tab.bkeys[home[j]] : GSDF_KEY_EMPTY;
-            /* the block filter, requested together with the home entry: pixels that look past the map (~1 in 6 on the bench
-             * stream) would otherwise walk their probe sequence to an empty entry, and the wave waits for its longest chain */
-            obit[j] = ok[j] ? gsdf_occ_bit_vox(tab, vx[j], vy[j], vz[j]) : 0u;
-            oword[j] = ok[j] ? tab.occ[obit[j] >> 5] : 0u;
         }
         /* stage C: the voxel record (neighbouring pixels share lines: 4 x-adjacent voxels per line) */
         const gsdf_payload* P[TRK_PPT];
@@ -1270,7 +1303,7 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
         {
             uint32_t want = 0u;
 #pragma unroll
-            for (int j = 0; j < TRK_PPT; ++j) want |= (ok[j] && gsdf_occ_test(oword[j], obit[j])) ? 1u << j : 0u;
+            for (int j = 0; j < TRK_PPT; ++j) want |= ok[j] ? 1u << j : 0u;
             gsdf_block_lookup_n<TRK_PPT, false>(tab, bkey, home, k0, want, blk);   /* the pixels' probe chains overlap */
         }
 #pragma unroll
@@ -1961,7 +1994,7 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
             /* 1. + 2. cell filter and block filter, both words requested together (in a band only the block filter) */
             const uint32_t cb = inr && in_coarse ? gsdf_occ2_bit_vox(tab, vx, vy, vz) : 0u;
             const uint32_t ob = inr ? gsdf_occ_bit_vox(tab, vx, vy, vz) : 0u;
-            const uint32_t cw = inr && in_coarse ? tab.occ2[cb >> 5] : 0xFFFFFFFFu;
+            const uint32_t cw = inr && in_coarse ? gsdf_occ2(tab)[cb >> 5] : 0xFFFFFFFFu;
             const uint32_t ow = inr ? tab.occ[ob >> 5] : 0u;
             if (in_coarse && inr && !gsdf_occ_test(cw, cb)) {
                 missing = true;

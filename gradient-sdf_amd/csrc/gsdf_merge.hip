@@ -197,6 +197,7 @@ unsigned long long random_token(const gsdf_ctx* c) {
 
 int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes_out) {
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = gsdf_flush_pending(c)) return rc;            /* the last frame's fusion may still wait for a successor (gsdf_update_dev) */
     if (c->merged && tr.nranks > 1)
         return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: this map already holds the sum of all ranks (the exchange is one-shot: "
                                            "a second one would count every rank's frames again); gsdf_reset starts over");
@@ -301,6 +302,7 @@ int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes
             rc = tr.allreduce_or_u32(c, (uint32_t*)dense_vis.p, vis_count);
             if (rc) return rc;
         }
+        c->occ_dirty = true;
         gsdf_launch_unpack_blocks(c->stream, c->tab, uk, (long long)nu, (const float*)dense.p, c->st);
         if (vw) gsdf_launch_unpack_vis(c->stream, c->tab, c->vis, vw, uk, (long long)nu, (const uint32_t*)dense_vis.p);
     }

@@ -52,20 +52,24 @@ struct gsdf_table {
     unsigned long long* bkeys;        /* [block_mask + 1] */
     gsdf_payload* vox;                /* [(block_mask + 1) * 64] */
     uint32_t block_mask;              /* number of blocks - 1 (power of two) */
-    /* Block filter: one bit per block KEY, at a hashed position among 64 x n_blocks bits (512 KB at the 2^22-voxel default),
-     * set when the block is inserted.  A clear bit proves the block absent with ONE load; without it an unsuccessful lookup
-     * walks its probe sequence to the first empty entry (1.7 entries at 40 % load -- and a wave waits for the longest of its
-     * lanes' chains: 5-8 dependent L2 round trips per sample of the raycaster's empty-space walk, measured).  A set bit
-     * (present, or 1 in ~150 absent blocks at that load) is followed by the normal probe.  Lookups that mostly succeed
-     * (fusion flush) do not use it. */
-    uint32_t* occ;                    /* [(occ_mask + 1) / 32] */
-    uint32_t occ_mask;                /* number of filter bits - 1 (power of two) */
+    /* Block filter: one bit per block KEY, at a hashed position among 64 x n_blocks bits (512 KB at the 2^22-voxel default).
+     * A clear bit proves the block absent with ONE load and a few instructions -- no key packing, no 64-bit hash, no walk of
+     * the probe sequence to the first empty entry; a set bit (present, or 1 in ~150 absent blocks at 40 % load) is followed by
+     * the normal probe.  Its user is the raycaster, most of whose samples lie in empty space.
+     * The filters are REBUILT from the key array when a raycast finds the map changed (k_occ_rebuild, a few us): setting the
+     * bits where blocks are inserted -- inside the fusion kernel's flush -- cost that kernel 24 vector registers and 16 more
+     * spilled scalar registers (measured: 97 -> 121 VGPRs, +2 us per fusion), for a structure the frame loop never reads. */
+    uint32_t* occ;                    /* 64 x n_blocks bits, then the cell filter below */
     /* The same one level up: one bit per CELL of 8x8x8 blocks (32^3 voxels) that holds a block, among n_blocks bits (8 KB at
-     * the default: L1-resident).  A ray crossing empty space tests the cell of its sample and, when the bit is clear, knows
-     * every sample up to the cell's far face to be missing without looking at any of them (the raycaster's empty-space skip). */
-    uint32_t* occ2;                   /* [(occ2_mask + 1) / 32] */
-    uint32_t occ2_mask;
+     * the default: L1-resident), stored behind the block filter.  A ray crossing empty space tests the cell of its sample and,
+     * when the bit is clear, knows every sample up to the cell's far face to be missing without looking at any of them (the
+     * raycaster's empty-space skip).
+     * Sizes and the second pointer are derived from block_mask (gsdf_occ_mask / gsdf_occ2_mask / gsdf_occ2): the struct is a
+     * kernel argument of the fusion kernel, which has no scalar registers to spare. */
 };
+__host__ __device__ __forceinline__ uint32_t gsdf_occ_mask(const gsdf_table& T) { return (T.block_mask << 6) | 63u; }   /* filter bits - 1 */
+__host__ __device__ __forceinline__ uint32_t gsdf_occ2_mask(const gsdf_table& T) { return T.block_mask | 31u; }         /* cell filter bits - 1 (>= one word) */
+__host__ __device__ __forceinline__ uint32_t* gsdf_occ2(const gsdf_table& T) { return T.occ + 2 * ((size_t)T.block_mask + 1); }
 #define GSDF_CELL_SHIFT 5             /* voxels per cell edge = 32 */
 
 __host__ __device__ __forceinline__ bool gsdf_key_in_range(int x, int y, int z) {
@@ -118,7 +122,7 @@ __host__ __device__ __forceinline__ uint32_t gsdf_probe_step(unsigned long long 
  * space evaluates it once per sample).  Neighbouring blocks never share a bit; blocks far apart alias at random, which only
  * costs a wasted probe (a set bit is always followed by the real lookup). */
 __host__ __device__ __forceinline__ uint32_t gsdf_occ_index(const gsdf_table& T, uint32_t bx, uint32_t by, uint32_t bz) {
-    return (bx + by * 0x9E3779u + bz * 0x85EBCBu) & T.occ_mask;
+    return (bx + by * 0x9E3779u + bz * 0x85EBCBu) & gsdf_occ_mask(T);
 }
 __host__ __device__ __forceinline__ uint32_t gsdf_occ_bit(const gsdf_table& T, unsigned long long bk) {
     return gsdf_occ_index(T, (uint32_t)(bk & 0x7FFFFull), (uint32_t)((bk >> 19) & 0x7FFFFull), (uint32_t)((bk >> 38) & 0x7FFFFull));
@@ -130,7 +134,7 @@ __host__ __device__ __forceinline__ uint32_t gsdf_occ_bit_vox(const gsdf_table& 
 
 /* position of a cell in the cell filter, from its biased cell coordinates ((v + 2^20) >> 5, 16 bits each) */
 __host__ __device__ __forceinline__ uint32_t gsdf_occ2_index(const gsdf_table& T, uint32_t cx, uint32_t cy, uint32_t cz) {
-    return (cx + cy * 0x6C8E95u + cz * 0xB5297Bu) & T.occ2_mask;
+    return (cx + cy * 0x6C8E95u + cz * 0xB5297Bu) & gsdf_occ2_mask(T);
 }
 __host__ __device__ __forceinline__ uint32_t gsdf_occ2_bit_vox(const gsdf_table& T, int x, int y, int z) {
     return gsdf_occ2_index(T, (uint32_t)(x + GSDF_KEY_OFF) >> GSDF_CELL_SHIFT, (uint32_t)(y + GSDF_KEY_OFF) >> GSDF_CELL_SHIFT,
@@ -138,13 +142,13 @@ __host__ __device__ __forceinline__ uint32_t gsdf_occ2_bit_vox(const gsdf_table&
 }
 
 #if defined(__HIPCC__)
-/* a block has been inserted: its bit in the block filter and its cell's bit in the cell filter */
+/* the bits of one existing block: block filter and cell filter (k_occ_rebuild) */
 __device__ __forceinline__ void gsdf_occ_set(const gsdf_table& T, unsigned long long bk) {
     const uint32_t bx = (uint32_t)(bk & 0x7FFFFull), by = (uint32_t)((bk >> 19) & 0x7FFFFull), bz = (uint32_t)((bk >> 38) & 0x7FFFFull);
     const uint32_t b = gsdf_occ_index(T, bx, by, bz);
     atomicOr(&T.occ[b >> 5], 1u << (b & 31u));
     const uint32_t c = gsdf_occ2_index(T, bx >> (GSDF_CELL_SHIFT - 2), by >> (GSDF_CELL_SHIFT - 2), bz >> (GSDF_CELL_SHIFT - 2));
-    atomicOr(&T.occ2[c >> 5], 1u << (c & 31u));
+    atomicOr(&gsdf_occ2(T)[c >> 5], 1u << (c & 31u));
 }
 /* false: the block is certainly absent */
 __device__ __forceinline__ bool gsdf_occ_test(uint32_t word, uint32_t bit) { return (word >> (bit & 31u)) & 1u; }
@@ -170,7 +174,7 @@ __device__ __forceinline__ void gsdf_block_lookup_n(const gsdf_table& T, const u
             unsigned long long kk = k[e];
             if (INSERT && kk == GSDF_KEY_EMPTY) {
                 kk = atomicCAS(&T.bkeys[h[e]], GSDF_KEY_EMPTY, bk[e]);
-                if (kk == GSDF_KEY_EMPTY) { kk = bk[e]; gsdf_occ_set(T, bk[e]); }      /* a new block: rare */
+                if (kk == GSDF_KEY_EMPTY) kk = bk[e];
             }
             if (kk == bk[e]) { b[e] = (int)h[e]; pend &= ~(1u << e); }
             else if (!INSERT && kk == GSDF_KEY_EMPTY) pend &= ~(1u << e);   /* entries are never freed: an empty one ends the chain */
