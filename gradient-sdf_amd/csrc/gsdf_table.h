@@ -147,8 +147,11 @@ __device__ __forceinline__ void gsdf_occ_set(const gsdf_table& T, unsigned long 
     const uint32_t bx = (uint32_t)(bk & 0x7FFFFull), by = (uint32_t)((bk >> 19) & 0x7FFFFull), bz = (uint32_t)((bk >> 38) & 0x7FFFFull);
     const uint32_t b = gsdf_occ_index(T, bx, by, bz);
     atomicOr(&T.occ[b >> 5], 1u << (b & 31u));
+    /* up to 512 blocks share a cell, 32 cells a word: only the first block of a cell needs the atomic (same-address atomics
+     * serialise: 25 us for the bench map without this look; a stale look only costs a redundant atomic) */
     const uint32_t c = gsdf_occ2_index(T, bx >> (GSDF_CELL_SHIFT - 2), by >> (GSDF_CELL_SHIFT - 2), bz >> (GSDF_CELL_SHIFT - 2));
-    atomicOr(&gsdf_occ2(T)[c >> 5], 1u << (c & 31u));
+    uint32_t* w = &gsdf_occ2(T)[c >> 5];
+    if (!((__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (c & 31u)) & 1u)) atomicOr(w, 1u << (c & 31u));
 }
 /* false: the block is certainly absent */
 __device__ __forceinline__ bool gsdf_occ_test(uint32_t word, uint32_t bit) { return (word >> (bit & 31u)) & 1u; }

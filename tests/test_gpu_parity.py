@@ -753,3 +753,52 @@ def test_full_size_properties_order_and_sharding(pkg):
     assert (np.abs(pa - pf) / scale).max() <= 1e-5
     for g in (fwd, bwd, a, b):
         g.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_gt_pose_fusion_is_invisible_except_in_time(pkg, O):
+    """gsdf_update_dev defers the launch of a frame's fusion until the next frame arrives (whose normals that launch computes in
+    its tail).  Whatever the caller does in between must see the map WITH the waiting frame: counts, exports, stats, tracking,
+    raycasts; a reset drops it together with the map; the frame counter and vis_ bits follow the call order."""
+    W, H = 320, 240
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=6, seed=0)
+    vs = np.float32(0.02)
+    T = np.float32(5) * vs
+    fr = [seq.frame(i) for i in range(6)]
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=20)
+    g.enable_vis(8)
+    o = O.Oracle(vs, T, W, H, seq.K)
+    dev = [g.upload(f[0]) for f in fr]
+    counts = []
+    for i in range(4):
+        g.update_dev(dev[i], fr[i][1], fr[i][2])
+        o.update(*fr[i])
+        if i in (0, 2):                               # a query between two frames: the waiting fusion is launched first
+            assert g.count() == o.count()
+            assert g.stats()["frames"] == i + 1
+        counts.append(o.count())
+    kg, pg = g.export(sorted=True)
+    ko, po = o.export()
+    assert np.array_equal(kg, ko) and np.abs(pg[:, 0] - po[:, 0]).max() <= TOL
+    kv, vis = g.export_vis()
+    assert np.array_equal(kv, ko) and np.array_equal(vis, o.export_vis(1))
+    # tracking right after a deferred fusion reads the map with it
+    g.update_dev(dev[4], fr[4][1], fr[4][2])
+    o.update(*fr[4])
+    p0 = pose7_from(O, fr[4][1], fr[4][2])
+    cg, pose_g, passes_g = g.track(fr[5][0], p0, iters=3)
+    co, pose_o, passes_o, _, _ = o.track(fr[5][0], p0, iters=3)
+    assert passes_g == passes_o and np.abs(pose_g - pose_o).max() <= 5 * TOL
+    # ... and so does a raycast (whose block filters are rebuilt because the map changed)
+    g.update_dev(dev[5], fr[5][1], fr[5][2])
+    o.update(*fr[5])
+    zg, _ = g.raycast(fr[5][1], fr[5][2])
+    zo, _ = o.raycast(fr[5][1], fr[5][2])
+    assert ((zg > 0) == (zo > 0)).mean() > 0.999
+    # a reset drops the frame that was still waiting together with the map
+    g.update_dev(dev[0], fr[0][1], fr[0][2])
+    g.reset()
+    assert g.count() == 0 and g.stats()["frames"] == 0
+    g.update_dev(dev[0], fr[0][1], fr[0][2])
+    assert g.count() == counts[0]
+    g.close()

@@ -11,6 +11,7 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 DRV="python $root/bench.py --gpus 1 --steps 20 --warmup 5"
+if [ -z "${SKIP_BENCH:-}" ]; then
 $DRV > $out/bench_driver_window.json 2> $out/bench_driver_window.err
 GSDF_BENCH_DEBUG=1 python $root/bench.py > $out/bench_default.json 2> $out/bench_default.err
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o bench -- $DRV --cpu-frames 0 > $out/bench_profiled.json 2> $out/rocprof_kernel_trace.err
@@ -20,14 +21,17 @@ python $root/tools/trace_timeline.py /tmp/kt > $out/bench_kernel_timeline.txt 2>
 # the same trace over the default 200-step window (a quarter of its frames does not converge: 25 passes, no fusion)
 rm -rf /tmp/ktd && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktd -o bench -- python $root/bench.py --cpu-frames 0 > $out/bench_default_profiled.json 2> $out/rocprof_kernel_trace_default.err
 python $root/tools/trace_summary.py /tmp/ktd > $out/bench_default_kernel_summary.txt 2>&1
+fi
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
   rm -rf /tmp/pmc$i
-  rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc$i -o pmc -- $DRV --cpu-frames 0 > /dev/null 2> $out/rocprof_pmc$i.err
+  # --only-main: the fused+tracked windows and the roofline replays.  (The sharded flavour creates an RCCL communicator, and
+  # rocprofv3's counter collection, which serialises dispatches, does not get along with RCCL's kernels: the pass hung.)
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc$i -o pmc -- $DRV --only-main > /dev/null 2> $out/rocprof_pmc$i.err
 done
 python $root/tools/pmc_summary.py /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4 /tmp/pmc5 > $out/pmc_counters.txt 2> $out/pmc_summary.err
-python $root/tools/pmc_summary.py --json "$DRV --cpu-frames 0" /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 > $out/pmc_latest.json 2>> $out/pmc_summary.err
+python $root/tools/pmc_summary.py --json "$DRV --only-main" /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 > $out/pmc_latest.json 2>> $out/pmc_summary.err
 # 4. the raycaster: timing against the sample-at-a-time kernel (test build), per-workgroup lifetimes, PMC counters of both
 python $root/tools/raycast_bench.py > $out/raycast_bench.json 2> $out/raycast_bench.err
 GRAFT_REPO_ROOT=$root bash $root/tools/raycast_pmc.sh $tag > /dev/null 2>&1
