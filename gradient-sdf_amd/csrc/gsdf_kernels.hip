@@ -1996,6 +1996,14 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
             const uint32_t ob = inr ? gsdf_occ_bit_vox(tab, vx, vy, vz) : 0u;
             const uint32_t cw = inr && in_coarse ? gsdf_occ2(tab)[cb >> 5] : 0xFFFFFFFFu;
             const uint32_t ow = inr ? tab.occ[ob >> 5] : 0u;
+            /* in a band the sample most likely exists: the home entry of the key array is requested with the filter word (one
+             * round trip less on the chain that decides the render's duration); in empty space it would be a wasted hash */
+            const bool early = inr && !in_coarse;
+            const unsigned long long key = gsdf_key_pack(vx, vy, vz);
+            const unsigned long long bkey = gsdf_block_key(key);
+            uint32_t home = 0u;
+            unsigned long long k0 = GSDF_KEY_EMPTY;
+            if (early) { home = gsdf_hash(bkey) & tab.block_mask; k0 = tab.bkeys[home]; }
             if (in_coarse && inr && !gsdf_occ_test(cw, cb)) {
                 missing = true;
                 /* every sample whose position stays >= half a voxel inside this cell is missing too: depth to the first face */
@@ -2012,10 +2020,8 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
             if (!gsdf_occ_test(ow, ob)) missing = true;
             if (!missing) {
                 /* 3. the lookup proper: probe of the key array + the 32-byte record */
-                const unsigned long long key = gsdf_key_pack(vx, vy, vz);
-                const unsigned long long bkey = gsdf_block_key(key);
-                const uint32_t home = gsdf_hash(bkey) & tab.block_mask;
-                const int blk = gsdf_block_find(tab, bkey, home, tab.bkeys[home]);
+                if (!early) { home = gsdf_hash(bkey) & tab.block_mask; k0 = tab.bkeys[home]; }
+                const int blk = gsdf_block_find(tab, bkey, home, k0);
                 if (blk >= 0) {
                     const float2* q = reinterpret_cast<const float2*>(tab.vox + ((size_t)blk * GSDF_BLOCK_VOX + gsdf_block_local(key)));
                     const float2 a = q[0], b = q[1], c = q[2];
@@ -2044,8 +2050,9 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
     /* counters of the roofline entry: one row per workgroup, plain read-modify-write by its thread 0 (launches are ordered
      * on the stream).  NOT atomics on one word: 2 same-address atomics per wave serialised the whole kernel (measured: +60 us) */
     __shared__ float rc_cnt[4][2];
+    __shared__ unsigned int rc_it[4];
     const float ts = wave_sum((float)n_samp), tr = wave_sum((float)n_rec);           /* < 2^24 per wave: exact */
-    if (lane == 0) { rc_cnt[wave][0] = ts; rc_cnt[wave][1] = tr; }
+    if (lane == 0) { rc_cnt[wave][0] = ts; rc_cnt[wave][1] = tr; rc_it[wave] = it_slow; }
     __syncthreads();
     if (wg_counts && threadIdx.x == 0) {
         unsigned long long* row = wg_counts + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
@@ -2053,6 +2060,7 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
         row[1] += (unsigned long long)(rc_cnt[0][1] + rc_cnt[1][1] + rc_cnt[2][1] + rc_cnt[3][1]);
         row[2] += it_fast; row[3] += it_slow;                           /* lane 0 of wave 0: cell skips / loop iterations */
         row[4] = t_begin; row[5] = wall_clock64();                      /* life of the workgroup, 100 MHz ticks (last launch) */
+        row[6] = max(max(rc_it[0], rc_it[1]), max(rc_it[2], rc_it[3]));   /* loop iterations of its slowest wave (last launch) */
     }
 }
 

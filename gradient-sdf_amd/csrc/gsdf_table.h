@@ -101,7 +101,17 @@ __host__ __device__ __forceinline__ unsigned long long gsdf_voxel_key(unsigned l
     const unsigned long long uz = (((bk >> 38) & 0x7FFFFull) << 2) | ((local >> 4) & 3u);
     return ux | (uy << 21) | (uz << 42);
 }
-/* hash choice is free: std::hash<Vec3i> (hash_map.h:44-52) only fixes phmap's iteration order */
+/* Hash choice is free: std::hash<Vec3i> (hash_map.h:44-52) only fixes phmap's iteration order.
+ * The 64-bit murmur finaliser of the packed block key; low half = home entry, high half = probe step.
+ * Cheaper forms were measured in round 3 (a wave64 instruction occupies its SIMD for 4 cycles, the finaliser's two 64 x 64
+ * multiplies are ~50 issue slots per lookup, a tracker pass does three lookups per lane):
+ *  - a lattice form of the block coordinates + one xor-shift (~10 slots): same probe counts in simulation (1.23 per key) --
+ *    and the tracker 4 us per pass SLOWER: the home entry decides where a block's 2 KB of voxel records live, neighbouring
+ *    blocks landed in neighbouring entries, and the records of a wall became one contiguous run of memory that all 256
+ *    workgroups hit at once (slowest workgroup's gather 5 -> 12 us: memory channels hot-spot).  Placement must be random;
+ *  - the lattice form + the 32-bit murmur finaliser (~20 slots, random placement again): gather median -0.1 us, launch span
+ *    unchanged within noise -- a pass waits for its slowest wave, not for instruction issue.  Not worth a change of the map's
+ *    layout function, so the finaliser stays. */
 __host__ __device__ __forceinline__ unsigned long long gsdf_hash64(unsigned long long k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
     k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;

@@ -54,12 +54,16 @@ def main():
             life = (rows[:, 5] - rows[:, 4]).astype(np.float64) / 100.0          # us
             start = (rows[:, 4] - rows[:, 4].min()).astype(np.float64) / 100.0
             itf, its = rows[:, 2].astype(np.float64) / (reps + 0), rows[:, 3].astype(np.float64) / (reps + 0)
+            itmax = rows[:, 6].astype(np.float64)
             order = np.argsort(-life)[:8]
             wg_stats = {"life_us_mean": round(float(life.mean()), 1), "life_us_p50": round(float(np.median(life)), 1), "life_us_max": round(float(life.max()), 1),
                         "last_start_us": round(float(start.max()), 1), "last_end_us": round(float((start + life).max()), 1),
                         "iters_fast_mean": round(float(itf.mean()), 2), "iters_slow_mean": round(float(its.mean()), 2), "iters_slow_max": float(its.max()),
+                        "slowest_wave_iters_mean": round(float(itmax.mean()), 1), "slowest_wave_iters_max": float(itmax.max()),
+                        "us_per_iteration_of_slowest_wave_p50": round(float(np.median(life / np.maximum(itmax, 1))), 3),
+                        "corr_life_iters": round(float(np.corrcoef(life, itmax)[0, 1]), 3),
                         "slowest": [{"wg": int(i), "life_us": round(float(life[i]), 1), "start_us": round(float(start[i]), 1), "fast": float(itf[i]), "slow": float(its[i]),
-                                     "samples": int(rows[i, 0] // reps)} for i in order]}
+                                     "samples": int(rows[i, 0] // reps), "slowest_wave_iters": float(itmax[i])} for i in order]}
         us = pr["ms"] * 1e3 / max(pr["launches"], 1)
         bufs[name] = g.download(p, (4, H, W), np.float32)
         hits = int((bufs[name][0] > 0).sum())
