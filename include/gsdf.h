@@ -86,7 +86,12 @@ int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float*
  * color is ignored by the reference and is not part of this ABI.  Synchronous; returns
  * GSDF_ERR_TABLE_FULL / GSDF_ERR_KEY_RANGE if the launch reported one. */
 int gsdf_update(gsdf_ctx* c, const float* depth_host, const float R[9], const float t[3]);
-/* same with depth already resident in HBM; enqueue only */
+/* same with depth already resident in HBM; enqueue only.
+ * Runs of this call are pipelined: the fusion of a frame is launched when the NEXT frame arrives (that launch's last workgroups
+ * compute the next frame's normals in its otherwise idle tail) or when any other entry point of this header is called on the
+ * context -- every one of them launches a waiting fusion first, so results never depend on it.  The caller's contract is the
+ * old one: depth_dev must stay valid and unchanged until the fusion has RUN, i.e. until a mark recorded after this call
+ * (gsdf_mark) has been reached, or gsdf_sync has returned. */
 int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const float t[3]);
 
 /* RigidOptimizer::optimize(depth, K) -- RigidOptimizer.h:106, RigidPointOptimizer.cpp:40-99.
