@@ -1,14 +1,21 @@
 /* CPU-only self test of the host-side pieces that need no GPU: PNG round trip, pose parsing,
- * SE3 helpers and the marching-cubes case tables (watertight sphere).  Run by tests/. */
+ * SE3 helpers, the marching-cubes case tables (watertight sphere), the PLY writer's text, and the abortable rendezvous of
+ * `Scan3D --gpus N`.  Run by tests/. */
+#include <unistd.h>
+
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <map>
+#include <sstream>
+#include <thread>
 #include <vector>
 
 #include "MarchingCubes.h"
 #include "img_loader.h"
 #include "png16.h"
+#include "shm_collective.h"
 
 static int fails = 0;
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
@@ -73,6 +80,47 @@ int main(int argc, char** argv) {
         CHECK(open == 0);
         CHECK(rmax < 0.81 && rmin > 0.79);
         CHECK(mc.savePly(dir + "/sphere.ply"));
+        /* the PLY text is what `ofstream << float` prints (LayeredMarchingCubesNoColor::savePly, :721-757) */
+        std::ostringstream want;
+        want << "ply\nformat ascii 1.0\nelement vertex " << mc.vertices().size() << "\nproperty float x\nproperty float y\nproperty float z\n"
+             << "element face " << (int)mc.faces().size() << "\nproperty list uchar int vertex_indices\nend_header\n";
+        for (const Vec3f& v : mc.vertices()) want << v[0] << " " << v[1] << " " << v[2] << "\n";
+        for (const auto& t : mc.faces()) want << "3 " << t[0] << " " << t[1] << " " << t[2] << "\n";
+        std::ifstream got(dir + "/sphere.ply", std::ios::binary);
+        std::stringstream gs;
+        gs << got.rdbuf();
+        CHECK(gs.str() == want.str());
+    }
+    {   /* the rendezvous of `Scan3D --gpus N`: a barrier that a failing rank can abort (here: two threads as the two ranks) */
+        const std::string name = "gsdf_selftest_" + std::to_string((long)getpid());
+        CHECK(ShmCollective::create(name, 2));
+        {
+            ShmCollective a(name, 2, 0), b(name, 2, 1);
+            CHECK(a.ok() && b.ok());
+            bool rb = false;
+            std::thread t([&] { rb = b.barrier(); });
+            CHECK(a.barrier());
+            t.join();
+            CHECK(rb);
+            /* all-gather through the segment */
+            const int va = 11, vb = 22;
+            int ra[2] = { 0, 0 }, rb2[2] = { 0, 0 };
+            gsdf_collective ca = a.ops(), cb = b.ops();
+            int rc_b = 1;
+            std::thread t2([&] { rc_b = cb.allgather(cb.user, &vb, rb2, sizeof(int)); });
+            CHECK(ca.allgather(ca.user, &va, ra, sizeof(int)) == 0);
+            t2.join();
+            CHECK(rc_b == 0 && ra[0] == 11 && ra[1] == 22 && rb2[0] == 11 && rb2[1] == 22);
+            /* rank 1 gives up: rank 0's barrier returns false instead of waiting for it */
+            bool r0 = true;
+            std::thread t3([&] { r0 = a.barrier(); });
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            b.abort();
+            t3.join();
+            CHECK(!r0 && a.aborted());
+            CHECK(!a.barrier());                                   /* and stays aborted */
+        }
+        ShmCollective::destroy(name);
     }
     std::printf(fails ? "host_selftest: %d FAILED\n" : "host_selftest: OK\n", fails);
     return fails ? 1 : 0;
