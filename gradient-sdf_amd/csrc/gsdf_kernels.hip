@@ -199,13 +199,15 @@ struct nrm_lds {
     float prod[3][NRM_TY + 2 * NRM_RMAX][NRM_TX + 2 * NRM_RMAX + 1];
     double rows[3][NRM_TY + 2 * NRM_RMAX][NRM_TX];
 };
+template <int NT = NRM_THREADS>          /* threads of the calling workgroup (>= NRM_TX * NRM_TY) */
 __device__ __forceinline__ void normals_tile(nrm_lds& S, int tile_x, int tile_y, int W, int H, int r, const gsdf_ncache& nc,
                                              const float* __restrict__ depth, float* __restrict__ nx, float* __restrict__ ny,
                                              float* __restrict__ nz) {
     const int tx0 = tile_x * NRM_TX, ty0 = tile_y * NRM_TY;
     const int PW = NRM_TX + 2 * r, PH = NRM_TY + 2 * r;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < PW * PH; idx += NRM_THREADS) {
+    static_assert(NT >= NRM_TX * NRM_TY, "one lane per pixel of the tile in the last stage");
+    for (int idx = tid; idx < PW * PH; idx += NT) {
         const int ly = idx / PW, lx = idx - ly * PW;
         const int gy = reflect101(ty0 + ly - r, H), gx = reflect101(tx0 + lx - r, W);
         const size_t i = (size_t)gy * W + gx;
@@ -216,7 +218,7 @@ __device__ __forceinline__ void normals_tile(nrm_lds& S, int tile_x, int tile_y,
         S.prod[2][ly][lx] = nc.ninv[i] * zi;
     }
     __syncthreads();
-    for (int idx = tid; idx < PH * NRM_TX; idx += NRM_THREADS) {
+    for (int idx = tid; idx < PH * NRM_TX; idx += NT) {
         const int ly = idx / NRM_TX, x = idx - ly * NRM_TX;
         double s0 = 0, s1 = 0, s2 = 0;
         for (int dx = 0; dx <= 2 * r; ++dx) {
@@ -229,7 +231,7 @@ __device__ __forceinline__ void normals_tile(nrm_lds& S, int tile_x, int tile_y,
     __syncthreads();
     const int x = tid & (NRM_TX - 1), y = tid / NRM_TX;
     const int px = tx0 + x, py = ty0 + y;
-    if (px >= W || py >= H) return;
+    if (y >= NRM_TY || px >= W || py >= H) return;
     double b1 = 0, b2 = 0, b3 = 0;
     for (int dy = 0; dy <= 2 * r; ++dy) {
         b1 += S.rows[0][y + dy][x];
@@ -294,11 +296,17 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
  *  - two workgroups (16 waves) per CU; a third one does not pay (the CU's issue and LDS throughput are the limit, not
  *    occupancy).  The kernel exists with two table sizes (FUSE_LCAP below), chosen per launch by the host.
  * ---------------------------------------------------------------------------------------------- */
-#define FUSE_T 16
-#ifndef FUSE_ZSPLIT
-#define FUSE_ZSPLIT 2                    /* slices of the ray walk: a tile is walked by 4 waves (8x8 pixels each) x FUSE_ZSPLIT */
+#define FUSE_T 16                        /* tile width */
+#ifndef FUSE_TH
+#define FUSE_TH 16                       /* tile height (a multiple of 4).  20: a 640x480 frame is 960 tiles = 1.88 dispatch rounds of the
+                                            512 workgroup slots instead of 2.34 (DESIGN.md "Dispatch rounds") */
 #endif
-#define FUSE_THREADS (256 * FUSE_ZSPLIT)
+#define FUSE_ZSPLIT 2                    /* slices of the ray walk a lane pair shares: the two halves of a wave */
+#define FUSE_NWAVES (FUSE_TH / 2)        /* a wave takes 32 pixels: 16 x TH / 32 */
+#define FUSE_THREADS (64 * FUSE_NWAVES)
+#define FUSE_RP (FUSE_TH / 4)            /* row phases of the spread mapping: wave w walks rows RP * (ly & 3) + (w >> 1) */
+#define FUSE_NPASS_MAX (FUSE_NWAVES / 2) /* most bands a tile is split into (4 rows each) */
+static_assert(FUSE_TH % 4 == 0 && FUSE_TH >= 8 && FUSE_TH <= 32, "tile height");
 /* LDS table entries.  The kernel exists in two sizes (template parameter LCAP, FUSE_LCAP below is that parameter):
  *   2048  512 buckets of 4, 57 KB with the accumulators: near scenes;
  *   2560  640 buckets, 72 KB (still two workgroups per CU): keeps far tiles (2.5-3 m at 640x480 / 1 cm), which the small
@@ -328,7 +336,7 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #define FUSE_BOUNDS __launch_bounds__(FUSE_THREADS, FUSE_OCC)
 #endif
 #ifndef FUSE_OCC
-#define FUSE_OCC (2 * FUSE_ZSPLIT)        /* waves per SIMD the register allocation must allow: 2 workgroups per CU */
+#define FUSE_OCC (FUSE_THREADS / 128)     /* waves per SIMD the register allocation must allow: 2 workgroups per CU */
 #endif
 /* LDS accumulators are fixed point (exact, order-independent integer adds) in THREE 64-bit words per entry, each in its
  * own array of 8-byte entries (a wave's scattered adds then use all banks; the walk is bound by LDS cycles).  Several
@@ -353,7 +361,7 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
 #ifndef FUSE_SPREAD
 #define FUSE_SPREAD 1                    /* spread lane -> (pixel, slice) mapping, see k_fuse */
 #endif
-#define FUSE_NSTAT (FUSE_SPREAD ? 8 : 4) /* waves of a workgroup that hold distinct pixels */
+#define FUSE_NSTAT (FUSE_SPREAD ? FUSE_NWAVES : 4) /* waves of a workgroup that hold distinct pixels */
 typedef uint32_t gsdf_u32x4 __attribute__((ext_vector_type(4)));
 typedef float gsdf_f2 __attribute__((ext_vector_type(2)));           /* packed f32 arithmetic (v_pk_*_f32): two results per issue slot */
 /* a * b + c with a, b < 2^24 (b uniform): full rate, where the 32-bit v_mul_lo_u32 is quarter rate */
@@ -403,7 +411,7 @@ template <int LCAP>
 struct fuse_lds {
     uint32_t key[FUSE_LCAP] __attribute__((aligned(16)));
     unsigned long long acc[3][FUSE_LCAP] __attribute__((aligned(16)));  /* see above: s | w + gz | gx + gy */
-    unsigned int cnt[2][4 * FUSE_ZSPLIT];   /* per wave: samples with w > 0, valid pixels */
+    unsigned int cnt[2][FUSE_NWAVES];       /* per wave: samples with w > 0, valid pixels */
     unsigned int n_defer, defer_base;
     unsigned int st_min[FUSE_NSTAT], st_max[FUSE_NSTAT];  /* per wave: smallest / largest valid depth (float bits) */
     float st_cnt[FUSE_NSTAT];                             /* per wave: valid pixels */
@@ -503,9 +511,8 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     const int tid = threadIdx.x;
     if (NEXT_NORMALS && (int)blockIdx.x >= a.n_tiles) {       /* the next frame's normals, in the tail of this launch */
         static_assert(sizeof(nrm_lds) <= sizeof(fuse_lds<LCAP>), "the normals tile works in the fusion table's LDS");
-        static_assert(FUSE_THREADS == NRM_THREADS, "normals tiles run in fusion-sized workgroups");
         const int t = (int)blockIdx.x - a.n_tiles;
-        normals_tile(*reinterpret_cast<nrm_lds*>(&L), t % a.nrm_ntx, t / a.nrm_ntx, a.g.W, a.g.H, a.nrm_r, a.nc, a.nrm_depth, a.nrm_x,
+        normals_tile<FUSE_THREADS>(*reinterpret_cast<nrm_lds*>(&L), t % a.nrm_ntx, t / a.nrm_ntx, a.g.W, a.g.H, a.nrm_r, a.nc, a.nrm_depth, a.nrm_x,
                      a.nrm_y, a.nrm_z);
         return;
     }
@@ -588,8 +595,9 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
      * atomics: a wave takes 32 pixels (every 2nd in x, every (4 / bands)-th in y: wave w has phase (w & 1, w >> 1)) and
      * BOTH slices of their ray walk (lanes 0-31 / 32-63), so neighbouring lanes are >= 2 pixels or half a ray apart. */
     static_assert(FUSE_ZSPLIT == 2, "the spread mapping splits a ray between the two halves of a wave");
-    const int px0 = tile_x * FUSE_T + 2 * lx + (wave & 1), py0 = tile_y * FUSE_T + 4 * (ly & 3) + (wave >> 1);
+    const int px0 = tile_x * FUSE_T + 2 * lx + (wave & 1), py0 = tile_y * FUSE_TH + FUSE_RP * (ly & 3) + (wave >> 1);
 #else
+    static_assert(FUSE_TH == 16, "the compact mapping exists for 16 x 16 tiles only");
     const int px0 = tile_x * FUSE_T + (wave & 1) * 8 + lx, py0 = tile_y * FUSE_T + ((wave >> 1) & 1) * 8 + ly;
 #endif
     float raw[7] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
@@ -616,7 +624,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         const float rfx = __frcp_rn(g.fx), rfy = __frcp_rn(g.fy);       /* a bounding box with margin: no parity item */
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float u = (float)(tile_x * FUSE_T + ((c & 1) ? FUSE_T : -1)), v = (float)(tile_y * FUSE_T + ((c & 2) ? FUSE_T : -1));
+            const float u = (float)(tile_x * FUSE_T + ((c & 1) ? FUSE_T : -1)), v = (float)(tile_y * FUSE_TH + ((c & 2) ? FUSE_TH : -1));
             const gsdf_v3 d = gsdf_matvec(R, gsdf_v3{ (u - g.cx) * rfx, (v - g.cy) * rfy, 1.f });
             dmin[0] = fminf(dmin[0], d.x); dmin[1] = fminf(dmin[1], d.y); dmin[2] = fminf(dmin[2], d.z);
             dmax[0] = fmaxf(dmax[0], d.x); dmax[1] = fmaxf(dmax[1], d.y); dmax[2] = fmaxf(dmax[2], d.z);
@@ -654,10 +662,10 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         const float D = 1.7421f * g.vs;
         const float s_min = __uint_as_float(zmin_bits) - (float)g.factor * g.vs - 2.f * D;
         const float x_lo = (float)(tile_x * FUSE_T) - g.cx, x_hi = x_lo + (float)(FUSE_T - 1);
-        const float y_lo = (float)(tile_y * FUSE_T) - g.cy, y_hi = y_lo + (float)(FUSE_T - 1);
+        const float y_lo = (float)(tile_y * FUSE_TH) - g.cy, y_hi = y_lo + (float)(FUSE_TH - 1);
         const float xm = fmaxf(fabsf(x_lo), fabsf(x_hi)) + 1.f, ym = fmaxf(fabsf(y_lo), fabsf(y_hi)) + 1.f;
-        const float gap = (float)FUSE_T + 0.5f;                       /* true gap is FUSE_T + 1 pixels */
-        bool ordered = s_min > 0.f && D * (g.fx + xm) <= gap * s_min && D * (g.fy + ym) <= gap * s_min;
+        const float gap = (float)FUSE_T + 0.5f, gap_y = (float)FUSE_TH + 0.5f;     /* true gaps: one pixel more */
+        bool ordered = s_min > 0.f && D * (g.fx + xm) <= gap * s_min && D * (g.fy + ym) <= gap_y * s_min;
         if (GSDF_EXPERIMENT(a.debug, 4)) ordered = false;
         if (tid == 0) {
             L.ordered = ordered ? 1u : 0u;                            /* read after the ray walk's barrier */
@@ -672,12 +680,12 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         const float zf = __uint_as_float(zmax_bits);
         const float rzf = __builtin_amdgcn_rcpf(zf);                    /* an estimate: hardware reciprocals will do */
         const float ppr = (g.fx * g.vs * rzf) * (g.fy * g.vs * rzf);    /* pixels per voxel face at the far end */
-        const float side = (float)FUSE_T * __builtin_amdgcn_rsqf(ppr);
+        const float side = (float)FUSE_T * __builtin_amdgcn_rsqf(ppr), side_y = (float)FUSE_TH * __builtin_amdgcn_rsqf(ppr);
         const float samples = n_valid * (float)nk_all;
-        const float est = fminf(samples, samples * __builtin_amdgcn_rcpf(ppr) + (side * side + 2.f * side * (float)nk_all) * __builtin_amdgcn_sqrtf(n_valid * (1.f / 256.f)));
-        n_pass = est <= 0.8f * FUSE_LCAP ? 1 : (est <= 1.6f * FUSE_LCAP ? 2 : 4);
+        const float est = fminf(samples, samples * __builtin_amdgcn_rcpf(ppr) + (side * side_y + (side + side_y) * (float)nk_all) * __builtin_amdgcn_sqrtf(n_valid * (1.f / (float)(FUSE_T * FUSE_TH))));
+        n_pass = est <= 0.8f * FUSE_LCAP ? 1 : (est <= 1.6f * FUSE_LCAP ? 2 : FUSE_NPASS_MAX);
         if (GSDF_EXPERIMENT(a.debug, 256)) n_pass = 1;
-        if (GSDF_EXPERIMENT(a.debug, 512)) n_pass = 4;
+        if (GSDF_EXPERIMENT(a.debug, 512)) n_pass = FUSE_NPASS_MAX;
         if (!(n_valid > 0.f)) n_pass = 1;
         big = FUSE_DUAL ? (est > 0.8f * FUSE_LCAP_SMALL * (float)n_pass ? 1 : 0) : 0;
         big = __builtin_amdgcn_readfirstlane(big);
@@ -715,9 +723,13 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
 #if FUSE_SPREAD
     /* a band of 256 / n_pass pixels = G groups of 32 (one per wave % G), walked in 2 * n_pass slices: the two halves
      * of a wave take slices 2 (wave / G) and 2 (wave / G) + 1 */
-    const int G = 8 / n_pass, grp = wave % G;
+    const int G = FUSE_NWAVES / n_pass, grp = wave % G;              /* n_pass is 1, 2 or FUSE_NPASS_MAX */
     const int zs = (lane >> 5) + 2 * (wave / G);
-    const int bx = 2 * lx + (grp & 1), by = (G / 2) * (ly & 3) + (grp >> 1);
+    int bx = 2 * lx + (grp & 1), by = (G / 2) * (ly & 3) + (grp >> 1);
+    if (G & 1) {                                                      /* an odd number of groups (TH = 20, two bands): row-major pixels */
+        const int q = grp * 32 + (lane & 31);
+        bx = q & (FUSE_T - 1); by = q / FUSE_T;
+    }
 #else
     const int per = FUSE_THREADS / (FUSE_ZSPLIT * n_pass);
     const int q = tid % per, zs = tid / per;
@@ -725,7 +737,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     const int by = n_pass == 4 ? (q >> 4) : (q >> 7) * 8 + ((q >> 3) & 7);
 #endif
     if (n_pass > 1)
-        load_pixel(tile_x * FUSE_T + bx, tile_y * FUSE_T + pass * (FUSE_T / n_pass) + by,
+        load_pixel(tile_x * FUSE_T + bx, tile_y * FUSE_TH + pass * (FUSE_TH / n_pass) + by,
                    L.plane[0], L.plane[1], L.plane[2], L.plane[3], L.plane[4], L.plane[5], L.plane[6]);
     n_val_w += (unsigned int)__popcll(__ballot(valid && zs == 0));    /* every pixel is held by one lane per slice */
     /* this slice's share of the ray walk k = -factor..factor (:101); the order is free (sums) */
@@ -1056,7 +1068,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     if (tid == 0) {
         unsigned long long nu = 0ull, nv = 0ull;
 #pragma unroll
-        for (int i = 0; i < 4 * FUSE_ZSPLIT; ++i) { nu += L.cnt[0][i]; nv += L.cnt[1][i]; }
+        for (int i = 0; i < FUSE_NWAVES; ++i) { nu += L.cnt[0][i]; nv += L.cnt[1][i]; }
         unsigned long long* c = a.blk_counters + 4 * ((size_t)tile_y * a.ntx + tile_x);
         c[0] = nu; c[1] = nv; c[2] += nu; c[3] += nv;
         if (tile_x == 0 && tile_y == 0) a.st->frames += 1;            /* :120 increase_counter() */
@@ -1146,7 +1158,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     a.g = g; a.nc = nc; a.depth = depth; a.nx = nx; a.ny = ny; a.nz = nz; a.pose = pose;
     a.use_dev_pose = use_dev_pose; a.tab = tab; a.st = st; a.blk_counters = blk_counters;
     a.deferred = deferred; a.deferred_count = deferred_count; a.deferred_cap = deferred_cap; a.tag = tag;
-    const int ntx = (g.W + FUSE_T - 1) / FUSE_T, nty = (g.H + FUSE_T - 1) / FUSE_T;
+    const int ntx = (g.W + FUSE_T - 1) / FUSE_T, nty = (g.H + FUSE_TH - 1) / FUSE_TH;
     gsdf_dev_state* gate = use_dev_pose ? st : nullptr;
     a.tile_flags = tile_flags; a.ntx = ntx; a.nty = nty; a.tile_order = tile_order;
     const int n = ntx * nty;
@@ -1162,13 +1174,13 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     if (resolve_follows)
         hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st, ticket + 1);
 }
-int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_T - 1) / FUSE_T); }
+int gsdf_fuse_grid_blocks(int W, int H) { return ((W + FUSE_T - 1) / FUSE_T) * ((H + FUSE_TH - 1) / FUSE_TH); }
 /* Launch order of the fusion tiles.  Colour-major (colour = parity of tile x, y): a tile only ever waits for tiles
  * of lower colour, which were dispatched before it.  Within that, workgroup b -- which the hardware places on XCD
  * b % 8 (observed; a performance assumption only) -- takes its tile from vertical image stripe b % 8, so the tiles
  * that share voxel records and block keys meet in one XCD's L2. */
 void gsdf_fuse_tile_order(int W, int H, uint32_t* order) {
-    const int ntx = (W + FUSE_T - 1) / FUSE_T, nty = (H + FUSE_T - 1) / FUSE_T;
+    const int ntx = (W + FUSE_T - 1) / FUSE_T, nty = (H + FUSE_TH - 1) / FUSE_TH;
     std::vector<uint32_t> lists[4][8];
     for (int ty = 0; ty < nty; ++ty)
         for (int tx = 0; tx < ntx; ++tx)
