@@ -185,6 +185,73 @@ def test_merge_allreduce_c_entry_world2_on_one_gpu(pkg, O, tmp_path):
     assert "one-shot" in str(a["again"]) and "one-shot" in str(b["again"])               # re-merging is refused on every rank
 
 
+def _gpu_worker8(rank, world, port, out_dir):
+    """One of EIGHT ranks (the node size of BASELINE configs[3]) on the one GPU of the test box: uneven frame shards (19 frames
+    over 8 ranks), vis_ enabled, the exchange over gloo callbacks."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.package()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H, n = 160, 120, 19
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=3, step_deg=4.0)
+    vs = np.float32(0.04)
+    g = pkg.GradSdf(vs, np.float32(5) * vs, W, H, seq.K, capacity_log2=18, device=0)
+    g.enable_vis(32)
+    lo, hi = pkg.parallel.shard_range(n, rank, world)
+    dev = [g.upload(seq.frame(i)[0]) for i in range(lo, hi)]
+    for j, i in enumerate(range(lo, hi)):
+        g.update_dev(dev[j], seq.frame(i)[1], seq.frame(i)[2])       # the pipelined entry: the last fusion waits until the exchange asks
+
+    def allgather(send):
+        t = torch.from_numpy(send)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return torch.cat(out).numpy()
+
+    def allreduce(buf):
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t)
+        return t.numpy()
+
+    g.merge_allreduce_with(allgather, allreduce, world)
+    keys, pay = g.export(sorted=True, raw=True)
+    kv, vis = g.export_vis()
+    np.savez(os.path.join(out_dir, "r8_%d.npz" % rank), keys=keys, pay=pay, vis=vis, frames=g.stats()["frames"], lo=lo, hi=hi)
+    g.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_merge_allreduce_eight_ranks_uneven_shards(pkg, O, tmp_path):
+    """Eight ranks with shards of 3 / 2 frames: every rank ends with the oracle's key set, its vis_ bit-vectors (frame f of
+    rank r = integrated frame lo(r) + f) and Sdf::counter_ = 19."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gpu_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    W, H, n = 160, 120, 19
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=3, step_deg=4.0)
+    vs = np.float32(0.04)
+    o = O.Oracle(vs, np.float32(5) * vs, W, H, seq.K)
+    for i in range(n):
+        o.update(*seq.frame(i))
+    keys, pay = o.export()
+    vo = o.export_vis(1)
+    shards = []
+    for r in range(8):
+        z = np.load(tmp_path / ("r8_%d.npz" % r))
+        shards.append((int(z["lo"]), int(z["hi"])))
+        assert np.array_equal(z["keys"], keys) and int(z["frames"]) == n
+        assert np.array_equal(z["vis"], vo)
+        w = z["pay"][:, 4]
+        assert (np.abs(w - pay[:, 4]) / np.maximum(1.0, pay[:, 4])).max() <= 1e-4
+        assert np.abs(z["pay"][:, 0] / w - pay[:, 0]).max() <= 1e-4
+    assert shards[0] == (0, 3) and shards[-1] == (17, 19) and all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+
+
 @pytest.mark.gpu
 def test_merge_allreduce_over_rccl_one_rank(pkg):
     """gsdf_merge_allreduce over a real RCCL communicator (gsdf_rccl_comm_init; one rank -- the box has one GPU): block ids,
