@@ -30,7 +30,7 @@ def main():
     N = W * H
     out = {}
     bufs = {}
-    for name, flag in (("lookahead", 0), ("v1", 16384)):
+    for name, flag in (("k_raycast", 0), ("k_raycast_v1", 16384)):
         g.debug_flags(flag)
         p = C.c_void_p()
         g._chk(g.L.gsdf_dev_alloc(g.h, C.byref(p), 4 * N * 4))
@@ -75,9 +75,9 @@ def main():
             b = 8.0 * samples / reps + 32.0 * records / reps + 16.0 * N
             out[name]["algorithmic_bytes"] = round(b)
             out[name]["GBps"] = round(b / (us * 1e-6) / 1e9, 1)
-    out["identical"] = bool(np.array_equal(bufs["lookahead"].view(np.uint32), bufs["v1"].view(np.uint32)))
+    out["identical"] = bool(np.array_equal(bufs["k_raycast"].view(np.uint32), bufs["k_raycast_v1"].view(np.uint32)))
     out["voxels"] = g.count()
-    out["depth_vs_input_p50_mm"] = float(np.median(np.abs(bufs["lookahead"][0] - fr[-1][0])[bufs["lookahead"][0] > 0]) * 1e3)
+    out["depth_vs_input_p50_mm"] = float(np.median(np.abs(bufs["k_raycast"][0] - fr[-1][0])[bufs["k_raycast"][0] > 0]) * 1e3)
     print(json.dumps(out))
     g.close()
 
