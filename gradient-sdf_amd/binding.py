@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GSDF_LIB", os.path.join(CSRC, "libgsdf.so"))   # GSDF_LIB: kernel-variant experiments (tools/)
 # the same sources with -DGSDF_EXPERIMENTS: path-forcing hooks for the tests, measurement switches for tools/
-TEST_LIB_PATH = os.path.join(CSRC, "libgsdf_test.so")
+TEST_LIB_PATH = os.environ.get("GSDF_TEST_LIB", os.path.join(CSRC, "libgsdf_test.so"))   # GSDF_TEST_LIB: variants of the test build (tools/)
 
 GSDF_OK, ERR_TABLE_FULL, ERR_KEY_RANGE, ERR_INVALID, ERR_HIP, ERR_NO_DEVICE = 0, 1, 2, 3, 4, 5
 
