@@ -1268,7 +1268,10 @@ __device__ __forceinline__ void trk_solve_update(const float* tot, float damping
  * z_first (nullable): depth of the first batch, already in registers. */
 __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_table& tab, const float* __restrict__ depth,
                                            const float* z_first, const float pose[7], int base0, int nthreads,
-                                           float (&acc)[GSDF_TRACK_NSUM]) {
+                                           float (&acc)[GSDF_TRACK_NSUM], unsigned long long* wave_stamp = nullptr) {
+    /* wave_stamp (test build, tools/track_waves.py): one word per wave = gather ticks | ticks until the block lookups are done |
+     * pixels that passed the z gate | pixels with a voxel, 16 bits each (first batch of pixels) */
+    const unsigned long long ws_t0 = wave_stamp ? wall_clock64() : 0ull;
     float R[9];
     gsdf_quat_to_R(pose + 3, R);                                          /* RigidPointOptimizer.cpp:53-54 */
     const float t[3] = { pose[0], pose[1], pose[2] };
@@ -1318,6 +1321,12 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
             for (int j = 0; j < TRK_PPT; ++j) want |= ok[j] ? 1u << j : 0u;
             gsdf_block_lookup_n<TRK_PPT, false>(tab, bkey, home, k0, want, blk);   /* the pixels' probe chains overlap */
         }
+        unsigned long long ws_lookup = 0ull, ws_ok = 0ull;
+        if (wave_stamp && base == base0) {
+            ws_lookup = wall_clock64() - ws_t0;
+#pragma unroll
+            for (int j = 0; j < TRK_PPT; ++j) ws_ok += (unsigned long long)__popcll(__ballot(ok[j]));
+        }
 #pragma unroll
         for (int j = 0; j < TRK_PPT; ++j) {
             P[j] = blk[j] >= 0 ? tab.vox + ((size_t)blk[j] * GSDF_BLOCK_VOX + gsdf_block_local(key[j])) : nullptr;
@@ -1350,11 +1359,19 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
                 for (int jj = i; jj < 6; ++jj) acc[q++] += J[i] * J[jj];  /* :80 */
             acc[28] += 1.f;                                               /* :81 */
         }
+        if (wave_stamp && base == base0) {
+            unsigned long long hits = 0ull;
+#pragma unroll
+            for (int j = 0; j < TRK_PPT; ++j) hits += (unsigned long long)__popcll(__ballot(pa[j].x > 0.f));
+            const unsigned long long tot = wall_clock64() - ws_t0;
+            if ((threadIdx.x & 63) == 0)
+                *wave_stamp = (tot & 0xFFFFull) | ((ws_lookup & 0xFFFFull) << 16) | ((ws_ok & 0xFFFFull) << 32) | ((hits & 0xFFFFull) << 48);
+        }
     }
 }
 
 static_assert(GSDF_TRACK_BLOCK == NRM_THREADS, "the normals tiles of the first pass run in tracker-sized workgroups");
-__global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
+__global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
                                                                  gsdf_table tab, gsdf_dev_state* st,
                                                                  double* rows, gsdf_track_params tp, gsdf_normals_job nj) {
     /* Workgroups beyond the tracker's own (first pass of a frame in the Scan3D loop only): one normals tile each
@@ -1487,7 +1504,8 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_pass(gsdf_frame_geom
     float acc[GSDF_TRACK_NSUM];
 #pragma unroll
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
-    trk_gather(g, tab, depth, z_pre, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, tp.n_track_blocks * GSDF_TRACK_BLOCK, acc);
+    trk_gather(g, tab, depth, z_pre, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, tp.n_track_blocks * GSDF_TRACK_BLOCK, acc,
+               trk_tr ? trk_tr + 8 + wave : nullptr);
     if (trk_tr && threadIdx.x == 0) trk_tr[2] = wall_clock64();                         /* wave 0: gather done */
     __syncthreads();                                                      /* wsum is reused */
     wave_sum_to_lane63(acc);

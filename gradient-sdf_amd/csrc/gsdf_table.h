@@ -180,6 +180,37 @@ __device__ __forceinline__ void gsdf_block_lookup_n(const gsdf_table& T, const u
     uint32_t step[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) { b[e] = -1; step[e] = 1u; }
+    if constexpr (!INSERT) {
+        /* Lookups only: TWO entries of the probe sequence per round.  A wave waits for the longest chain among its lanes' keys
+         * (64 x N of them: 4-6 entries at 40 % load, measured per wave with tools/track_waves.py: the lookups are 60 % of the
+         * tracker's gather) and every round is a dependent L2 round trip; the second entry's load costs nothing but a request.
+         * The order of the sequence is kept (first the entry, then its successor), so the result is the same. */
+        unsigned long long k2[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            step[e] = gsdf_probe_step(bk[e]);
+            k2[e] = ((pend >> e) & 1u) ? T.bkeys[(h[e] + step[e]) & T.block_mask] : GSDF_KEY_EMPTY;
+        }
+        for (int r = 0; r < GSDF_MAX_PROBE; r += 2) {
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                if (!((pend >> e) & 1u)) continue;
+                if (k[e] == bk[e]) { b[e] = (int)h[e]; pend &= ~(1u << e); }
+                else if (k[e] == GSDF_KEY_EMPTY) pend &= ~(1u << e);           /* entries are never freed: an empty one ends the chain */
+                else if (k2[e] == bk[e]) { b[e] = (int)((h[e] + step[e]) & T.block_mask); pend &= ~(1u << e); }
+                else if (k2[e] == GSDF_KEY_EMPTY) pend &= ~(1u << e);
+            }
+            if (!__any(pend != 0u)) break;
+#pragma unroll
+            for (int e = 0; e < N; ++e)
+                if ((pend >> e) & 1u) {
+                    h[e] = (h[e] + 2u * step[e]) & T.block_mask;
+                    k[e] = T.bkeys[h[e]];
+                    k2[e] = T.bkeys[(h[e] + step[e]) & T.block_mask];
+                }
+        }
+        return;
+    }
     for (int r = 0; r < GSDF_MAX_PROBE; ++r) {
 #pragma unroll
         for (int e = 0; e < N; ++e) {
