@@ -38,6 +38,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -70,6 +71,7 @@ def parse_args():
                          "gsdf_merge_allreduce_with over torch.distributed (RCCL refuses two ranks on one device)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (CPU test of --gpus N): the ranks rendezvous over gloo, barrier, max-reduce, rank 0 prints a stub line")
+    ap.add_argument("--sharded-timeout", type=float, default=240.0, help="seconds the sharded flavour may take before the line is printed without it")
     ap.add_argument("--rank-timeout", type=float, default=1500.0, help="seconds after which the self-started ranks are stopped")
     return ap.parse_args()
 
@@ -431,14 +433,6 @@ def main():
 
     g.close()
 
-    # ---- the flavour that shards: GT-pose fusion of frame shards + ONE all-reduce of the per-voxel sums (configs[3]) ------
-    sharded = None
-    if c4 is not None:
-        try:
-            sharded = sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, W, H, coll_dev)
-        except Exception as e:                                  # noqa: BLE001 -- the headline line must still be printed
-            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
-
     # HBM traffic of one k_fuse launch: PMC counters cannot be read from inside the process, so they come from the committed
     # rocprofv3 --pmc passes over this very command (profiles/pmc_latest.json names file and command); reported only for
     # the workload they were collected on, null otherwise
@@ -455,166 +449,87 @@ def main():
     except (OSError, ValueError):
         pass
 
-    if rank == 0:
-        total_frames = K * world
-        out = {
-            "metric": "depth frames/sec fused+tracked, 640x480 @1cm voxels",
-            "value": round(total_frames / elapsed, 2),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": Wm,
-            "ms_per_step": round(elapsed / K * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "S-tum: TUM fr1/xyz-format synthetic stream (BASELINE.json configs[1])",
-                "width": W, "height": H, "voxel_size_m": float(vs), "trunc_voxels": args.trunc,
-                "hash_capacity_log2": args.hash_capacity_log2, "tracker": "25 iters, conv 1e-3, damping 1",
-                "parallelism": "replicas x%d (tracked path does not shard)" % world,
-                "value_is": "median of %d timed windows" % len(runs),
-                "value_runs": [round(total_frames / r, 1) for r in runs],
-                "converged_frames": n_conv, "mean_tracker_passes": round(passes, 2),
-                "max_abs_translation_error_m": round(trans_err, 5), "voxels": voxels,
-                "n_upd_per_frame": round(n_upd_timed / max(n_conv, 1)), "n_hit_per_pass": round(n_hit_timed / max(passes * K, 1)),
-                "n_upd_oracle_checked": n_upd_checked,
-                "fused_only_fps": round(fused_fps * world, 1),
-                "raycast_us": raycast["avg_launch_us"] if raycast else None,
-                "sharded": sharded,
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": "k_fuse", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(fuse_ms * 1e3, 2),
-                "launches": prof["fusion"]["launches"],
-                "l2_atomics_per_launch": l2_atomics,       # the C2 table is cache resident, so report atomics too
-                "tracker": {"kernel": "k_track_pass", "achieved": round(trk_achieved, 1), "frac": round(trk_achieved / HBM_PEAK_GBS, 4),
-                            "algorithmic_bytes": round(trk_bytes), "passes": int(trk_passes),
-                            "launches": prof_t["track_pass"]["launches"],
-                            "avg_launch_us": round(trk_ms * 1e3 / max(prof_t["track_pass"]["launches"], 1), 2)},
-                "raycast": raycast,
-            },
-            "cpu_baseline": cpu,
-        }
-    # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which would otherwise be
-    # flushed behind it at exit
+    printed = threading.Lock()
+
+    def emit(sharded):
+        """Rank 0 prints THE line (once); everything it needs is known before the sharded flavour starts."""
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            total_frames = K * world
+            out = {
+                "metric": "depth frames/sec fused+tracked, 640x480 @1cm voxels",
+                "value": round(total_frames / elapsed, 2),
+                "unit": "frames/s",
+                "n_gpus": world,
+                "steps": K,
+                "warmup": Wm,
+                "ms_per_step": round(elapsed / K * 1e3, 4),
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "f32",
+                "data": "synthetic",
+                "config": {
+                    "workload": "S-tum: TUM fr1/xyz-format synthetic stream (BASELINE.json configs[1])",
+                    "width": W, "height": H, "voxel_size_m": float(vs), "trunc_voxels": args.trunc,
+                    "hash_capacity_log2": args.hash_capacity_log2, "tracker": "25 iters, conv 1e-3, damping 1",
+                    "parallelism": "replicas x%d (tracked path does not shard)" % world,
+                    "value_is": "median of %d timed windows" % len(runs),
+                    "value_runs": [round(total_frames / r, 1) for r in runs],
+                    "converged_frames": n_conv, "mean_tracker_passes": round(passes, 2),
+                    "max_abs_translation_error_m": round(trans_err, 5), "voxels": voxels,
+                    "n_upd_per_frame": round(n_upd_timed / max(n_conv, 1)), "n_hit_per_pass": round(n_hit_timed / max(passes * K, 1)),
+                    "n_upd_oracle_checked": n_upd_checked,
+                    "fused_only_fps": round(fused_fps * world, 1),
+                    "raycast_us": raycast["avg_launch_us"] if raycast else None,
+                    "sharded": sharded,
+                },
+                "roofline": {
+                    "bound": "hbm", "kernel": "k_fuse", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "algorithmic_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(fuse_ms * 1e3, 2),
+                    "launches": prof["fusion"]["launches"],
+                    "l2_atomics_per_launch": l2_atomics,       # SURVEY.md 8(d): the C2 table is cache resident, so report atomics too
+                    "tracker": {"kernel": "k_track_pass", "achieved": round(trk_achieved, 1), "frac": round(trk_achieved / HBM_PEAK_GBS, 4),
+                                "algorithmic_bytes": round(trk_bytes), "passes": int(trk_passes),
+                                "launches": prof_t["track_pass"]["launches"],
+                                "avg_launch_us": round(trk_ms * 1e3 / max(prof_t["track_pass"]["launches"], 1), 2)},
+                    "raycast": raycast,
+                },
+                "cpu_baseline": cpu,
+            }
+        # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which would otherwise be
+        # flushed behind it at exit
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                       # noqa: BLE001
+            pass
+        if rank == 0:
+            print(json.dumps(out))
+            sys.stdout.flush()
+
+    # ---- the flavour that shards: GT-pose fusion of frame shards + ONE all-reduce of the per-voxel sums (configs[3]) ------
+    # It is the only part of the run with a data-path collective on a communicator of its own.  The headline numbers are
+    # complete before it starts, so a watchdog bounds it: if the exchange does not come back (a fabric or RCCL problem on
+    # the node), every rank prints / leaves on its own after --sharded-timeout seconds instead of hanging the whole line.
+    sharded = None
+    if c4 is not None:
+        def give_up():
+            emit({"error": "sharded flavour did not finish within %.0f s" % args.sharded_timeout})
+            os._exit(0)
+        dog = threading.Timer(args.sharded_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            sharded = sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, W, H, coll_dev)
+        except Exception as e:                                  # noqa: BLE001 -- the headline line must still be printed
+            sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+        dog.cancel()
     if world > 1:
         dist.destroy_process_group()
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:                                           # noqa: BLE001
-        pass
-    if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
-
-
-def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, W, H, coll_dev):
-    """BASELINE configs[3] on N ranks: every rank fuses its contiguous shard of ONE sphere-orbit stream with the ground-truth
-    poses (main_scan_3d.cpp:250-254) into its own map, then ONE exchange -- gsdf_merge_allreduce over an RCCL communicator that
-    exists before the timed region -- after which every rank holds the map of all frames; rank 0 extracts the mesh.
-    Weak scaling: --c4-frames per rank.  Two rounds, the second one is reported (the first one warms RCCL's channels)."""
-    seq, frames, F, total = c4["seq"], c4["frames"], c4["F"], c4["total"]
-    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=23, device=local_rank)
-    dev = [g.upload(f[0]) for f in frames]
-
-    def barrier():
-        g.sync()
-        if world > 1:
-            dist.barrier()
-
-    def vmax(values):
-        if world == 1:
-            return [float(v) for v in values]
-        tt = torch.tensor(list(values), dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return [float(v) for v in tt.tolist()]
-
-    # ---- transport, outside the timed region ----
-    comm, transport, rccl_ranks = None, None, None
-    use_rccl = not args.single_device and (world == 1 or args.dist_backend == "nccl")
-    if use_rccl:
-        ok = 1.0
-        try:
-            idt = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                idt = torch.frombuffer(bytearray(pkg.binding.rccl_unique_id()), dtype=torch.uint8).clone()
-            if world > 1:
-                idt = idt.cuda()
-                dist.broadcast(idt, src=0)
-            comm = pkg.binding.rccl_comm_init(world, bytes(idt.cpu().numpy().tobytes()), rank, local_rank)
-            rccl_ranks = pkg.binding.rccl_comm_count(comm)
-        except Exception as e:                                   # noqa: BLE001
-            print("bench.py rank %d: RCCL communicator: %s" % (rank, e), file=sys.stderr)
-            ok = 0.0
-        # every rank takes the same route
-        ok = -vmax([-ok])[0] if world > 1 else ok
-        if ok > 0:
-            transport = "rccl (gsdf_merge_allreduce: pack -> ncclAllReduce -> unpack on the context's stream)"
-        else:
-            if comm is not None:
-                pkg.binding.rccl_comm_destroy(comm)
-                comm = None
-            use_rccl = False
-    if not use_rccl:
-        transport = "torch.distributed %s through gsdf_merge_allreduce_with (host staging)" % args.dist_backend
-
-    def ag(send):
-        if world == 1:
-            return send
-        t = torch.from_numpy(send).to(coll_dev)
-        out = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(out, t)
-        return torch.cat(out).cpu().numpy()
-
-    def ar(buf):
-        if world == 1:
-            return buf
-        t = torch.from_numpy(buf).to(coll_dev)
-        dist.all_reduce(t)
-        return t.cpu().numpy()
-
-    res = {}
-    for rnd in range(2):
-        g.reset()
-        barrier()
-        t0 = time.perf_counter()
-        for j, (d, f) in enumerate(zip(dev, frames)):
-            g.update_dev(d, f[1], f[2])
-            if j % 32 == 31:
-                g.sync()
-        g.sync()
-        t_fuse = time.perf_counter() - t0
-        own = g.count()
-        barrier()
-        t1 = time.perf_counter()
-        if use_rccl:
-            nb, nbytes = g.merge_allreduce_rccl(comm)
-        else:
-            nb, nbytes = g.merge_allreduce_with(ag, ar, world)
-        g.sync()
-        t_exch = time.perf_counter() - t1
-        t_fuse, t_exch, t_both = vmax([t_fuse, t_exch, t_fuse + t_exch])
-        res = {"frames_per_rank": F, "frames_total": total, "ranks": world, "rccl_ranks": rccl_ranks, "transport": transport,
-               "sharded_fused_fps": round(total / t_fuse, 1), "sharded_fused_fps_incl_exchange": round(total / t_both, 1),
-               "fuse_ms": round(t_fuse * 1e3, 3), "exchange_ms": round(t_exch * 1e3, 3), "exchange_bytes": int(nbytes),
-               "exchange_blocks": int(nb), "voxels_own_shard": int(own)}
-    res["voxels_merged"] = int(g.count())
-    res["frames_counter_after_merge"] = int(g.stats()["frames"])
-    if rank == 0:
-        t2 = time.perf_counter()
-        tris = g.extract_mesh()
-        res["mesh_faces"] = int(len(tris))
-        res["export_ms"] = round((time.perf_counter() - t2) * 1e3, 2)
-    barrier()
-    if comm is not None:
-        pkg.binding.rccl_comm_destroy(comm)
-    g.close()
-    return res
+    emit(sharded)
 
 
 if __name__ == "__main__":
