@@ -532,5 +532,109 @@ def main():
     emit(sharded)
 
 
+def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, W, H, coll_dev):
+    """BASELINE configs[3] on N ranks: every rank fuses its contiguous shard of ONE sphere-orbit stream with the ground-truth
+    poses (main_scan_3d.cpp:250-254) into its own map, then ONE exchange -- gsdf_merge_allreduce over an RCCL communicator that
+    exists before the timed region -- after which every rank holds the map of all frames; rank 0 extracts the mesh.
+    Weak scaling: --c4-frames per rank.  Two rounds, the second one is reported (the first one warms RCCL's channels)."""
+    seq, frames, F, total = c4["seq"], c4["frames"], c4["F"], c4["total"]
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=23, device=local_rank)
+    dev = [g.upload(f[0]) for f in frames]
+
+    def barrier():
+        g.sync()
+        if world > 1:
+            dist.barrier()
+
+    def vmax(values):
+        if world == 1:
+            return [float(v) for v in values]
+        tt = torch.tensor(list(values), dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return [float(v) for v in tt.tolist()]
+
+    # ---- transport, outside the timed region ----
+    comm, transport, rccl_ranks = None, None, None
+    use_rccl = not args.single_device and (world == 1 or args.dist_backend == "nccl")
+    if use_rccl:
+        ok = 1.0
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(pkg.binding.rccl_unique_id()), dtype=torch.uint8).clone()
+            if world > 1:
+                idt = idt.cuda()
+                dist.broadcast(idt, src=0)
+            comm = pkg.binding.rccl_comm_init(world, bytes(idt.cpu().numpy().tobytes()), rank, local_rank)
+            rccl_ranks = pkg.binding.rccl_comm_count(comm)
+        except Exception as e:                                   # noqa: BLE001
+            print("bench.py rank %d: RCCL communicator: %s" % (rank, e), file=sys.stderr)
+            ok = 0.0
+        # every rank takes the same route
+        ok = -vmax([-ok])[0] if world > 1 else ok
+        if ok > 0:
+            transport = "rccl (gsdf_merge_allreduce: pack -> ncclAllReduce -> unpack on the context's stream)"
+        else:
+            if comm is not None:
+                pkg.binding.rccl_comm_destroy(comm)
+                comm = None
+            use_rccl = False
+    if not use_rccl:
+        transport = "torch.distributed %s through gsdf_merge_allreduce_with (host staging)" % args.dist_backend
+
+    def ag(send):
+        if world == 1:
+            return send
+        t = torch.from_numpy(send).to(coll_dev)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return torch.cat(out).cpu().numpy()
+
+    def ar(buf):
+        if world == 1:
+            return buf
+        t = torch.from_numpy(buf).to(coll_dev)
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    res = {}
+    for rnd in range(2):
+        g.reset()
+        barrier()
+        t0 = time.perf_counter()
+        for j, (d, f) in enumerate(zip(dev, frames)):
+            g.update_dev(d, f[1], f[2])
+            if j % 32 == 31:
+                g.sync()
+        g.sync()
+        t_fuse = time.perf_counter() - t0
+        own = g.count()
+        barrier()
+        t1 = time.perf_counter()
+        if use_rccl:
+            nb, nbytes = g.merge_allreduce_rccl(comm)
+        else:
+            nb, nbytes = g.merge_allreduce_with(ag, ar, world)
+        g.sync()
+        t_exch = time.perf_counter() - t1
+        t_fuse, t_exch, t_both = vmax([t_fuse, t_exch, t_fuse + t_exch])
+        res = {"frames_per_rank": F, "frames_total": total, "ranks": world, "rccl_ranks": rccl_ranks, "transport": transport,
+               "sharded_fused_fps": round(total / t_fuse, 1), "sharded_fused_fps_incl_exchange": round(total / t_both, 1),
+               "fuse_ms": round(t_fuse * 1e3, 3), "exchange_ms": round(t_exch * 1e3, 3), "exchange_bytes": int(nbytes),
+               "exchange_blocks": int(nb), "voxels_own_shard": int(own)}
+    res["voxels_merged"] = int(g.count())
+    res["frames_counter_after_merge"] = int(g.stats()["frames"])
+    if rank == 0:
+        t2 = time.perf_counter()
+        tris = g.extract_mesh()
+        res["mesh_faces"] = int(len(tris))
+        res["export_ms"] = round((time.perf_counter() - t2) * 1e3, 2)
+    barrier()
+    if comm is not None:
+        pkg.binding.rccl_comm_destroy(comm)
+    g.close()
+    return res
+
+
 if __name__ == "__main__":
     main()

@@ -74,22 +74,29 @@ __device__ __forceinline__ void wave_uminmax(uint32_t& lo, uint32_t& hi) {
 }
 
 /* wave-64 sums of N values at once: every DPP stage is applied to all N values before the next stage, so
- * the N dependency chains interleave instead of stalling on each other; lane 63 ends up with the totals */
+ * the N dependency chains interleave instead of stalling on each other; lane 63 ends up with the totals.
+ * Each stage of each value is ONE instruction -- `v_add_f32_dpp v, v, v <ctrl>`: lanes without a source add 0
+ * (bound_ctrl), rows outside the row mask keep their value.  Written as inline assembly because the compiler turns
+ * the update_dpp builtin + add into three instructions per value and stage (clear, v_mov_dpp, packed add: 435
+ * instructions for the tracker's 29 sums against 174).  The adds and their order are the same, bit for bit.
+ * Hazard kept by construction: a VGPR written by a VALU instruction must not be read by a DPP instruction within the
+ * next two wait states -- stages follow each other at a distance of N >= 3 instructions (volatile asm keeps its
+ * order), and an s_nop separates the first stage from whatever produced the values. */
+#define GSDF_DPP_STAGE(CTRL)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < N; ++i)                                                \
+        asm volatile("v_add_f32_dpp %0, %0, %0 " CTRL : "+v"(v[i]))
 template <int N>
 __device__ __forceinline__ void wave_sum_to_lane63(float (&v)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x111, 0xf>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x112, 0xf>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x114, 0xf>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x118, 0xf>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x142, 0xa>(v[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = dpp_add<0x143, 0xc>(v[i]);
+    static_assert(N >= 3, "DPP read-after-write distance");
+    asm volatile("s_nop 1");
+    GSDF_DPP_STAGE("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    GSDF_DPP_STAGE("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    GSDF_DPP_STAGE("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    GSDF_DPP_STAGE("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");       /* lane 15 of each row holds the row sum */
+    GSDF_DPP_STAGE("row_bcast:15 row_mask:0xa bank_mask:0xf");                 /* into rows 1, 3 */
+    GSDF_DPP_STAGE("row_bcast:31 row_mask:0xc bank_mask:0xf");                 /* into rows 2, 3: lane 63 holds the wave sum */
 }
+#undef GSDF_DPP_STAGE
 
 __device__ __forceinline__ int reflect101(int i, int n) {      /* cv::BORDER_REFLECT_101 */
     if (n == 1) return 0;
@@ -1277,6 +1284,8 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
     const float t[3] = { pose[0], pose[1], pose[2] };
     const float fx_inv = 1.f / g.fx, fy_inv = 1.f / g.fy;                 /* :46-47 */
     const int N = g.W * g.H;
+    const uint32_t uW = (uint32_t)g.W;
+    const uint32_t step_y = (uint32_t)nthreads / uW, step_x = (uint32_t)nthreads - step_y * uW;
     for (int base = base0; base < N; base += TRK_PPT * nthreads) {
         /* stage A: depth */
         float z[TRK_PPT];
@@ -1292,11 +1301,15 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
         int vx[TRK_PPT], vy[TRK_PPT], vz[TRK_PPT];
         unsigned long long key[TRK_PPT], bkey[TRK_PPT], k0[TRK_PPT];
         uint32_t home[TRK_PPT];
+        /* (x, y) of the lane's pixels: one division for the first, the others follow by the (uniform) stride */
+        uint32_t px, py = (uint32_t)base / uW;
+        px = (uint32_t)base - py * uW;
 #pragma unroll
         for (int j = 0; j < TRK_PPT; ++j) {
-            const int pix = base + j * nthreads;
             ok[j] = ok[j] && !(z[j] <= g.zmin || z[j] >= g.zmax);         /* :64-65 */
-            const int y = pix / g.W, x = pix - y * g.W;
+            const int y = (int)py, x = (int)px;
+            px += step_x; py += step_y;
+            if (px >= uW) { px -= uW; ++py; }
             const float x0 = ((float)x - g.cx) * fx_inv;                  /* :67-68 */
             const float y0 = ((float)y - g.cy) * fy_inv;
             const gsdf_v3 pc = { x0 * z[j], y0 * z[j], z[j] };

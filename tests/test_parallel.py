@@ -301,6 +301,30 @@ def test_bench_gpus_n_starts_n_ranks_dry():
     assert out == {"dry_run": True, "n_gpus": 3, "max_over_ranks": 3.0, "local_rank": 0}
 
 
+def test_bench_names_resolve():
+    """bench.py is only executed end to end on the GPU box; here: every plain name it CALLS is defined somewhere in the file
+    (a function lost in an edit would otherwise only show up as an error string inside the JSON line)."""
+    import ast
+    import builtins
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    defined = set(dir(builtins))
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            defined.add(node.name)
+            if isinstance(node, ast.FunctionDef):
+                a = node.args
+                defined.update(x.arg for x in a.args + a.kwonlyargs + a.posonlyargs)
+        elif isinstance(node, ast.Name) and isinstance(node.ctx, ast.Store):
+            defined.add(node.id)
+        elif isinstance(node, (ast.Import, ast.ImportFrom)):
+            defined.update((al.asname or al.name).split(".")[0] for al in node.names)
+        elif isinstance(node, ast.ExceptHandler) and node.name:
+            defined.add(node.name)
+    called = {n.func.id for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Name)}
+    assert not (called - defined), sorted(called - defined)
+    assert {"main", "sharded_flavour", "spawn_ranks", "render_frames", "parse_args"} <= defined
+
+
 def test_bench_rejects_world_size_mismatch():
     import subprocess
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
