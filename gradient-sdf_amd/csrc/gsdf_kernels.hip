@@ -1235,6 +1235,77 @@ void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st) { hipLaunchKernel
 
 /* One Gauss-Newton step from the 29 sums (RigidPointOptimizer.cpp:86-98): solve, test, apply.  `passes` counts
  * this pass.  Identical arithmetic wherever it runs (every workgroup computes it redundantly). */
+/* The head's solve is executed by ONE wave whose 64 lanes would all do the same scalar work; it was 2.5 us of a 10 us
+ * pass (~1900 dependent instructions: 6 correctly rounded square roots, 27 divisions, four sinf / cosf).  These two
+ * helpers spread it over lanes WITHOUT changing a single operation or its order, so the result is bit-identical to
+ * gsdf_llt_solve6 / gsdf_se3_exp_mul in every lane:
+ *  - the Cholesky factorisation holds row i of L in lane i: column k of all rows (the dot product with row k, the
+ *    division by the pivot) is one instruction sequence instead of 5 - k, the entries of row k reach the other lanes
+ *    as wave-uniform values (v_readlane), which are also what the triangular solves then use;
+ *  - sinf / cosf of theta / 2 and of theta are evaluated once, lanes with bit 0 set taking theta. */
+__device__ __forceinline__ float trk_lane_value(float v, int lane_const) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
+}
+__device__ __forceinline__ void trk_llt_solve6_wave(const float* Hm, const float* g, float* x) {
+    const int lane = (int)(threadIdx.x & 63u);
+    float Lr[6];                                               /* row min(lane, 5) of the matrix being factorised */
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float v = Hm[6 * 5 + j];
+#pragma unroll
+        for (int r = 4; r >= 0; --r) v = lane == r ? Hm[6 * r + j] : v;
+        Lr[j] = v;
+    }
+    float Lu[36];                                              /* the factor, wave-uniform; lower triangle used */
+    bool positive = true;                                      /* every pivot so far was > 0 (or NaN) */
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float s = Lr[k];                                       /* lane k: the pivot; lanes i > k: L(i,k) before the division */
+#pragma unroll
+        for (int j = 0; j < k; ++j) s -= Lr[j] * Lu[6 * k + j];
+        float d = trk_lane_value(s, k);
+        positive = positive && !(d <= 0.f);
+        d = sqrtf(d);
+        Lu[6 * k + k] = d;
+        const float q = s / d;
+        Lr[k] = lane > k ? q : Lr[k];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) Lu[6 * i + k] = trk_lane_value(Lr[k], i);
+    }
+    if (!positive) {                   /* Eigen's llt_inplace stops at a non-positive pivot and the solves run on what is there: */
+        gsdf_llt_solve6(Hm, g, x);     /* rare (no overlap: all-zero H), and the straight-line code above assumed otherwise */
+        return;
+    }
+    float y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float s = g[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s -= Lu[6 * i + j] * y[j];
+        y[i] = s / Lu[6 * i + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        float s = y[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= Lu[6 * j + i] * x[j];
+        x[i] = s / Lu[6 * i + i];
+    }
+}
+__device__ __forceinline__ void trk_se3_exp_mul_wave(const float* xi, float* pose7) {
+    float trig[4] = { 0.f, 1.f, 0.f, 1.f };
+    const float theta_sq = gsdf_se3_theta_sq(xi);
+    if (!(theta_sq < GSDF_SOPHUS_EPS * GSDF_SOPHUS_EPS)) {
+        const float theta = sqrtf(theta_sq), half = 0.5f * theta;
+        const float arg = (threadIdx.x & 1u) ? theta : half;
+        const float sn = sinf(arg), cs = cosf(arg);
+        trig[0] = trk_lane_value(sn, 0); trig[1] = trk_lane_value(cs, 0);
+        trig[2] = trk_lane_value(sn, 1); trig[3] = trk_lane_value(cs, 1);
+    }
+    gsdf_se3_exp_mul_trig(xi, pose7, trig);
+}
+
+/* called by a full wave (all 64 lanes active, same arguments in every lane) */
 __device__ __forceinline__ void trk_solve_update(const float* tot, float damping, float conv_sq, int passes, int max_passes,
                                                  int no_solve, float pose[7], int* done, int* converged) {
     float gvec[6], Hm[36];
@@ -1247,7 +1318,7 @@ __device__ __forceinline__ void trk_solve_update(const float* tot, float damping
         for (int j = i; j < 6; ++j) { Hm[6 * i + j] = tot[q]; Hm[6 * j + i] = tot[q]; ++q; }
     float xi[6];
     if (no_solve) { for (int i = 0; i < 6; ++i) xi[i] = 1.f; }            /* experiment switch */
-    else gsdf_llt_solve6(Hm, gvec, xi);                                   /* RigidPointOptimizer.cpp:86 */
+    else trk_llt_solve6_wave(Hm, gvec, xi);                               /* RigidPointOptimizer.cpp:86 */
 #pragma unroll
     for (int i = 0; i < 6; ++i) xi[i] = damping * xi[i];
     const float nrm = gsdf_sum3(xi[0] * xi[0], xi[1] * xi[1], xi[2] * xi[2]) +
@@ -1264,7 +1335,7 @@ __device__ __forceinline__ void trk_solve_update(const float* tot, float damping
             float mxi[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
-            gsdf_se3_exp_mul(mxi, pose);
+            trk_se3_exp_mul_wave(mxi, pose);
         }
         if (passes >= max_passes) *done = 1;                              /* :98 return false */
     }
@@ -1471,6 +1542,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
 #pragma unroll
             for (int i = 0; i < 7; ++i) pose[i] = in.pose7[i];
             const int passes = in.passes + 1;
+            if (trk_tr && threadIdx.x == 0) { trk_tr[4] = wall_clock64() + (unsigned long long)(gs != gs) + (unsigned long long)(passes < 0); }   /* sums + state arrived */
             int done = 1, converged = 0;
             if (!in_done) {                                               /* else: this optimize() already ended */
                 const float totv = (float)gs;
@@ -1478,6 +1550,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
 #pragma unroll
                 for (int i = 0; i < GSDF_TRACK_NSUM; ++i) tot[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(totv), i));
                 trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, GSDF_EXPERIMENT(tp.debug, 1), pose, &done, &converged);
+                if (trk_tr && threadIdx.x == 0) trk_tr[5] = wall_clock64() + (unsigned long long)(pose[0] != pose[0]);               /* solved */
                 if (blockIdx.x == 0 && tid == 0) {
                     gsdf_trk_buf& o = st->trk[k & 1];
 #pragma unroll
@@ -1520,13 +1593,15 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
     trk_gather(g, tab, depth, z_pre, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, tp.n_track_blocks * GSDF_TRACK_BLOCK, acc,
                trk_tr ? trk_tr + 8 + wave : nullptr);
     if (trk_tr && threadIdx.x == 0) trk_tr[2] = wall_clock64();                         /* wave 0: gather done */
-    __syncthreads();                                                      /* wsum is reused */
+    /* every wave reduces its sums as soon as its own gather is done (wsum is used here only): ONE barrier per pass tail */
     wave_sum_to_lane63(acc);
     if (lane == 63) {
 #pragma unroll
         for (int i = 0; i < GSDF_TRACK_NSUM; ++i) wsum[wave][i] = acc[i];
     }
+    if (trk_tr && threadIdx.x == 0) trk_tr[6] = wall_clock64();                         /* wave 0: its sums are in LDS */
     __syncthreads();
+    if (trk_tr && threadIdx.x == 0) trk_tr[7] = wall_clock64();                         /* every wave's sums are in LDS */
     if (tid < 32) {
         float v = 0.f;
         if (tid < GSDF_TRACK_NSUM) {

@@ -104,13 +104,19 @@ GSDF_HD void gsdf_R_to_quat(const float* m, float* q /*x y z w*/) {
     }
 }
 
+/* the rotation angle of xi, squared -- Sophus SO3::expAndTheta */
+GSDF_HD float gsdf_se3_theta_sq(const float* xi) { return gsdf_sum3(xi[3] * xi[3], xi[4] * xi[4], xi[5] * xi[5]); }
+#define GSDF_SOPHUS_EPS 1e-5f                                   /* Sophus::Constants<float>::epsilon() */
+
 /* pose7 = SE3::exp(xi) * pose7 -- Sophus SO3::expAndTheta, SE3::exp and the SE3 group product
- * (RigidPointOptimizer.cpp:95 calls it with -xi).  pose7 = tx ty tz qx qy qz qw. */
-GSDF_HD void gsdf_se3_exp_mul(const float* xi, float* pose7) {
-    const float eps = 1e-5f;                                   /* Sophus::Constants<float>::epsilon() */
+ * (RigidPointOptimizer.cpp:95 calls it with -xi).  pose7 = tx ty tz qx qy qz qw.
+ * trig = { sinf(theta / 2), cosf(theta / 2), sinf(theta), cosf(theta) } with theta = sqrtf(theta_sq); read only when
+ * theta_sq >= eps^2.  (The tracker's head evaluates the four in two lanes at once, trk_solve_update.) */
+GSDF_HD void gsdf_se3_exp_mul_trig(const float* xi, float* pose7, const float* trig) {
+    const float eps = GSDF_SOPHUS_EPS;
     const gsdf_v3 ups = { xi[0], xi[1], xi[2] };
     const gsdf_v3 om = { xi[3], xi[4], xi[5] };
-    const float theta_sq = gsdf_sum3(om.x * om.x, om.y * om.y, om.z * om.z);
+    const float theta_sq = gsdf_se3_theta_sq(xi);
     float theta, imag, real;
     if (theta_sq < eps * eps) {
         theta = 0.f;
@@ -119,9 +125,8 @@ GSDF_HD void gsdf_se3_exp_mul(const float* xi, float* pose7) {
         real = 1.f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * theta_po4;
     } else {
         theta = sqrtf(theta_sq);
-        const float half = 0.5f * theta;
-        imag = sinf(half) / theta;
-        real = cosf(half);
+        imag = trig[0] / theta;
+        real = trig[1];
     }
     const float qe[4] = { imag * om.x, imag * om.y, imag * om.z, real };
     const float Om[9] = { 0.f, -om.z, om.y, om.z, 0.f, -om.x, -om.y, om.x, 0.f };
@@ -134,8 +139,8 @@ GSDF_HD void gsdf_se3_exp_mul(const float* xi, float* pose7) {
         gsdf_quat_to_R(qe, V);
     } else {
         const float tsq = theta * theta;
-        const float a = (1.f - cosf(theta)) / tsq;
-        const float b = (theta - sinf(theta)) / (tsq * theta);
+        const float a = (1.f - trig[3]) / tsq;
+        const float b = (theta - trig[2]) / (tsq * theta);
         for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + a * Om[i] + b * Om2[i];
     }
     const gsdf_v3 te = gsdf_matvec(V, ups);
@@ -157,6 +162,15 @@ GSDF_HD void gsdf_se3_exp_mul(const float* xi, float* pose7) {
     pose7[1] = te.y + (tt.y + aw * uv.y + c2.y);
     pose7[2] = te.z + (tt.z + aw * uv.z + c2.z);
     pose7[3] = qn[0]; pose7[4] = qn[1]; pose7[5] = qn[2]; pose7[6] = qn[3];
+}
+GSDF_HD void gsdf_se3_exp_mul(const float* xi, float* pose7) {
+    float trig[4] = { 0.f, 1.f, 0.f, 1.f };
+    const float theta_sq = gsdf_se3_theta_sq(xi);
+    if (!(theta_sq < GSDF_SOPHUS_EPS * GSDF_SOPHUS_EPS)) {
+        const float theta = sqrtf(theta_sq), half = 0.5f * theta;
+        trig[0] = sinf(half); trig[1] = cosf(half); trig[2] = sinf(theta); trig[3] = cosf(theta);
+    }
+    gsdf_se3_exp_mul_trig(xi, pose7, trig);
 }
 
 /* x = H^-1 g by Cholesky (Eigen H.llt().solve(g), RigidPointOptimizer.cpp:86).  H is the full

@@ -47,6 +47,16 @@ for p in range(12):
         line += "; gather %.2f median / %.2f max; reduce+atomics %.2f; last workgroup ends %.2f (launch span %.2f)" % (
             np.median(ga), ga.max(), np.median((rows[has_g, 3] - rows[has_g, 2]) / 100.0), en.max(), en.max() - st.min())
     print(line)
+    if (rows[:, 4] > 0).any():                 # head in parts: sums + state arrived | solved | pose handed to the other waves
+        m = rows[:, 4] > 0
+        line2 = "          head: sums and state arrive after %.2f, solve %.2f, hand-over %.2f" % (
+            np.median((rows[m, 4] - rows[m, 0]) / 100.0), np.median((rows[m, 5] - rows[m, 4]) / 100.0) if (rows[m, 5] > 0).all() else -1,
+            np.median((rows[m, 1] - np.maximum(rows[m, 5], rows[m, 4])) / 100.0))
+        if has_g.any():
+            line2 += " | tail: wave 0's sums %.2f, waits %.2f for the slowest wave, workgroup sum + atomics issued %.2f; ends %.2f after the first workgroup's end" % (
+                np.median((rows[has_g, 6] - rows[has_g, 2]) / 100.0), np.median((rows[has_g, 7] - rows[has_g, 6]) / 100.0),
+                np.median((rows[has_g, 3] - rows[has_g, 7]) / 100.0), (rows[has_g, 3].max() - rows[has_g, 3].min()) / 100.0)
+        print(line2)
 
 if os.environ.get("RAW"):
     for p in range(6):
