@@ -28,6 +28,7 @@
 #include "gsdf_math.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -1232,6 +1233,9 @@ void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st) { hipLaunchKernel
 #ifndef TRK_PPT
 #define TRK_PPT 3          /* pixels per lane handled as one batch: independent gathers in flight */
 #endif
+#ifndef TRK_CHUNK          /* pixels of one workgroup's batch in k_track_pass: half of its waves TRK_PPT per lane, the others one less */
+#define TRK_CHUNK ((GSDF_TRACK_BLOCK / 128) * 64 * (2 * TRK_PPT - 1))
+#endif
 
 /* One Gauss-Newton step from the 29 sums (RigidPointOptimizer.cpp:86-98): solve, test, apply.  `passes` counts
  * this pass.  Identical arithmetic wherever it runs (every workgroup computes it redundantly). */
@@ -1341,11 +1345,13 @@ __device__ __forceinline__ void trk_solve_update(const float* tot, float damping
     }
 }
 
-/* Gather + normal-equation sums of one pass for this lane's pixels (base, base + nthreads, ...): back-project,
- * voxel lookup (block key from the L2-resident key array, then the 32-byte record), residual, Jacobian.
+/* Gather + normal-equation sums of one pass for this lane's pixels: back-project, voxel lookup (block key from the
+ * L2-resident key array, then the 32-byte record), residual, Jacobian.  The lane's pixels of one batch are pix0 + j * pix_stride
+ * (j < PPT: independent gathers in flight), the next batch follows batch_stride pixels further.
  * z_first (nullable): depth of the first batch, already in registers. */
+template <int PPT>
 __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_table& tab, const float* __restrict__ depth,
-                                           const float* z_first, const float pose[7], int base0, int nthreads,
+                                           const float* z_first, const float pose[7], int pix0, int pix_stride, int batch_stride,
                                            float (&acc)[GSDF_TRACK_NSUM], unsigned long long* wave_stamp = nullptr) {
     /* wave_stamp (test build, tools/track_waves.py): one word per wave = gather ticks | ticks until the block lookups are done |
      * pixels that passed the z gate | pixels with a voxel, 16 bits each (first batch of pixels) */
@@ -1356,27 +1362,27 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
     const float fx_inv = 1.f / g.fx, fy_inv = 1.f / g.fy;                 /* :46-47 */
     const int N = g.W * g.H;
     const uint32_t uW = (uint32_t)g.W;
-    const uint32_t step_y = (uint32_t)nthreads / uW, step_x = (uint32_t)nthreads - step_y * uW;
-    for (int base = base0; base < N; base += TRK_PPT * nthreads) {
+    const uint32_t step_y = (uint32_t)pix_stride / uW, step_x = (uint32_t)pix_stride - step_y * uW;
+    for (int base = pix0; base < N; base += batch_stride) {
         /* stage A: depth */
-        float z[TRK_PPT];
-        bool ok[TRK_PPT];
+        float z[PPT];
+        bool ok[PPT];
 #pragma unroll
-        for (int j = 0; j < TRK_PPT; ++j) {
-            const int pix = base + j * nthreads;
+        for (int j = 0; j < PPT; ++j) {
+            const int pix = base + j * pix_stride;
             ok[j] = pix < N;
-            z[j] = (z_first && base == base0) ? z_first[j] : (ok[j] ? depth[pix] : 0.f);
+            z[j] = (z_first && base == pix0) ? z_first[j] : (ok[j] ? depth[pix] : 0.f);
         }
         /* stage B: back-project, voxel key, block key at the home entry (L2-resident key array) */
-        gsdf_v3 p[TRK_PPT];
-        int vx[TRK_PPT], vy[TRK_PPT], vz[TRK_PPT];
-        unsigned long long key[TRK_PPT], bkey[TRK_PPT], k0[TRK_PPT];
-        uint32_t home[TRK_PPT];
+        gsdf_v3 p[PPT];
+        int vx[PPT], vy[PPT], vz[PPT];
+        unsigned long long key[PPT], bkey[PPT], k0[PPT];
+        uint32_t home[PPT];
         /* (x, y) of the lane's pixels: one division for the first, the others follow by the (uniform) stride */
         uint32_t px, py = (uint32_t)base / uW;
         px = (uint32_t)base - py * uW;
 #pragma unroll
-        for (int j = 0; j < TRK_PPT; ++j) {
+        for (int j = 0; j < PPT; ++j) {
             ok[j] = ok[j] && !(z[j] <= g.zmin || z[j] >= g.zmax);         /* :64-65 */
             const int y = (int)py, x = (int)px;
             px += step_x; py += step_y;
@@ -1396,23 +1402,23 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
             k0[j] = ok[j] ? tab.bkeys[home[j]] : GSDF_KEY_EMPTY;
         }
         /* stage C: the voxel record (neighbouring pixels share lines: 4 x-adjacent voxels per line) */
-        const gsdf_payload* P[TRK_PPT];
-        float2 pa[TRK_PPT], pb[TRK_PPT], pc2[TRK_PPT];
-        int blk[TRK_PPT];
+        const gsdf_payload* P[PPT];
+        float2 pa[PPT], pb[PPT], pc2[PPT];
+        int blk[PPT];
         {
             uint32_t want = 0u;
 #pragma unroll
-            for (int j = 0; j < TRK_PPT; ++j) want |= ok[j] ? 1u << j : 0u;
-            gsdf_block_lookup_n<TRK_PPT, false>(tab, bkey, home, k0, want, blk);   /* the pixels' probe chains overlap */
+            for (int j = 0; j < PPT; ++j) want |= ok[j] ? 1u << j : 0u;
+            gsdf_block_lookup_n<PPT, false>(tab, bkey, home, k0, want, blk);   /* the pixels' probe chains overlap */
         }
         unsigned long long ws_lookup = 0ull, ws_ok = 0ull;
-        if (wave_stamp && base == base0) {
+        if (wave_stamp && base == pix0) {
             ws_lookup = wall_clock64() - ws_t0;
 #pragma unroll
-            for (int j = 0; j < TRK_PPT; ++j) ws_ok += (unsigned long long)__popcll(__ballot(ok[j]));
+            for (int j = 0; j < PPT; ++j) ws_ok += (unsigned long long)__popcll(__ballot(ok[j]));
         }
 #pragma unroll
-        for (int j = 0; j < TRK_PPT; ++j) {
+        for (int j = 0; j < PPT; ++j) {
             P[j] = blk[j] >= 0 ? tab.vox + ((size_t)blk[j] * GSDF_BLOCK_VOX + gsdf_block_local(key[j])) : nullptr;
             if (P[j]) {
                 const float2* q = reinterpret_cast<const float2*>(P[j]);
@@ -1423,7 +1429,7 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
         }
         /* stage D: residual, Jacobian, normal-equation sums */
 #pragma unroll
-        for (int j = 0; j < TRK_PPT; ++j) {
+        for (int j = 0; j < PPT; ++j) {
             const float w0 = pa[j].x;                                     /* weights(): MapGradPixelSdf.h:117-125 */
             if (!(w0 > 0.f)) continue;                                    /* :73 */
             /* tsdf(): MapGradPixelSdf.h:109-115 */
@@ -1443,10 +1449,10 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
                 for (int jj = i; jj < 6; ++jj) acc[q++] += J[i] * J[jj];  /* :80 */
             acc[28] += 1.f;                                               /* :81 */
         }
-        if (wave_stamp && base == base0) {
+        if (wave_stamp && base == pix0) {
             unsigned long long hits = 0ull;
 #pragma unroll
-            for (int j = 0; j < TRK_PPT; ++j) hits += (unsigned long long)__popcll(__ballot(pa[j].x > 0.f));
+            for (int j = 0; j < PPT; ++j) hits += (unsigned long long)__popcll(__ballot(pa[j].x > 0.f));
             const unsigned long long tot = wall_clock64() - ws_t0;
             if ((threadIdx.x & 63) == 0)
                 *wave_stamp = (tot & 0xFFFFull) | ((ws_lookup & 0xFFFFull) << 16) | ((ws_ok & 0xFFFFull) << 32) | ((hits & 0xFFFFull) << 48);
@@ -1492,13 +1498,20 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
      * j + 1, which nothing has touched since launch j - 2 read it.  Every launch does the clearing first, also
      * the ones that return early. */
     /* the depth of this lane's (first) pixels does not depend on the pose: requested now, it arrives under the head */
+    /* Pixels -> lanes.  A workgroup takes chunks of TRK_CHUNK = 1280 consecutive pixels (chunk b, b + workgroups, ...): waves
+     * 0-3 three rows of 64 per lane-set (3 pixels per lane), waves 4-7 two.  Wave w and wave w + 4 share a SIMD, and the gather
+     * is paced by the SIMD's instruction issue: 3 + 2 pixels on every SIMD of every CU, where 3 pixels per lane in all eight waves
+     * left a third of the workgroups with 6 per SIMD and the others with 4 (307 200 pixels are 2.34 per lane). */
+    const bool trk_heavy = wave < GSDF_TRACK_BLOCK / 128;
+    const int trk_pix0 = (int)blockIdx.x * TRK_CHUNK + (trk_heavy ? wave * (64 * TRK_PPT) : (GSDF_TRACK_BLOCK / 128) * 64 * TRK_PPT + (wave - GSDF_TRACK_BLOCK / 128) * (64 * (TRK_PPT - 1))) + lane;
+    const int trk_batch = tp.n_track_blocks * TRK_CHUNK;
     float z_pre[TRK_PPT];
     {
-        const int N = g.W * g.H, base0 = (int)blockIdx.x * GSDF_TRACK_BLOCK + tid, nthreads = tp.n_track_blocks * GSDF_TRACK_BLOCK;
+        const int N = g.W * g.H;
 #pragma unroll
         for (int j = 0; j < TRK_PPT; ++j) {
-            const int pix = base0 + j * nthreads;
-            z_pre[j] = pix < N ? depth[pix] : 0.f;
+            const int pix = trk_pix0 + j * 64;
+            z_pre[j] = (pix < N && (trk_heavy || j < TRK_PPT - 1)) ? depth[pix] : 0.f;
         }
     }
     double* acc_cur = rows + (size_t)(tp.rot % 3u) * GSDF_TRACK_ROWSET;
@@ -1590,8 +1603,8 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
     float acc[GSDF_TRACK_NSUM];
 #pragma unroll
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
-    trk_gather(g, tab, depth, z_pre, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, tp.n_track_blocks * GSDF_TRACK_BLOCK, acc,
-               trk_tr ? trk_tr + 8 + wave : nullptr);
+    if (trk_heavy) trk_gather<TRK_PPT>(g, tab, depth, z_pre, pose, trk_pix0, 64, trk_batch, acc, trk_tr ? trk_tr + 8 + wave : nullptr);
+    else trk_gather<TRK_PPT - 1>(g, tab, depth, z_pre, pose, trk_pix0, 64, trk_batch, acc, trk_tr ? trk_tr + 8 + wave : nullptr);
     if (trk_tr && threadIdx.x == 0) trk_tr[2] = wall_clock64();                         /* wave 0: gather done */
     /* every wave reduces its sums as soon as its own gather is done (wsum is used here only): ONE barrier per pass tail */
     wave_sum_to_lane63(acc);
@@ -1619,6 +1632,8 @@ void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float
                             gsdf_dev_state* st, double* partials, int n_blocks, const gsdf_track_params& tp_in,
                             const gsdf_normals_job* normals) {
     gsdf_track_params tp = tp_in;
+    /* one chunk of TRK_CHUNK pixels per workgroup while the grid allows it (640 x 480: 240 workgroups), more by looping */
+    n_blocks = std::max(1, std::min(n_blocks, (g.W * g.H + TRK_CHUNK - 1) / TRK_CHUNK));
     tp.n_track_blocks = n_blocks;
     gsdf_normals_job nj;
     memset(&nj, 0, sizeof(nj));
@@ -1710,7 +1725,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_all(gsdf_frame_geom 
         float acc[GSDF_TRACK_NSUM];
 #pragma unroll
         for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
-        trk_gather(g, tab, depth, z_pre, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, nb * GSDF_TRACK_BLOCK, acc);
+        trk_gather<TRK_PPT>(g, tab, depth, z_pre, pose, blockIdx.x * GSDF_TRACK_BLOCK + tid, nb * GSDF_TRACK_BLOCK, TRK_PPT * nb * GSDF_TRACK_BLOCK, acc);
         if (trk_tr && tid == 0 && k < 12) trk_tr[16 * 512 * k + 1] = wall_clock64();        /* wave 0: gather done */
         wave_sum_to_lane63(acc);
         if (lane == 63) {

@@ -32,8 +32,9 @@ log = g.frame_log()
 print("frame %d: converged %d after %d passes" % (last, int(log[-1][7]), int(log[-1][8])))
 t0 = None
 for p in range(12):
-    rows = t[2048 + p * 512:2048 + p * 512 + 256]
-    if rows[:, 0].max() == 0:
+    rows = t[2048 + p * 512:2048 + p * 512 + 512]
+    rows = rows[rows[:, 0] > 0]                 # the workgroups of the pass (640 x 480: 240)
+    if len(rows) == 0:
         continue
     if t0 is None:
         t0 = rows[:, 0].min()

@@ -29,24 +29,29 @@ buf = (ctypes.c_ulonglong * (NW * 16))()
 assert L.gsdf_debug_trace(g.h, buf, NW) == 0
 t = np.array(list(buf), dtype=np.uint64).reshape(NW, 16)
 for p in range(1, 4):
-    rows = t[2048 + p * 512:2048 + p * 512 + 256]
-    w = rows[:, 8:16].reshape(-1)                         # 2048 waves: workgroup-major
-    if w.max() == 0:
+    rows = t[2048 + p * 512:2048 + p * 512 + 512]
+    rows = rows[rows[:, 0] > 0]                           # the workgroups of the pass (640 x 480: 240)
+    NWG = len(rows)
+    if NWG == 0 or rows[:, 8:16].max() == 0:
         continue
+    w = rows[:, 8:16].reshape(-1)                         # waves: workgroup-major
     tot = (w & np.uint64(0xFFFF)).astype(np.float64) / 100.0
     look = ((w >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.float64) / 100.0
     ok = ((w >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.float64)
     hit = ((w >> np.uint64(48)) & np.uint64(0xFFFF)).astype(np.float64)
     slow = tot > np.percentile(tot, 95)
-    wg = np.arange(2048) // 8
+    wg = np.arange(NWG * 8) // 8
     print("pass %d: gather per wave %.2f med / %.2f p95 / %.2f max us | until the lookups are done %.2f med / %.2f p95 | "
           "corr(time, hits) %.2f, corr(time, lookup time) %.2f" % (p, np.median(tot), np.percentile(tot, 95), tot.max(), np.median(look),
           np.percentile(look, 95), np.corrcoef(tot, hit)[0, 1], np.corrcoef(tot, look)[0, 1]))
     print("        slowest 5 %% of the waves: hits %.0f (all waves %.0f of 192), valid %.0f (%.0f), lookup part %.2f us (%.2f), "
-          "workgroups they sit in: %d distinct of 256, image thirds of their first pixels: WG index quartiles %s" % (
-              hit[slow].mean(), hit.mean(), ok[slow].mean(), ok.mean(), look[slow].mean(), look.mean(), len(set(wg[slow])),
+          "workgroups they sit in: %d distinct of %d, image thirds of their first pixels: WG index quartiles %s" % (
+              hit[slow].mean(), hit.mean(), ok[slow].mean(), ok.mean(), look[slow].mean(), look.mean(), len(set(wg[slow])), NWG,
               np.percentile(wg[slow], [25, 50, 75]).round().tolist()))
-    per_wg_max = tot.reshape(256, 8).max(axis=1)
+    heavy = np.tile(np.arange(8) < 4, NWG)
+    print("        waves 0-3 (3 pixels per lane) %.2f med / %.2f p95 / %.2f max, waves 4-7 (2 pixels per lane) %.2f med / %.2f p95 / %.2f max" % (
+        np.median(tot[heavy]), np.percentile(tot[heavy], 95), tot[heavy].max(), np.median(tot[~heavy]), np.percentile(tot[~heavy], 95), tot[~heavy].max()))
+    per_wg_max = tot.reshape(NWG, 8).max(axis=1)
     print("        slowest wave per workgroup: %.2f med / %.2f max; workgroups whose slowest wave is > 1.3x their median wave: %d" % (
-        np.median(per_wg_max), per_wg_max.max(), int((per_wg_max > 1.3 * np.median(tot.reshape(256, 8), axis=1)).sum())))
+        np.median(per_wg_max), per_wg_max.max(), int((per_wg_max > 1.3 * np.median(tot.reshape(NWG, 8), axis=1)).sum())))
 g.close()
