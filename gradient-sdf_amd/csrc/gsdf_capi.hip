@@ -176,6 +176,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
         nj.nx = c->normals + 6 * N; nj.ny = c->normals + 7 * N; nj.nz = c->normals + 8 * N;          /* set 2 */
         nj.deferred_count = c->deferred_count;
         nj.r = c->win / 2; nj.ntx = 0;
+        nj.tile_first = 0; nj.tile_count = 0;
     }
     gsdf_track_params tp;
     tp.max_passes = iters;
@@ -214,9 +215,22 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
             tp.pass_index = k;
             tp.rot = c->track_rot;
             c->track_rot = (c->track_rot + 1u) % 3u;          /* kept in [0, 3): no discontinuity at wrap-around */
+            /* The frame's normals tiles ride in its first launches: nrm_split per cent in launch 0, nrm_split2 in launch 1, the rest
+             * in launch 2.  Launch 1 always exists (it is at least the head of pass 0), launch 2 when the first batch has three
+             * launches and optimize() may take two passes.  Next to the one tracker workgroup per CU a launch hides a share of the
+             * tiles; launch 0 has no head and ends early, so it takes the smallest one.  Tile 0 (it resets the frame's deferred list)
+             * stays in launch 0. */
+            const gsdf_normals_job* job = nullptr;
+            if (fuse_after && k <= 2) {
+                const int tiles = gsdf_normals_tiles(c->W, c->H);
+                const bool three = iters >= 2 && batch >= 3;
+                const int b1 = std::max(1, tiles * c->nrm_split / 100);
+                const int b2 = three ? std::min(tiles, std::max(b1, tiles * (c->nrm_split + c->nrm_split2) / 100)) : tiles;
+                const int lo = k == 0 ? 0 : k == 1 ? b1 : b2, hi = k == 0 ? b1 : k == 1 ? b2 : tiles;
+                if (hi > lo && (k < 2 || three)) { nj.tile_first = lo; nj.tile_count = hi - lo; job = &nj; }
+            }
             prof_scope ps(c, 2);
-            gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks, tp,
-                                   fuse_after && k == 0 ? &nj : nullptr);
+            gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks, tp, job);
         }
         if (fuse_after) {
             const int rc = enqueue_fuse(c, depth_dev, unused, 1, true);           /* main_scan_3d.cpp:261-265 */
@@ -362,6 +376,12 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         const char* env = getenv("GSDF_ADAPTIVE");
         if (env) c->adaptive = atoi(env);
         if ((env = getenv("GSDF_FIRST_BATCH")) && atoi(env) >= 2) c->first_batch = atoi(env);
+        if ((env = getenv("GSDF_NRM_SPLIT"))) {            /* experiments: "a" or "a,b" = per cent of the normals tiles in launch 0 (and 1) */
+            int a = -1, b = -1;
+            const int n = sscanf(env, "%d,%d", &a, &b);
+            if (n >= 1 && a >= 0 && a <= 100) { c->nrm_split = a; c->nrm_split2 = 100 - a; }
+            if (n >= 2 && b >= 0 && a + b <= 100) c->nrm_split2 = b;
+        }
         if ((env = getenv("GSDF_NEXT_BATCH")) && atoi(env) >= 1) c->next_batch = atoi(env);
         if ((env = getenv("GSDF_PERSIST"))) c->persist = atoi(env);
         if ((env = getenv("GSDF_FAR_TABLE"))) c->far_table = atoi(env);       /* experiments: 0 / 1 pin the fusion kernel's table size */

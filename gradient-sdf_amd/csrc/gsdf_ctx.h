@@ -39,6 +39,7 @@ struct gsdf_ctx {
     /* a GT-pose fusion whose launch waits for the next gsdf_update_dev (its launch then also computes that frame's normals) */
     struct pending_fuse { bool valid = false; const float* depth = nullptr; gsdf_pose_arg pose; int set = 0; } pending;
     int defer = 1;                                 /* pipeline runs of gsdf_update_dev that way (GSDF_DEFER=0: launch at once) */
+    int nrm_split = 30, nrm_split2 = 40;           /* per cent of a tracked frame's normals tiles computed in its first / second tracker launch (rest: third) */
     int nrm_parity = 0;                            /* which set of normal planes the next GT-pose fusion uses (0 / 1; set 2: tracked frames) */
     /* MapGradPixelSdf / Sdf members */
     float voxel_size = 0, voxel_size_inv = 0, T = 0, inv_T = 0;

@@ -122,7 +122,9 @@ struct gsdf_normals_job {
     float *nx, *ny, *nz;
     unsigned int* deferred_count; /* cleared for the k_fuse of this frame */
     int r, ntx;                   /* window radius; tiles per image row (set by the launcher) */
+    int tile_first, tile_count;   /* the tiles this launch computes: [tile_first, tile_first + tile_count); count 0 = all the rest */
 };
+int  gsdf_normals_tiles(int W, int H);       /* normals tiles of a frame (workgroups of k_normals / of the normals role) */
 void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st);
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
                             gsdf_dev_state* st, double* partials /* 3 * GSDF_TRACK_ROWSET, zeroed */, int n_blocks,

@@ -1470,7 +1470,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
      * dynamic LDS so that the later passes of the frame stay small. */
     if ((int)blockIdx.x >= tp.n_track_blocks) {
         extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-        const int t = (int)blockIdx.x - tp.n_track_blocks;
+        const int t = (int)blockIdx.x - tp.n_track_blocks + nj.tile_first;
         if (t == 0 && threadIdx.x == 0) {
             *nj.deferred_count = 0u;                            /* fresh list for the k_fuse of this frame */
             st->frame_cur = st->frames;                         /* counter_ seen by every workgroup of k_fuse */
@@ -1628,6 +1628,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
     }
     if (trk_tr && threadIdx.x == 0) trk_tr[3] = wall_clock64();
 }
+int gsdf_normals_tiles(int W, int H) { return ((W + NRM_TX - 1) / NRM_TX) * ((H + NRM_TY - 1) / NRM_TY); }
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
                             gsdf_dev_state* st, double* partials, int n_blocks, const gsdf_track_params& tp_in,
                             const gsdf_normals_job* normals) {
@@ -1642,8 +1643,9 @@ void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float
     if (normals) {
         nj = *normals;
         nj.ntx = (g.W + NRM_TX - 1) / NRM_TX;
-        extra = nj.ntx * ((g.H + NRM_TY - 1) / NRM_TY);
-        dyn = sizeof(nrm_lds);
+        const int rest = nj.ntx * ((g.H + NRM_TY - 1) / NRM_TY) - nj.tile_first;
+        extra = std::max(0, nj.tile_count > 0 ? std::min(nj.tile_count, rest) : rest);
+        dyn = extra ? sizeof(nrm_lds) : 0;
     }
     hipLaunchKernelGGL(k_track_pass, dim3(n_blocks + extra), dim3(GSDF_TRACK_BLOCK), dyn, s, g, depth, tab, st, partials, tp, nj);
 }
