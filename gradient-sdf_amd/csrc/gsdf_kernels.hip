@@ -1634,7 +1634,11 @@ void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float
                             const gsdf_normals_job* normals) {
     gsdf_track_params tp = tp_in;
     /* one chunk of TRK_CHUNK pixels per workgroup while the grid allows it (640 x 480: 240 workgroups), more by looping */
-    n_blocks = std::max(1, std::min(n_blocks, (g.W * g.H + TRK_CHUNK - 1) / TRK_CHUNK));
+    {                                   /* ... and then the same number of chunks for every workgroup (1280 x 960: 480 x 2, not 512 x 1.9) */
+        const int chunks = std::max(1, (g.W * g.H + TRK_CHUNK - 1) / TRK_CHUNK), cap = std::max(1, n_blocks);
+        const int per = (chunks + cap - 1) / cap;
+        n_blocks = (chunks + per - 1) / per;
+    }
     tp.n_track_blocks = n_blocks;
     gsdf_normals_job nj;
     memset(&nj, 0, sizeof(nj));
