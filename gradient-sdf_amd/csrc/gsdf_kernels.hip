@@ -89,7 +89,15 @@ __device__ __forceinline__ void wave_uminmax(uint32_t& lo, uint32_t& hi) {
 template <int N>
 __device__ __forceinline__ void wave_sum_to_lane63(float (&v)[N]) {
     static_assert(N >= 3, "DPP read-after-write distance");
-    asm volatile("s_nop 1");
+    /* the s_nop names every value as an operand: whatever instruction produced v[i] is scheduled BEFORE it */
+    if constexpr (N == 29) {
+        asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                     "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]),
+                     "+v"(v[19]), "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]), "+v"(v[24]), "+v"(v[25]), "+v"(v[26]), "+v"(v[27]), "+v"(v[28]));
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm volatile("s_nop 1" : "+v"(v[i]));
+    }
     GSDF_DPP_STAGE("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
     GSDF_DPP_STAGE("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
     GSDF_DPP_STAGE("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
