@@ -802,3 +802,56 @@ def test_pipelined_gt_pose_fusion_is_invisible_except_in_time(pkg, O):
     g.update_dev(dev[0], fr[0][1], fr[0][2])
     assert g.count() == counts[0]
     g.close()
+
+
+def _quat_to_R_f32(q):
+    """Eigen's toRotationMatrix in float32, operation by operation as the library's gsdf_quat_to_R (csrc/gsdf_math.h) does it"""
+    f = np.float32
+    x, y, z, w = (f(v) for v in q)
+    tx, ty, tz = f(2) * x, f(2) * y, f(2) * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    one = f(1)
+    return np.array([one - (tyy + tzz), txy - twz, txz + twy, txy + twz, one - (txx + tzz), tyz - twx,
+                     txz - twy, tyz + twx, one - (txx + tyy)], np.float32).reshape(3, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("iters", [1, 2, 3, 25])
+def test_frame_loop_call_equals_optimize_then_update(pkg, O, iters):
+    """gsdf_track_and_fuse_dev (one call per frame: the frame's normals tiles ride in its first tracker launches -- two of them
+    when optimize() is limited to one pass, three otherwise -- and the fusion is gated on the device) leaves the same pose and
+    the same map, bit for bit, as the two blocking calls optimize() + update() it stands for (main_scan_3d.cpp:258-263), at any
+    iteration limit; frames that do not converge within the limit are not fused by either."""
+    W, H = 320, 240
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=5, seed=0)
+    vs = np.float32(0.02)
+    T = np.float32(5) * vs
+    fr = [seq.frame(i) for i in range(5)]
+    res = []
+    for one_call in (True, False):
+        g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=20)
+        g.update(*fr[0])
+        pose = pose7_from(O, fr[0][1], fr[0][2])
+        g.set_pose(pose)
+        flags = []
+        for i in range(1, 5):
+            if one_call:
+                g.track_and_fuse_dev(g.upload(fr[i][0]), iters=iters)
+                g.sync()
+                row = g.frame_log()[-1]
+                flags.append((int(row[7]), int(row[8])))
+                pose = g.get_pose()
+            else:
+                conv, pose, passes = g.track(fr[i][0], pose, iters=iters)
+                flags.append((int(conv), int(passes)))
+                if conv:
+                    g.update(fr[i][0], _quat_to_R_f32(pose[3:]), pose[:3])
+        k, p = g.export(sorted=True)
+        res.append((flags, np.array(pose, np.float32), k, p))
+        g.close()
+    (f1, p1, k1, v1), (f2, p2, k2, v2) = res
+    assert f1 == f2, (f1, f2)
+    assert np.array_equal(p1, p2)
+    assert np.array_equal(k1, k2) and np.array_equal(v1, v2)
