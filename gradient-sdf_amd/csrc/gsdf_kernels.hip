@@ -431,6 +431,7 @@ struct fuse_lds {
     unsigned int n_defer, defer_base;
     unsigned int st_min[FUSE_NSTAT], st_max[FUSE_NSTAT];  /* per wave: smallest / largest valid depth (float bits) */
     float st_cnt[FUSE_NSTAT];                             /* per wave: valid pixels */
+    int dec[8];                         /* the tile-wide decisions, made by wave 0: n_pass, big, ox, oy, oz, range_ok */
     unsigned int ordered;               /* flush with plain read-modify-write (1) or through the deferred list (0) */
     unsigned int any_defer, is_last;    /* this workgroup appended to the deferred list / is the last one to finish */
     const float* plane[7];              /* depth, x0, y0, 1/n2, nx, ny, nz: read from here by the band reloads, so the
@@ -636,7 +637,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     }
     /* extreme components of the rays through the tile's corners (plus a pixel of margin): R (x0, y0, 1) */
     float dmin[3] = { 3.0e38f, 3.0e38f, 3.0e38f }, dmax[3] = { -3.0e38f, -3.0e38f, -3.0e38f };
-    {
+    if (wave == 0) {                                                    /* the tile-wide decisions below are wave 0's job */
         const float rfx = __frcp_rn(g.fx), rfy = __frcp_rn(g.fy);       /* a bounding box with margin: no parity item */
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -661,12 +662,13 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     const int nk_all = 2 * g.factor + 1;
     const int colour = (tile_x & 1) + 2 * (tile_y & 1);
     unsigned int* my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
-    /* every lane derives the tile-wide decisions from the four entries (same result everywhere) */
-    int n_pass;
+    /* Wave 0 derives the tile-wide decisions from the per-wave entries and hands them to the others through LDS: ~200 uniform
+     * instructions that all eight waves used to execute -- 7 % of the kernel's instruction issue, which is what bounds it. */
+    int n_pass = 1;
     int big = 0;                                                    /* the tile (each of its bands) uses the full LDS table */
-    int ox, oy, oz;
-    bool range_ok;
-    {
+    int ox = 0, oy = 0, oz = 0;
+    bool range_ok = false;
+    if (wave == 0) {
         unsigned int zmin_bits = L.st_min[0], zmax_bits = L.st_max[0];
         float n_valid = L.st_cnt[0];
 #pragma unroll
@@ -727,7 +729,12 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
          * global key is only needed on the deferred route */
         range_ok = ox >= -GSDF_KEY_OFF && ox + 1023 < GSDF_KEY_OFF && oy >= -GSDF_KEY_OFF && oy + 1023 < GSDF_KEY_OFF &&
                    oz >= -GSDF_KEY_OFF && oz + 1023 < GSDF_KEY_OFF;
+        if (lane == 0) { L.dec[0] = n_pass; L.dec[1] = big; L.dec[2] = ox; L.dec[3] = oy; L.dec[4] = oz; L.dec[5] = range_ok ? 1 : 0; }
     }
+    __syncthreads();
+    n_pass = __builtin_amdgcn_readfirstlane(L.dec[0]); big = __builtin_amdgcn_readfirstlane(L.dec[1]);
+    ox = __builtin_amdgcn_readfirstlane(L.dec[2]); oy = __builtin_amdgcn_readfirstlane(L.dec[3]); oz = __builtin_amdgcn_readfirstlane(L.dec[4]);
+    range_ok = __builtin_amdgcn_readfirstlane(L.dec[5]) != 0;
     unsigned int n_upd_w = 0u, n_val_w = 0u;                          /* wave-uniform counters */
     unsigned int dbg_go = 0u, dbg_full = 0u, dbg_lost = 0u;
     unsigned long long T1 = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
