@@ -147,6 +147,8 @@ def load(path=None):
         "gsdf_mark": (C.c_int, [vp, i64p]),
         "gsdf_mark_wait": (C.c_int, [vp, C.c_int64]),
         "gsdf_mark_reached": (C.c_int, [vp, C.c_int64, C.POINTER(C.c_int)]),
+        "gsdf_dev_upload_ahead": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
+        "gsdf_upload_wait": (C.c_int, [vp, C.c_int64]),
         "gsdf_timer_start": (C.c_int, [vp]),
         "gsdf_timer_stop_ms": (C.c_int, [vp, fp]),
         "gsdf_profile": (C.c_int, [vp, C.c_int]),
@@ -173,6 +175,7 @@ ABI_SYMBOLS = [
     "gsdf_query", "gsdf_get_voxels", "gsdf_raycast", "gsdf_raycast_dev", "gsdf_raycast_counters", "gsdf_extract_mesh",
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_dev_download", "gsdf_timer_start", "gsdf_timer_stop_ms",
     "gsdf_host_alloc", "gsdf_host_free", "gsdf_dev_upload_async", "gsdf_mark", "gsdf_mark_wait", "gsdf_mark_reached",
+    "gsdf_dev_upload_ahead", "gsdf_upload_wait",
     "gsdf_profile", "gsdf_profile_read", "gsdf_profile_read_n",
 ]
 

@@ -400,6 +400,8 @@ void gsdf_destroy(gsdf_ctx* c) {
     if (c->trace) { (void)hipFree(c->trace); c->trace = nullptr; }      /* after the sync: a running kernel may still write stamps */
     prof_collect(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto& u : c->uploads) { (void)hipEventSynchronize(u.second); (void)hipEventDestroy(u.second); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (hipEvent_t e : c->mark_pool) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.second);
     void* ptrs[] = { c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
@@ -1285,6 +1287,32 @@ int gsdf_mark_reached(gsdf_ctx* c, int64_t mark, int* reached) {
     if (!c || !reached) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     return marks_reached(c, mark, 0, reached);
+}
+
+int gsdf_dev_upload_ahead(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes, int64_t* upload) {
+    if (!c || !dev_dst || !host_src || bytes < 0 || !upload) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->copy_stream));
+    hipEvent_t e = nullptr;
+    if (!c->mark_pool.empty()) { e = c->mark_pool.back(); c->mark_pool.pop_back(); }
+    else HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e, c->copy_stream));
+    c->uploads.push_back({ ++c->upload_serial, e });
+    *upload = c->upload_serial;
+    return GSDF_OK;
+}
+int gsdf_upload_wait(gsdf_ctx* c, int64_t upload) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    while (!c->uploads.empty() && c->uploads.front().first <= upload) {
+        hipEvent_t e = c->uploads.front().second;
+        const hipError_t q = hipEventSynchronize(e);
+        if (q != hipSuccess) return fail(GSDF_ERR_HIP, std::string("gsdf upload: ") + hipGetErrorString(q));
+        c->mark_pool.push_back(e);
+        c->uploads.pop_front();
+    }
+    return GSDF_OK;
 }
 
 int gsdf_timer_start(gsdf_ctx* c) {

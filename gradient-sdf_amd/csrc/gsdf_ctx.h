@@ -111,6 +111,9 @@ struct gsdf_ctx {
     std::deque<std::pair<long long, hipEvent_t>> marks;
     std::vector<hipEvent_t> mark_pool;
     long long mark_serial = 0;
+    hipStream_t copy_stream = nullptr;             /* gsdf_dev_upload_ahead: created on first use */
+    std::deque<std::pair<long long, hipEvent_t>> uploads;
+    long long upload_serial = 0;
     double prof_ms[GSDF_PROF_SLOTS] = { 0 };
     long long prof_n[GSDF_PROF_SLOTS] = { 0 };
 

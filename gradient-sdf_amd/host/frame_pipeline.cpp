@@ -5,8 +5,9 @@
 FramePipeline::FramePipeline(gsdf_ctx* ctx, const ImageLoader* loader, std::vector<FrameEntry> entries, int W, int H, int threads,
                              int slots)
     : ctx_(ctx), loader_(loader), entries_(std::move(entries)), W_(W), H_(H) {
-    if (threads <= 0) threads = (int)std::min<unsigned>(16u, std::max(2u, std::thread::hardware_concurrency() / 2));
-    if (slots <= 0) slots = 2 * threads + 4;
+    /* a decoder thread delivers ~1000 frames/s (libdeflate inflate 0.3-0.7 ms + conversion); the tracked loop consumes 5-9 k */
+    if (threads <= 0) threads = (int)std::min<unsigned>(8u, std::max(2u, std::thread::hardware_concurrency() / 2));
+    if (slots <= 0) slots = std::min(2 * threads + 4, 20);      /* each slot is a page-locked + a device buffer: ~0.4 ms to create */
     slots = (int)std::min<size_t>((size_t)slots, std::max<size_t>(entries_.size(), 1));
     slots_.resize((size_t)slots);
     const int64_t bytes = (int64_t)W_ * H_ * (int64_t)sizeof(float);
@@ -28,7 +29,8 @@ FramePipeline::~FramePipeline() {
         std::lock_guard<std::mutex> lk(mu_);
         stop_ = true;
     }
-    cv_.notify_all();
+    cv_free_.notify_all();
+    cv_filled_.notify_all();
     for (std::thread& t : threads_) t.join();
     gsdf_sync(ctx_);                                   /* nothing on the stream reads the buffers any more */
     for (Slot& s : slots_) {
@@ -44,13 +46,14 @@ void FramePipeline::worker() {
         Slot* s;
         {
             std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return stop_ || next_decode_ >= entries_.size() || slots_[next_decode_ % slots_.size()].state == FREE; });
-            if (stop_ || next_decode_ >= entries_.size()) return;
+            cv_free_.wait(lk, [&] { return stop_ || next_decode_ >= entries_.size() || slots_[next_decode_ % slots_.size()].state == FREE; });
+            if (stop_ || next_decode_ >= entries_.size()) { cv_free_.notify_all(); return; }
             f = next_decode_++;
             s = &slots_[f % slots_.size()];
             s->state = DECODING;
             s->frame = f;
         }
+        cv_free_.notify_one();                         /* the frame after this one may have a free slot too: pass the baton */
         std::string err;
         const bool ok = loader_->decode_depth(entries_[f].depth_file, s->host, W_, H_, &err);
         {
@@ -58,13 +61,13 @@ void FramePipeline::worker() {
             s->state = ok ? FILLED : FAILED;
             if (!ok) s->error = err;                   /* reported when THIS frame is delivered, not before (the frames ahead of it are fine) */
         }
-        cv_.notify_all();
+        cv_filled_.notify_one();                       /* one consumer; the other decoders have nothing to learn from this */
     }
 }
 
 /* slots whose frame the stream has finished with go back to the decoders (called with mu_ NOT held) */
 void FramePipeline::reclaim(bool block_oldest) {
-    bool freed = false;
+    int freed = 0;
     for (;;) {
         Slot* oldest = nullptr;
         {
@@ -80,9 +83,35 @@ void FramePipeline::reclaim(bool block_oldest) {
             std::lock_guard<std::mutex> lk(mu_);
             oldest->state = FREE;
         }
-        freed = true;
+        ++freed;
     }
-    if (freed) cv_.notify_all();
+    for (int i = 0; i < freed; ++i) cv_free_.notify_one();      /* one decoder per slot that came back (they pass the baton on) */
+}
+
+/* The copies run AHEAD of the stream on the context's copy stream (gsdf_dev_upload_ahead): frames are copied in order as soon as
+ * they are decoded, up to UPLOAD_AHEAD beyond the one being delivered, so a frame's depth image is in HBM before the kernels
+ * of the frame before it have finished -- the stream itself never changes from kernels to a copy and back. */
+bool FramePipeline::start_uploads() {
+    constexpr size_t UPLOAD_AHEAD = 4;
+    for (;;) {
+        Slot* s = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (next_upload_ >= entries_.size() || next_upload_ > next_deliver_ + UPLOAD_AHEAD) return true;
+            Slot& c = slots_[next_upload_ % slots_.size()];
+            if (c.state != FILLED || c.frame != next_upload_) return true;       /* not decoded yet (or failed: reported at delivery) */
+            s = &c;
+        }
+        int64_t id = 0;
+        if (gsdf_dev_upload_ahead(ctx_, s->dev, s->host, (int64_t)W_ * H_ * (int64_t)sizeof(float), &id) != GSDF_OK) {
+            error_ = std::string("upload: ") + gsdf_last_error();
+            return false;
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        s->upload = id;
+        s->state = UPLOADING;
+        ++next_upload_;
+    }
 }
 
 const float* FramePipeline::next(size_t* index) {
@@ -91,14 +120,16 @@ const float* FramePipeline::next(size_t* index) {
     Slot& s = slots_[f % slots_.size()];
     for (;;) {
         reclaim(false);
+        if (!start_uploads()) return nullptr;
         std::unique_lock<std::mutex> lk(mu_);
-        if ((s.state == FILLED || s.state == FAILED) && s.frame == f) break;
+        if ((s.state == UPLOADING || s.state == FAILED) && s.frame == f) break;
+        if (s.state == FILLED && s.frame == f) continue;   /* decoded a moment ago: start its copy */
         if (s.state == INFLIGHT) {                     /* the ring is full of frames the GPU still owns: wait for the oldest */
             lk.unlock();
             reclaim(true);
             continue;
         }
-        cv_.wait_for(lk, std::chrono::milliseconds(2));
+        cv_filled_.wait_for(lk, std::chrono::milliseconds(2));
     }
     if (s.state == FAILED) {
         std::lock_guard<std::mutex> lk(mu_);
@@ -106,7 +137,7 @@ const float* FramePipeline::next(size_t* index) {
         next_deliver_ = entries_.size();
         return nullptr;
     }
-    if (gsdf_dev_upload_async(ctx_, s.dev, s.host, (int64_t)W_ * H_ * (int64_t)sizeof(float)) != GSDF_OK) {
+    if (gsdf_upload_wait(ctx_, s.upload) != GSDF_OK) {   /* normally long done: it was started frames ago */
         error_ = std::string("upload: ") + gsdf_last_error();
         return nullptr;
     }

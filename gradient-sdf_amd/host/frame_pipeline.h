@@ -45,8 +45,9 @@ public:
     const FrameEntry& entry(size_t i) const { return entries_[i]; }
 
 private:
-    enum State { FREE, DECODING, FILLED, FAILED, INFLIGHT };
-    struct Slot { float* host = nullptr; float* dev = nullptr; State state = FREE; size_t frame = 0; int64_t mark = 0; std::string error; };
+    enum State { FREE, DECODING, FILLED, FAILED, UPLOADING, INFLIGHT };
+    struct Slot { float* host = nullptr; float* dev = nullptr; State state = FREE; size_t frame = 0; int64_t mark = 0; int64_t upload = 0; std::string error; };
+    bool start_uploads();        /* host->HBM copies of the next few decoded frames, on the copy stream, in frame order */
     void worker();
     void reclaim(bool block_oldest);
 
@@ -57,9 +58,11 @@ private:
     std::vector<Slot> slots_;
     std::vector<std::thread> threads_;
     std::mutex mu_;
-    std::condition_variable cv_;
+    std::condition_variable cv_free_;     /* decoders wait here for the slot of the next frame to come back from the GPU */
+    std::condition_variable cv_filled_;   /* the consumer waits here for its frame's decode */
     size_t next_decode_ = 0;     /* next frame a decoder may claim */
     size_t next_deliver_ = 0;    /* next frame next() returns */
+    size_t next_upload_ = 0;     /* next frame whose copy has not been started */
     long last_slot_ = -1;
     bool stop_ = false;
     std::string error_;          /* written and read by the consumer thread only (decode errors wait in their slot) */

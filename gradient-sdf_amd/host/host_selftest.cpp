@@ -30,6 +30,20 @@ int main(int argc, char** argv) {
         PngImage im;
         CHECK(png_read(dir + "/t.png", im));
         CHECK(im.width == W && im.height == H && im.bit_depth == 16 && im.first_channel == px);
+        /* every scanline filter, mixed filters + two IDAT chunks, and the decoder threads' direct-to-float path */
+        for (int mode = 1; mode <= 5; ++mode) {
+            CHECK(png_write_gray16(dir + "/tf.png", W, H, px.data(), mode));
+            PngImage im2;
+            CHECK(png_read(dir + "/tf.png", im2));
+            CHECK(im2.width == W && im2.height == H && im2.first_channel == px);
+            std::vector<float> fl((size_t)W * H, -1.f);
+            CHECK(png_read_scaled(dir + "/tf.png", fl.data(), W, H, 0.0002f));
+            bool same = true;
+            for (int i = 0; i < W * H; ++i) same = same && fl[i] == (float)px[i] * 0.0002f;
+            CHECK(same);
+            std::string err;
+            CHECK(!png_read_scaled(dir + "/tf.png", fl.data(), W + 1, H, 0.0002f, &err) && err.find("differs") != std::string::npos);
+        }
     }
     {   /* pose file */
         std::ofstream f(dir + "/pose.txt");

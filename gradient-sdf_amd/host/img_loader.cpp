@@ -29,17 +29,12 @@ bool ImageLoader::load_depth(const std::string& filename, DepthImage& depth) {
 }
 
 bool ImageLoader::decode_depth(const std::string& filename, float* dst, int W, int H, std::string* err) const {
-    PngImage img;
     std::string e;
-    if (filename.empty() || !png_read(path_ + filename, img, &e)) {
-        if (err) *err = "empty depth image " + path_ + filename + " (" + e + ")";
+    if (filename.empty() || !png_read_scaled(path_ + filename, dst, W, H, unit_, &e)) {   /* convertTo(CV_32FC1, unit_) */
+        if (err) *err = e.find("differs") != std::string::npos ? "frame size of " + filename + " differs from --width/--height"
+                                                               : "empty depth image " + path_ + filename + " (" + e + ")";
         return false;
     }
-    if (img.width != W || img.height != H) {
-        if (err) *err = "frame size of " + filename + " differs from --width/--height";
-        return false;
-    }
-    for (size_t i = 0; i < img.first_channel.size(); ++i) dst[i] = (float)img.first_channel[i] * unit_;   /* convertTo(CV_32FC1, unit_) */
     return true;
 }
 

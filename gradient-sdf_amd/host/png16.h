@@ -14,7 +14,12 @@ struct PngImage {
 };
 
 bool png_read(const std::string& path, PngImage& out, std::string* err = nullptr);
+/* the decoder threads' path: first channel of a width x height image as float * unit (cv::Mat::convertTo(CV_32FC1, unit),
+ * ImageLoader.h:167-172) straight into dst, without the intermediate image */
+bool png_read_scaled(const std::string& path, float* dst, int width, int height, float unit, std::string* err = nullptr);
 /* 16-bit grayscale writer (stored-deflate friendly): used to build synthetic datasets in tests */
-bool png_write_gray16(const std::string& path, int width, int height, const uint16_t* pixels);
+/* filter_mode: scanline filter type of every row (0 = None ... 4 = Paeth), 5 = row y uses filter y % 5 and the data is
+ * split into two IDAT chunks (the reader's self-test) */
+bool png_write_gray16(const std::string& path, int width, int height, const uint16_t* pixels, int filter_mode = 0);
 
 #endif

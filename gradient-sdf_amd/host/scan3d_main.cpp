@@ -10,7 +10,7 @@
  *   (default)         the device-resident loop: PNG decode on host threads into page-locked buffers, asynchronous copy
  *                     to HBM, gsdf_track_and_fuse_dev / gsdf_update_dev enqueued per frame, poses read back once at
  *                     the end (frame_pipeline.h) -- same poses and map as --sync;
- *   --decode-threads  host threads of the PNG decode (default: half the cores, at most 16);
+ *   --decode-threads  host threads of the PNG decode (default: half the cores, at most 8);
  *   --gpus N          GT-pose fusion sharded over N ranks, one process per GPU (main_scan_3d.cpp:250-254 has no frame-to-
  *                     frame dependence): contiguous frame ranges, ONE exchange (gsdf_merge_allreduce: RCCL all-reduce of
  *                     the per-voxel sums over the union of blocks), then rank 0 writes the outputs.  Tracked mode does

@@ -255,6 +255,13 @@ int gsdf_dev_upload_async(gsdf_ctx* c, void* dev_dst, const void* host_src, int6
 int gsdf_mark(gsdf_ctx* c, int64_t* mark);
 int gsdf_mark_wait(gsdf_ctx* c, int64_t mark);
 int gsdf_mark_reached(gsdf_ctx* c, int64_t mark, int* reached);
+/* Staging AHEAD of the stream: the copy runs on the context's copy stream -- a DMA engine beside the kernels of the frames
+ * before it, where gsdf_dev_upload_async queues behind them and makes the stream change engines twice per frame --
+ * and gsdf_upload_wait blocks the HOST until that copy has arrived; after it returned, dev_dst may be handed to any _dev entry.
+ * The caller keeps dev_dst out of the stream's reach meanwhile (a buffer whose last reader passed a mark) and host_src
+ * untouched until the wait returned.  Uploads complete in the order they were started. */
+int gsdf_dev_upload_ahead(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes, int64_t* upload);
+int gsdf_upload_wait(gsdf_ctx* c, int64_t upload);
 /* HIP-event timing on the context's stream: t0/t1 bracket whatever is enqueued between them */
 int gsdf_timer_start(gsdf_ctx* c);
 int gsdf_timer_stop_ms(gsdf_ctx* c, float* ms);          /* synchronises */

@@ -21,6 +21,10 @@ def test_host_selftest(tmp_path):
     _build()
     out = subprocess.run([os.path.join(HOST, "host_selftest"), str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "host_selftest: OK" in out.stdout, out.stdout + out.stderr
+    # the PNG reader inflates with libdeflate where the image has it and with zlib otherwise: both paths, same checks
+    out = subprocess.run([os.path.join(HOST, "host_selftest"), str(tmp_path)], capture_output=True, text=True,
+                         env=dict(os.environ, GSDF_NO_LIBDEFLATE="1"))
+    assert out.returncode == 0 and "host_selftest: OK" in out.stdout, out.stdout + out.stderr
 
 
 def test_python_png_is_read_by_cpp_loader(pkg, tmp_path):
