@@ -235,11 +235,14 @@ def main():
             g.track_and_fuse_dev(dev[i])
 
     # ---- burn-in: whole windows, untimed ------------------------------------------------------------------------------
-    # The HIP runtime grows its launch resources once per process -- ONE launch call that takes ~40 ms -- wherever the process's
-    # launch count crosses its threshold; a change of a few bytes of kernel arguments moves that point from one window to
-    # another (seen: the second of five timed windows at 475 frames/s between four at 9 400).  At least two windows are run
-    # untimed, and further ones until a window takes no more than 1.5 x the fastest so far (at most eight): the timed windows
-    # below then all see the steady state.  `config.burn_in_windows` says how many it took.
+    # Python's cyclic garbage collector is switched off for the windows: a generation-2 collection -- ~40 ms with the frame
+    # lists of this process alive -- had landed in the second of five timed windows (475 frames/s between four at 9 400) after
+    # an unrelated edit moved the allocation count that triggers it.  At least two whole windows are run untimed first, and
+    # further ones until a window takes no more than 1.5 x the fastest so far (at most eight), so that whatever else happens
+    # once per process is over: `config.burn_in_windows` / `burn_in_runs` say what they saw.
+    import gc
+    gc.collect()
+    gc.disable()                  # no collector pauses inside the windows (re-enabled behind them)
     burn = []
     while len(burn) < 8:
         start_stream()
@@ -265,6 +268,7 @@ def main():
             g.track_and_fuse_dev(dev[i])
         sync_all()
         runs.append(max_over_ranks([time.perf_counter() - t_start])[0])
+    gc.enable()
     elapsed = float(np.median(runs))
 
     st = g.stats()
@@ -495,7 +499,7 @@ def main():
                     "parallelism": "replicas x%d (tracked path does not shard)" % world,
                     "value_is": "median of %d timed windows" % len(runs),
                     "value_runs": [round(total_frames / r, 1) for r in runs],
-                "burn_in_windows": len(burn),
+                "burn_in_windows": len(burn), "burn_in_runs": [round(total_frames / r, 1) for r in burn],
                     "converged_frames": n_conv, "mean_tracker_passes": round(passes, 2),
                     "max_abs_translation_error_m": round(trans_err, 5), "voxels": voxels,
                     "n_upd_per_frame": round(n_upd_timed / max(n_conv, 1)), "n_hit_per_pass": round(n_hit_timed / max(passes * K, 1)),
