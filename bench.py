@@ -242,7 +242,7 @@ def main():
     # once per process is over: `config.burn_in_windows` / `burn_in_runs` say what they saw.
     import gc
     gc.collect()
-    gc.disable()                  # no collector pauses inside the windows (re-enabled behind them)
+    gc.disable()                  # no collector pauses inside anything that is timed from here on
     burn = []
     while len(burn) < 8:
         start_stream()
@@ -268,8 +268,7 @@ def main():
             g.track_and_fuse_dev(dev[i])
         sync_all()
         runs.append(max_over_ranks([time.perf_counter() - t_start])[0])
-    gc.enable()
-    elapsed = float(np.median(runs))
+    elapsed = float(np.median(runs))          # (the collector stays off: the flavours measured below are timed too)
 
     st = g.stats()
     log = g.frame_log()
