@@ -855,3 +855,42 @@ def test_frame_loop_call_equals_optimize_then_update(pkg, O, iters):
     assert f1 == f2, (f1, f2)
     assert np.array_equal(p1, p2)
     assert np.array_equal(k1, k2) and np.array_equal(v1, v2)
+
+
+@pytest.mark.gpu
+def test_staging_ahead_of_the_stream(pkg, O):
+    """gsdf_dev_upload_ahead / gsdf_upload_wait (the CLI's frame staging): copies started on the library's copy stream while
+    earlier frames are still being fused arrive intact, in order, and the frames fused from them give the map of the blocking
+    path; waiting twice, or for an id of the past, returns at once."""
+    import ctypes as C
+    W, H = 320, 240
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=6, seed=1)
+    vs = np.float32(0.02)
+    T = np.float32(5) * vs
+    fr = [seq.frame(i) for i in range(6)]
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=20)
+    ref = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=20)
+    L = g.L
+    nbytes = W * H * 4
+    host, dev, ids = [], [], []
+    for i in range(6):
+        hp, dp = C.c_void_p(), C.c_void_p()
+        assert L.gsdf_host_alloc(g.h, C.byref(hp), nbytes) == 0 and L.gsdf_dev_alloc(g.h, C.byref(dp), nbytes) == 0
+        C.memmove(hp, np.ascontiguousarray(fr[i][0], np.float32).ctypes.data, nbytes)
+        host.append(hp); dev.append(dp)
+    for i in range(6):                                  # all copies in flight before the first fusion is even enqueued
+        uid = C.c_int64(0)
+        assert L.gsdf_dev_upload_ahead(g.h, dev[i], host[i], nbytes, C.byref(uid)) == 0
+        ids.append(uid.value)
+    assert ids == sorted(ids) and len(set(ids)) == 6
+    for i in range(6):
+        assert L.gsdf_upload_wait(g.h, ids[i]) == 0
+        g.update_dev(dev[i], fr[i][1], fr[i][2])
+        ref.update(*fr[i])
+    assert L.gsdf_upload_wait(g.h, ids[2]) == 0 and L.gsdf_upload_wait(g.h, ids[5]) == 0
+    kg, pg = g.export(sorted=True)
+    kr, pr = ref.export(sorted=True)
+    assert np.array_equal(kg, kr) and np.array_equal(pg, pr)
+    for hp, dp in zip(host, dev):
+        assert L.gsdf_dev_free(g.h, dp) == 0 and L.gsdf_host_free(g.h, hp) == 0
+    g.close(); ref.close()
