@@ -684,6 +684,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         const float xm = fmaxf(fabsf(x_lo), fabsf(x_hi)) + 1.f, ym = fmaxf(fabsf(y_lo), fabsf(y_hi)) + 1.f;
         const float gap = (float)FUSE_T + 0.5f, gap_y = (float)FUSE_TH + 0.5f;     /* true gaps: one pixel more */
         bool ordered = s_min > 0.f && D * (g.fx + xm) <= gap * s_min && D * (g.fy + ym) <= gap_y * s_min;
+        if (!(n_valid > 0.f)) ordered = false;                          /* nothing to write: the flag is published at once (below) */
         if (GSDF_EXPERIMENT(a.debug, 4)) ordered = false;
         if (tid == 0) {
             L.ordered = ordered ? 1u : 0u;                            /* read after the ray walk's barrier */
@@ -704,7 +705,9 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         n_pass = est <= 0.8f * FUSE_LCAP ? 1 : (est <= 1.6f * FUSE_LCAP ? 2 : FUSE_NPASS_MAX);
         if (GSDF_EXPERIMENT(a.debug, 256)) n_pass = 1;
         if (GSDF_EXPERIMENT(a.debug, 512)) n_pass = FUSE_NPASS_MAX;
-        if (!(n_valid > 0.f)) n_pass = 1;
+        /* a tile without a valid pixel (background: two thirds of the tiles of a sphere frame) walks and flushes nothing: no band
+         * at all -- it used to go through an empty walk and an empty flush, ~7 us of a workgroup slot */
+        if (!(n_valid > 0.f)) n_pass = 0;
         big = FUSE_DUAL ? (est > 0.8f * FUSE_LCAP_SMALL * (float)n_pass ? 1 : 0) : 0;
         big = __builtin_amdgcn_readfirstlane(big);
         /* tiles the small table cannot hold in one band: what the host chooses the next launches' table size by */
