@@ -1096,7 +1096,8 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
 #pragma unroll
         for (int i = 0; i < FUSE_NWAVES; ++i) { nu += L.cnt[0][i]; nv += L.cnt[1][i]; }
         unsigned long long* c = a.blk_counters + 4 * ((size_t)tile_y * a.ntx + tile_x);
-        c[0] = nu; c[1] = nv; c[2] += nu; c[3] += nv;
+        c[0] = nu; c[1] = nv;
+        if (nu | nv) { c[2] += nu; c[3] += nv; }                      /* (an empty tile does not wait for its totals to arrive) */
         if (tile_x == 0 && tile_y == 0) a.st->frames += 1;            /* :120 increase_counter() */
         /* Arrival.  The deferred contributions (near tiles, LDS overflow, timed-out waits: normally a handful) are added
          * by whichever workgroup finishes last, so the common case needs no second launch.  A workgroup that appended to
