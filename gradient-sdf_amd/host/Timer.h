@@ -12,8 +12,9 @@ public:
     double toc(const std::string& s = "Time elapsed") {
         if (!started_) { std::cout << "Timer was not started, no time could be measured." << std::endl; return 0.; }
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
-        if (el < 1.) std::cout << "---------- " << s << ": " << 1000. * el << "ms." << std::endl;
-        else std::cout << "---------- " << s << ": " << el << "s." << std::endl;
+        /* '\n', not std::endl: the frame loop prints three lines per frame, and a flush per line is a system call per line */
+        if (el < 1.) std::cout << "---------- " << s << ": " << 1000. * el << "ms.\n";
+        else std::cout << "---------- " << s << ": " << el << "s.\n";
         return el;
     }
 };

@@ -344,7 +344,7 @@ int run(int, char**, Options& opt) {
                                opt.height, opt.decode_threads);
             for (size_t j = lo; j < hi; ++j) {
                 const size_t i = opt.first + j;                       /* frame number as in the reference's loop */
-                if (lead) std::cout << "Working on frame: " << i << std::endl;
+                if (lead) std::cout << "Working on frame: " << i << "\n";
                 T.tic();
                 size_t got = 0;
                 const float* d = pipe.next(&got);
