@@ -32,6 +32,7 @@ FramePipeline::~FramePipeline() {
     cv_free_.notify_all();
     cv_filled_.notify_all();
     for (std::thread& t : threads_) t.join();
+    if (last_upload_ > 0) gsdf_upload_wait(ctx_, last_upload_);   /* copies started ahead and never delivered (early exit) */
     gsdf_sync(ctx_);                                   /* nothing on the stream reads the buffers any more */
     for (Slot& s : slots_) {
         if (s.host) gsdf_host_free(ctx_, s.host);
@@ -109,6 +110,7 @@ bool FramePipeline::start_uploads() {
         }
         std::lock_guard<std::mutex> lk(mu_);
         s->upload = id;
+        last_upload_ = id;
         s->state = UPLOADING;
         ++next_upload_;
     }

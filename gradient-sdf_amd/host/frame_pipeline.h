@@ -63,6 +63,7 @@ private:
     size_t next_decode_ = 0;     /* next frame a decoder may claim */
     size_t next_deliver_ = 0;    /* next frame next() returns */
     size_t next_upload_ = 0;     /* next frame whose copy has not been started */
+    int64_t last_upload_ = 0;    /* id of the copy started last */
     long last_slot_ = -1;
     bool stop_ = false;
     std::string error_;          /* written and read by the consumer thread only (decode errors wait in their slot) */
