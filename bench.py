@@ -64,6 +64,7 @@ def parse_args():
     ap.add_argument("--c4-frames", type=int, default=250,
                     help="frames PER RANK of the sharded GT-pose flavour (8 ranks x 250 = the 2000 frames of BASELINE configs[3]); 0 = skip")
     ap.add_argument("--raycast-reps", type=int, default=10, help="raycasts of the bench map timed for roofline.raycast (0 = skip)")
+    ap.add_argument("--no-staged", action="store_true", help="skip the staging-inclusive flavour (config.staged_fps)")
     ap.add_argument("--only-main", action="store_true", help="fused+tracked windows and the roofline replays only (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--single-device", action="store_true",
@@ -172,6 +173,7 @@ def main():
         args.c4_frames = 0
         args.raycast_reps = 0
         args.cpu_frames = 0
+        args.no_staged = True
 
     W, H = args.width, args.height
     K, Wm = args.steps, args.warmup
@@ -280,6 +282,59 @@ def main():
     n_upd_timed = st["n_upd"] - st_w["n_upd"]
     n_hit_timed = st["n_hit"] - st_w["n_hit"]
     voxels = g.count()
+
+    # ---- staging-inclusive flavour: the same K frames, but every timed frame starts in a page-locked HOST buffer ----
+    # main_scan_3d.cpp:213: the reference's loop loads the frame inside the loop.  Here: gsdf_dev_upload_ahead (the copy runs on
+    # the library's copy stream, up to `ahead` frames in front of the kernels) into a ring of device slots, gsdf_upload_wait,
+    # gsdf_track_and_fuse_dev, gsdf_mark (the slot is reused once the stream has passed its mark) -- what the Scan3D CLI's
+    # FramePipeline does, without the PNG decode.  Timed like `value`; reported as config.staged_fps, never as `value`.
+    staged_runs = []
+    if not args.no_staged:
+        import ctypes as C
+        Lb = g.L
+        nbytes = W * H * 4
+        first, last = 1 + Wm, Wm + K
+        host = []
+        for i in range(first, last + 1):
+            hp = C.c_void_p()
+            g._chk(Lb.gsdf_host_alloc(g.h, C.byref(hp), nbytes))
+            C.memmove(hp, np.ascontiguousarray(frames[i][0], np.float32).ctypes.data, nbytes)
+            host.append(hp)
+        S_SLOTS, AHEAD = 8, 4
+        slots = []
+        for _ in range(S_SLOTS):
+            dp = C.c_void_p()
+            g._chk(Lb.gsdf_dev_alloc(g.h, C.byref(dp), nbytes))
+            g._dev.append(dp)
+            slots.append(dp)
+        for rep in range(max(1, args.repeats)):
+            start_stream()
+            sync_all()
+            slot_mark = [None] * S_SLOTS
+            ids = {}
+            nxt = 0
+            t_start = time.perf_counter()
+            for j in range(K):
+                while nxt < K and nxt <= j + AHEAD:
+                    sl = nxt % S_SLOTS
+                    if slot_mark[sl] is not None:
+                        g._chk(Lb.gsdf_mark_wait(g.h, slot_mark[sl]))
+                    uid = C.c_int64(0)
+                    g._chk(Lb.gsdf_dev_upload_ahead(g.h, slots[sl], host[nxt], nbytes, C.byref(uid)))
+                    ids[nxt] = uid.value
+                    nxt += 1
+                g._chk(Lb.gsdf_upload_wait(g.h, ids.pop(j)))
+                g.track_and_fuse_dev(slots[j % S_SLOTS])
+                mk = C.c_int64(0)
+                g._chk(Lb.gsdf_mark(g.h, C.byref(mk)))
+                slot_mark[j % S_SLOTS] = mk.value
+            sync_all()
+            staged_runs.append(max_over_ranks([time.perf_counter() - t_start])[0])
+        staged_log = g.frame_log()[Wm:Wm + K]
+        # the staged window must have done the same work as the resident one
+        staged_same = bool(len(staged_log) == len(timed) and np.array_equal(staged_log[:, 7:9], timed[:, 7:9]))
+        for hp in host:
+            g._chk(Lb.gsdf_host_free(g.h, hp))
 
     # fused-only flavour (GT poses, update only) over the same K frames.  Measured BEFORE the event-timed replay:
     # recording timing events switches the HIP queue to a slower, profiled dispatch for the rest of the process.
@@ -461,14 +516,27 @@ def main():
     l2_atomics = None
     traffic_source = None
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            if (W, H) == (640, 480) and abs(float(vs) - 0.01) < 1e-6 and args.trunc == 10.0:
+        is_c3_ = (W, H) == (1280, 960) and abs(float(vs) - 0.005) < 1e-6 and args.trunc == 10.0 and args.hash_capacity_log2 == 25
+        with open(os.path.join(ROOT, "profiles", "pmc_latest_c3.json" if is_c3_ else "pmc_latest.json")) as f:
+            if is_c3_ or ((W, H) == (640, 480) and abs(float(vs) - 0.01) < 1e-6 and args.trunc == 10.0 and args.hash_capacity_log2 == 22):
                 pmc = json.load(f)
                 traffic = pmc.get("traffic_bytes_per_fusion")
                 l2_atomics = round(pmc.get("k_fuse", {}).get("TCC_ATOMIC", 0))
                 traffic_source = "%s (rocprofv3 --pmc, `%s`)" % (pmc.get("source"), pmc.get("command"))
     except (OSError, ValueError):
         pass
+
+    # what the line is quoted on follows the arguments: only the two single-GPU BASELINE configurations carry their names
+    cm = "%gcm" % (float(vs) * 100.0)
+    is_c2 = (W, H) == (640, 480) and abs(float(vs) - 0.01) < 1e-6 and args.trunc == 10.0 and args.hash_capacity_log2 == 22
+    is_c3 = (W, H) == (1280, 960) and abs(float(vs) - 0.005) < 1e-6 and args.trunc == 10.0 and args.hash_capacity_log2 == 25
+    if is_c2:
+        workload = "S-tum: TUM fr1/xyz-format synthetic stream, 640x480, 1 cm voxels, trunc 10, capacity 2^22 (BASELINE.json configs[1])"
+    elif is_c3:
+        workload = "S-stress: the S-tum stream at 1280x960, 5 mm voxels, trunc 10, capacity 2^25 (BASELINE.json configs[2])"
+    else:
+        workload = "S-tum stream at %dx%d, %s voxels, trunc %g, capacity 2^%d (not a BASELINE.json configuration)" % (
+            W, H, cm, args.trunc, args.hash_capacity_log2)
 
     printed = threading.Lock()
 
@@ -479,7 +547,7 @@ def main():
         if rank == 0:
             total_frames = K * world
             out = {
-                "metric": "depth frames/sec fused+tracked, 640x480 @1cm voxels",
+                "metric": "depth frames/sec fused+tracked, %dx%d @%s voxels" % (W, H, cm),
                 "value": round(total_frames / elapsed, 2),
                 "unit": "frames/s",
                 "n_gpus": world,
@@ -492,7 +560,7 @@ def main():
                 "dtype": "f32",
                 "data": "synthetic",
                 "config": {
-                    "workload": "S-tum: TUM fr1/xyz-format synthetic stream (BASELINE.json configs[1])",
+                    "workload": workload,
                     "width": W, "height": H, "voxel_size_m": float(vs), "trunc_voxels": args.trunc,
                     "hash_capacity_log2": args.hash_capacity_log2, "tracker": "25 iters, conv 1e-3, damping 1",
                     "parallelism": "replicas x%d (tracked path does not shard)" % world,
@@ -504,6 +572,10 @@ def main():
                     "n_upd_per_frame": round(n_upd_timed / max(n_conv, 1)), "n_hit_per_pass": round(n_hit_timed / max(passes * K, 1)),
                     "n_upd_oracle_checked": n_upd_checked,
                     "fused_only_fps": round(fused_fps * world, 1),
+                    # the same K frames handed over as page-locked HOST buffers (upload ahead of the stream + wait + track + fuse)
+                    "staged_fps": round(total_frames / float(np.median(staged_runs)), 1) if staged_runs else None,
+                    "staged_runs": [round(total_frames / r, 1) for r in staged_runs] if staged_runs else None,
+                    "staged_same_passes_as_resident": staged_same if staged_runs else None,
                     "raycast_us": raycast["avg_launch_us"] if raycast else None,
                     "sharded": sharded,
                 },

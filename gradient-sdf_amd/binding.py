@@ -73,6 +73,12 @@ def load_test_lib():
     L.gsdf_debug_read.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     L.gsdf_debug_trace.restype = C.c_int
     L.gsdf_debug_trace.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+    for name, args in (("gsdf_debug_tile_counters", [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
+                       ("gsdf_debug_set_tile_order", [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]),
+                       ("gsdf_debug_get_tile_order", [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)])):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = args
     return L
 
 
@@ -118,6 +124,7 @@ def load(path=None):
         "gsdf_ba_solve_dist": (C.c_int, [vp, C.c_float]),
         "gsdf_ba_optimize": (C.c_int, [vp, C.c_int, fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "gsdf_ba_get_poses": (C.c_int, [vp, fp]),
+        "gsdf_ba_counters": (C.c_int, [vp, i64p, i64p]),
         "gsdf_merge_raw": (C.c_int, [vp, i32p, fp, C.c_int64]),
         "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
@@ -167,7 +174,7 @@ ABI_SYMBOLS = [
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
     "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
-    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses",
+    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
     "gsdf_merge_allreduce", "gsdf_merge_allreduce_with", "gsdf_rccl_unique_id", "gsdf_rccl_comm_init", "gsdf_rccl_comm_count",
@@ -397,6 +404,12 @@ class GradSdf:
         ne, conv = C.c_int(0), C.c_int(0)
         self._chk(self.L.gsdf_ba_optimize(self.h, int(max_it), _fp(e), C.byref(ne), C.byref(conv)))
         return bool(conv.value), e[:ne.value]
+
+    def ba_counters(self):
+        """(voxels that took part, voxel x keyframe observations) of the last energy sweep read back"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.gsdf_ba_counters(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def ba_poses(self):
         P = np.zeros((self._ba_n, 16), np.float32)

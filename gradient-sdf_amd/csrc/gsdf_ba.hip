@@ -150,9 +150,12 @@ __device__ __forceinline__ void ba_wave_sum_to_lane63(float (&v)[N]) {
 }
 
 /* ---- getEnergy ---- */
+/* block_E: [3][gridDim.x] -- the workgroup's energy, its voxels that took part (|dist| <= vs, seen by >= 1 keyframe) and their
+ * observations (voxel x keyframe pairs that project into the image): the counts are the units of the sweep's algorithmic bytes */
 __global__ __launch_bounds__(256) void k_ba_energy(ba_args a, double* block_E) {
-    __shared__ double red[4];
+    __shared__ double red[3][4];
     double E = 0.0;
+    unsigned int n_act = 0u, n_obs = 0u;
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x; slot < a.n_slots; slot += stride) {
         ba_voxel v;
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(256) void k_ba_energy(ba_args a, double* block_E) {
             ++Nj;
         }
         if (!Nj) continue;
+        n_act += 1u; n_obs += (unsigned int)Nj;
         const float inv = (float)(1. / (double)(float)Nj);
         mean = gsdf_v3{ inv * mean.x, inv * mean.y, inv * mean.z };
         for (int i = 0; i < a.n; ++i) {                                        /* second sweep: same samples */
@@ -182,10 +186,11 @@ __global__ __launch_bounds__(256) void k_ba_energy(ba_args a, double* block_E) {
             E += (double)gsdf_dot3(r, r);                                      /* :316 */
         }
     }
-    for (int off = 32; off > 0; off >>= 1) E += __shfl_down(E, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = E;
+    double cA = (double)n_act, cO = (double)n_obs;                             /* small integers: exact in any order */
+    for (int off = 32; off > 0; off >>= 1) { E += __shfl_down(E, off); cA += __shfl_down(cA, off); cO += __shfl_down(cO, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = E; red[1][threadIdx.x >> 6] = cA; red[2][threadIdx.x >> 6] = cO; }
     __syncthreads();
-    if (threadIdx.x == 0) block_E[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x < 3) block_E[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
 /* ---- solveDist ---- */

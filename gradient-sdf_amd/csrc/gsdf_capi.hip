@@ -35,8 +35,10 @@ hipEvent_t take_event(gsdf_ctx* c) {
         c->event_pool.pop_back();
         return e;
     }
+    /* timing events only: no system-scope fence when they are recorded (the cache write-back and invalidation it implies would
+     * be charged to the kernels they bracket, and slow the ones behind them) */
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
     return e;
 }
 
@@ -270,6 +272,17 @@ int gsdf_flush_pending(gsdf_ctx* c) {
     return launch_fuse(c, c->pending.depth, c->normals + (size_t)c->pending.set * 3 * N, c->pending.pose, 0, nullptr, nullptr);
 }
 #define GSDF_FLUSH(c) do { if ((c) && (c)->pending.valid) { const int rc_ = gsdf_flush_pending(c); if (rc_) return rc_; } } while (0)
+/* The staging entries (gsdf_dev_upload*) write device memory the caller names.  A GT-pose fusion that still waits for its
+ * successor reads its depth image when it is LAUNCHED, so a copy into that image has to come behind the launch: the pattern
+ * upload(buf) -> update_dev(buf) -> upload(buf) -> update_dev(buf) on ONE staging buffer is correct by stream order only if
+ * the waiting fusion is launched before the second copy is queued.  Copies elsewhere leave the pipelining alone. */
+static int flush_if_overlaps(gsdf_ctx* c, const void* dst, int64_t bytes) {
+    if (!c || !c->pending.valid) return GSDF_OK;
+    const uintptr_t a0 = (uintptr_t)dst, a1 = a0 + (uintptr_t)std::max<int64_t>(bytes, 0);
+    const uintptr_t b0 = (uintptr_t)c->pending.depth, b1 = b0 + (size_t)c->W * c->H * sizeof(float);
+    if (a0 < b1 && b0 < a1) return gsdf_flush_pending(c);
+    return GSDF_OK;
+}
 
 extern "C" {
 
@@ -308,6 +321,28 @@ int gsdf_debug_raycast_rows(gsdf_ctx* c, unsigned long long* out, int n_rows) {
     if (!c || !out || !c->rc_counts || (size_t)n_rows > c->rc_rows) return GSDF_ERR_INVALID;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
     if (hipMemcpy(out, c->rc_counts, (size_t)n_rows * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
+    return GSDF_OK;
+}
+/* experiments with the launch order of the fusion tiles (tools/fuse_order.py): the per-tile counter rows (last n_upd, last
+ * n_valid, totals) and a caller-made order (same encoding as gsdf_fuse_tile_order; n = workgroups) */
+int gsdf_debug_tile_counters(gsdf_ctx* c, unsigned long long* out, int n_rows) {
+    GSDF_FLUSH(c);
+    if (!c || !out || !c->blk_counters || n_rows > c->fuse_blocks) return GSDF_ERR_INVALID;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
+    if (hipMemcpy(out, c->blk_counters, (size_t)n_rows * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
+    return GSDF_OK;
+}
+int gsdf_debug_set_tile_order(gsdf_ctx* c, const uint32_t* order, int n) {
+    GSDF_FLUSH(c);
+    if (!c || !order || !c->tile_order || n != c->fuse_blocks) return GSDF_ERR_INVALID;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
+    if (hipMemcpy(c->tile_order, order, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return GSDF_ERR_HIP;
+    return GSDF_OK;
+}
+int gsdf_debug_get_tile_order(gsdf_ctx* c, uint32_t* order, int* n) {
+    if (!c || !order || !n || !c->tile_order) return GSDF_ERR_INVALID;
+    if (hipMemcpy(order, c->tile_order, (size_t)c->fuse_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return GSDF_ERR_HIP;
+    *n = c->fuse_blocks;
     return GSDF_OK;
 }
 int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[24]) {
@@ -403,11 +438,13 @@ void gsdf_destroy(gsdf_ctx* c) {
     for (auto& u : c->uploads) { (void)hipEventSynchronize(u.second); (void)hipEventDestroy(u.second); }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (hipEvent_t e : c->mark_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->upload_pool) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.second);
     void* ptrs[] = { c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& b : c->mx) if (b.p) (void)hipFree(b.p);
     if (c->progress) (void)hipHostFree((void*)c->progress);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -882,7 +919,9 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
     HIP_TRY(hipMalloc((void**)&c->ba_images, img_bytes));
     HIP_TRY(hipMalloc((void**)&c->ba_Rt, (size_t)n * 12 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->ba_frame_idx, (size_t)n * sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&c->ba_block_E, (size_t)gsdf_ba_blocks() * sizeof(double)));
+    /* two sets of 3 x blocks doubles (energy, voxels, observations per workgroup): gsdf_ba_optimize keeps the sweep behind the
+     * pose step and the one behind the distance step apart and reads both with one synchronisation */
+    HIP_TRY(hipMalloc((void**)&c->ba_block_E, (size_t)2 * 3 * gsdf_ba_blocks() * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->ba_block_part, (size_t)gsdf_ba_blocks() * n * 27 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->ba_Hb, (size_t)n * 27 * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(c->ba_images, images_bgr_host, img_bytes, hipMemcpyHostToDevice, c->stream));
@@ -896,44 +935,63 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
     return ba_upload_poses(c);
 }
 
+/* the energy sweep enqueued into set `which` of the per-workgroup sums; ba_energy_read adds a set up in the fixed order */
+static int ba_energy_enqueue(gsdf_ctx* c, int which) {
+    gsdf_launch_ba_energy(c->stream, ba_dev(c), c->ba_block_E + (size_t)which * 3 * gsdf_ba_blocks());
+    HIP_TRY(hipGetLastError());
+    return GSDF_OK;
+}
+static float ba_energy_sum(gsdf_ctx* c, const double* h) {
+    const size_t nb = (size_t)gsdf_ba_blocks();
+    double s = 0.0, a = 0.0, o = 0.0;
+    for (size_t i = 0; i < nb; ++i) { s += h[i]; a += h[nb + i]; o += h[2 * nb + i]; }
+    c->ba_last_voxels = (long long)a; c->ba_last_obs = (long long)o;
+    return (float)s;
+}
+
 int gsdf_ba_energy(gsdf_ctx* c, float* E) {
     GSDF_FLUSH(c);
     int rc = ba_require(c);
     if (rc) return rc;
     if (!E) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    gsdf_launch_ba_energy(c->stream, ba_dev(c), c->ba_block_E);
-    std::vector<double> h((size_t)gsdf_ba_blocks());
+    if ((rc = ba_energy_enqueue(c, 0))) return rc;
+    std::vector<double> h((size_t)3 * gsdf_ba_blocks());
     HIP_TRY(hipMemcpyAsync(h.data(), c->ba_block_E, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    double s = 0.0;
-    for (double v : h) s += v;
-    *E = (float)s;
+    *E = ba_energy_sum(c, h.data());
     return GSDF_OK;
 }
 
+int gsdf_ba_counters(gsdf_ctx* c, int64_t* voxels, int64_t* observations) {
+    if (!c || !voxels || !observations) return fail(GSDF_ERR_INVALID, "null argument");
+    *voxels = c->ba_last_voxels; *observations = c->ba_last_obs;
+    return GSDF_OK;
+}
+
+static int ba_dist_enqueue(gsdf_ctx* c, float damping) {
+    gsdf_launch_ba_dist(c->stream, ba_dev(c), damping);
+    HIP_TRY(hipGetLastError());
+    return GSDF_OK;
+}
 int gsdf_ba_solve_dist(gsdf_ctx* c, float damping) {
     GSDF_FLUSH(c);
     int rc = ba_require(c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    gsdf_launch_ba_dist(c->stream, ba_dev(c), damping);
-    HIP_TRY(hipGetLastError());
+    if ((rc = ba_dist_enqueue(c, damping))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GSDF_OK;
 }
 
-int gsdf_ba_solve_pose(gsdf_ctx* c, float damping) {
-    GSDF_FLUSH(c);
-    (void)damping;                                            /* unused by the reference as well (:499) */
-    int rc = ba_require(c);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
+/* the pose sweep + the per-keyframe 6x6 solves; wait_upload: block until the new poses are on the device (the public entry)
+ * or leave the copy queued in front of whatever the caller enqueues next (gsdf_ba_optimize) */
+static int ba_solve_pose(gsdf_ctx* c, bool wait_upload) {
     const int n = c->ba_n;
     gsdf_launch_ba_pose(c->stream, ba_dev(c), c->ba_block_part, c->ba_Hb);
     std::vector<float> hb((size_t)n * 27);
     HIP_TRY(hipMemcpyAsync(hb.data(), c->ba_Hb, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                 /* the 6x6 systems are solved on the host (:577-589) */
     for (int i = 0; i < n; ++i) {                             /* per-keyframe 6x6 LDLT + pose update (:577-589) */
         const float* v = &hb[27 * (size_t)i];
         float H[36], dp[6];
@@ -954,25 +1012,47 @@ int gsdf_ba_solve_pose(gsdf_ctx* c, float damping) {
             for (int k = 0; k < 3; ++k) Rn[3 * r + k] = gsdf_sum3(Ri[3 * r] * Ex[k], Ri[3 * r + 1] * Ex[3 + k], Ri[3 * r + 2] * Ex[6 + k]);
         std::memcpy(&c->ba_R[9 * (size_t)i], Rn, sizeof(Rn));
     }
-    return ba_upload_poses(c);
+    if (wait_upload) return ba_upload_poses(c);
+    /* c->ba_R / ba_t are members: they stay untouched until the caller's next synchronisation, which is behind these copies */
+    HIP_TRY(hipMemcpyAsync(c->ba_Rt, c->ba_R.data(), c->ba_R.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ba_Rt + 9 * (size_t)c->ba_n, c->ba_t.data(), c->ba_t.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    return GSDF_OK;
+}
+int gsdf_ba_solve_pose(gsdf_ctx* c, float damping) {
+    GSDF_FLUSH(c);
+    (void)damping;                                            /* unused by the reference as well (:499) */
+    int rc = ba_require(c);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    return ba_solve_pose(c, true);
 }
 
+/* optimize (:611-662).  Per iteration the host needs two things from the device: the 27 sums per keyframe of the pose sweep
+ * (it solves the 6x6 systems) and, for the stop rule, the two energies.  So an iteration synchronises twice: behind the pose
+ * sweep, and ONCE behind [energy -> distance sweep -> energy], both energies in one read (they used to be four waits). */
 int gsdf_ba_optimize(gsdf_ctx* c, int max_it, float* energies, int* n_energies, int* converged) {
     GSDF_FLUSH(c);
     int rc = ba_require(c);
     if (rc) return rc;
     if (!energies || !n_energies || !converged || max_it < 0) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
     int ne = 0;
     float E = 0.f, E_pose = 0.f;
     *converged = 0;
     if ((rc = gsdf_ba_energy(c, &E))) return rc;
     energies[ne++] = E;
+    const size_t set = (size_t)3 * gsdf_ba_blocks();
+    std::vector<double> h(2 * set);
     for (int iter = 0; iter < max_it; ++iter) {               /* :621-657 */
-        if ((rc = gsdf_ba_solve_pose(c, 1.0f))) return rc;
-        if ((rc = gsdf_ba_energy(c, &E_pose))) return rc;
+        if ((rc = ba_solve_pose(c, false))) return rc;
+        if ((rc = ba_energy_enqueue(c, 0))) return rc;
+        if ((rc = ba_dist_enqueue(c, 1.0f))) return rc;
+        if ((rc = ba_energy_enqueue(c, 1))) return rc;
+        HIP_TRY(hipMemcpyAsync(h.data(), c->ba_block_E, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        E_pose = ba_energy_sum(c, h.data());
+        E = ba_energy_sum(c, h.data() + set);
         energies[ne++] = E_pose;
-        if ((rc = gsdf_ba_solve_dist(c, 1.0f))) return rc;
-        if ((rc = gsdf_ba_energy(c, &E))) return rc;
         energies[ne++] = E;
         const float rel = std::fabs(E_pose - E) / E_pose;
         if (rel < 0.0005f) { *converged = 1; break; }
@@ -1228,6 +1308,7 @@ int gsdf_dev_download(gsdf_ctx* c, void* host_dst, const void* dev_src, int64_t 
 int gsdf_dev_upload(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes) {
     if (!c || !dev_dst || !host_src || bytes < 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = flush_if_overlaps(c, dev_dst, bytes); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GSDF_OK;
@@ -1249,6 +1330,7 @@ int gsdf_host_free(gsdf_ctx* c, void* host_ptr) {
 int gsdf_dev_upload_async(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes) {
     if (!c || !dev_dst || !host_src || bytes < 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = flush_if_overlaps(c, dev_dst, bytes); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
     return GSDF_OK;
 }
@@ -1256,9 +1338,12 @@ int gsdf_mark(gsdf_ctx* c, int64_t* mark) {
     GSDF_FLUSH(c);
     if (!c || !mark) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    /* a mark says "the stream has passed this point" -- what a staging slot's recycling needs -- and nothing about device
+     * memory being visible to the host (the download entries synchronise for that): no system-scope fence, which would write
+     * back and invalidate the caches between the frame's fusion and the next frame's first tracker pass */
     hipEvent_t e = nullptr;
     if (!c->mark_pool.empty()) { e = c->mark_pool.back(); c->mark_pool.pop_back(); }
-    else HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    else HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
     HIP_TRY(hipEventRecord(e, c->stream));
     c->marks.push_back({ ++c->mark_serial, e });
     *mark = c->mark_serial;
@@ -1292,10 +1377,18 @@ int gsdf_mark_reached(gsdf_ctx* c, int64_t mark, int* reached) {
 int gsdf_dev_upload_ahead(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes, int64_t* upload) {
     if (!c || !dev_dst || !host_src || bytes < 0 || !upload) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    /* (a caller that keeps to the contract -- dev_dst is out of the stream's reach: its last reader passed a gsdf_mark, which
+     * launched any waiting fusion -- never gets here with an overlap; the copy stream is not ordered behind the kernels) */
+    if (c->pending.valid) {
+        const uintptr_t a0 = (uintptr_t)dev_dst, b0 = (uintptr_t)c->pending.depth;
+        if (a0 < b0 + (size_t)c->W * c->H * sizeof(float) && b0 < a0 + (uintptr_t)bytes)
+            return fail(GSDF_ERR_INVALID, "gsdf_dev_upload_ahead into the depth image of a fusion that has not run yet (record a gsdf_mark "
+                                          "behind its gsdf_update_dev and wait for it first)");
+    }
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->copy_stream));
-    hipEvent_t e = nullptr;
-    if (!c->mark_pool.empty()) { e = c->mark_pool.back(); c->mark_pool.pop_back(); }
+    hipEvent_t e = nullptr;                                      /* (a pool of their own: these keep the default fences) */
+    if (!c->upload_pool.empty()) { e = c->upload_pool.back(); c->upload_pool.pop_back(); }
     else HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(e, c->copy_stream));
     c->uploads.push_back({ ++c->upload_serial, e });
@@ -1309,7 +1402,7 @@ int gsdf_upload_wait(gsdf_ctx* c, int64_t upload) {
         hipEvent_t e = c->uploads.front().second;
         const hipError_t q = hipEventSynchronize(e);
         if (q != hipSuccess) return fail(GSDF_ERR_HIP, std::string("gsdf upload: ") + hipGetErrorString(q));
-        c->mark_pool.push_back(e);
+        c->upload_pool.push_back(e);
         c->uploads.pop_front();
     }
     return GSDF_OK;

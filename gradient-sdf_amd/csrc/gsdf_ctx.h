@@ -15,6 +15,7 @@
 #include <vector>
 
 #define GSDF_SCRATCH_BYTES (256 * 1024)
+#define GSDF_MX_BUFS 8
 #define GSDF_PROF_SLOTS 5     /* gsdf_profile: 0 normals, 1 fusion, 2 tracking launches, 3 raycast, 4 tracker (whole optimize) */
 
 inline thread_local std::string g_gsdf_err;
@@ -64,7 +65,7 @@ struct gsdf_ctx {
     unsigned int* track_abort = nullptr;           /* k_track_all: abort word */
     int persist = 0;                               /* optimize() as one launch (k_track_all) instead of one launch per pass */
     unsigned long long* blk_counters = nullptr;
-    int fuse_blocks = 0;
+    int fuse_blocks = 0;                           /* tiles of a frame */
     gsdf_deferred* deferred = nullptr;
     unsigned int* deferred_count = nullptr;
     unsigned int* fuse_ticket = nullptr;           /* arrivals of finished k_fuse workgroups (reset by the last one) */
@@ -80,6 +81,7 @@ struct gsdf_ctx {
     void* scratch = nullptr;                       /* device scratch of gsdf_query / gsdf_get_voxels for small batches (GSDF_SCRATCH_BYTES) */
     bool occ_dirty = false;                        /* blocks may have been inserted since the raycaster's filters (gsdf_table::occ) were built */
     bool merged = false;                           /* gsdf_merge_allreduce has run: the map is the sum of all ranks (one-shot) */
+    struct mx_buf { void* p = nullptr; size_t bytes = 0; } mx[GSDF_MX_BUFS];   /* scratch of the exchange (gsdf_merge.hip): grows, never shrinks */
     /* PhotoBA (PhotometricOptimizer) */
     int ba_n = 0;
     float ba_reg = 10.f;
@@ -91,6 +93,7 @@ struct gsdf_ctx {
     float* ba_block_part = nullptr;
     float* ba_Hb = nullptr;
     std::vector<float> ba_R, ba_t;                 /* host copies of the keyframe poses being optimised */
+    long long ba_last_voxels = 0, ba_last_obs = 0; /* what the last energy sweep read back counted (gsdf_ba_counters) */
     unsigned int track_serial = 0;                 /* optimize() call counter */
     volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */
     unsigned int* progress_dev = nullptr;
@@ -109,7 +112,7 @@ struct gsdf_ctx {
     std::vector<hipEvent_t> event_pool;
     /* gsdf_mark: events recorded on the stream, retired in order */
     std::deque<std::pair<long long, hipEvent_t>> marks;
-    std::vector<hipEvent_t> mark_pool;
+    std::vector<hipEvent_t> mark_pool, upload_pool;
     long long mark_serial = 0;
     hipStream_t copy_stream = nullptr;             /* gsdf_dev_upload_ahead: created on first use */
     std::deque<std::pair<long long, hipEvent_t>> uploads;

@@ -159,6 +159,10 @@ void gsdf_launch_mesh(hipStream_t s, gsdf_table tab, size_t n_slots, float vs, f
 
 /* mesh export: device radix sort of (64-bit sweep key, triangle index) pairs (rocPRIM; tmp == nullptr: only *tmp_bytes is set),
  * index fill, and the gather of 9-float triangles into sorted order (gsdf_sort.hip) */
+hipError_t gsdf_sort_keys_u64(void* tmp, size_t* tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, size_t n,
+                              hipStream_t s);
+hipError_t gsdf_unique_u64(void* tmp, size_t* tmp_bytes, const unsigned long long* sorted_in, unsigned long long* out,
+                           unsigned long long* count_out, size_t n, hipStream_t s);
 hipError_t gsdf_sort_pairs_u64(void* tmp, size_t* tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
                                const uint32_t* vals_in, uint32_t* vals_out, size_t n, hipStream_t s);
 void gsdf_launch_iota(hipStream_t s, uint32_t* idx, size_t n);

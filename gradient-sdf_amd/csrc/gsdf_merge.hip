@@ -6,7 +6,8 @@
  * MapGradPixelSdf::update with a known pose (the GT-pose branch, main_scan_3d.cpp:250-254) depends only on (depth, pose)
  * and changes the map additively, so every rank (one process per GPU) fuses its own frames into its own map and ONE
  * exchange makes every map the sum of all:
- *   1. all-gather of the ranks' 4x4x4-block ids, sorted union (identical on every rank);
+ *   1. all-gather of the ranks' block-key arrays (the ids of their 4x4x4 blocks, 8 B per table entry, as they lie in HBM),
+ *      sorted union on the device (rocPRIM radix sort + unique; identical on every rank);
  *   2. gsdf pack:    64 x 5 raw sums (w, s, gx, gy, gz) per block of the union into ONE dense device buffer
  *                    (zeros where this rank has nothing): 1280 B per block, independent of the number of ranks;
  *   3. all-reduce (sum, float32) of that buffer -- RCCL over xGMI; RCCL picks ring / direct by size;
@@ -145,11 +146,18 @@ struct host_transport : transport {
     }
 };
 
-struct dev_buf {
-    void* p = nullptr;
-    ~dev_buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-};
+/* Scratch of the exchange lives in the context and only grows (gsdf_ctx::mx): the first exchange of a context allocates,
+ * later ones find their buffers -- like the communicator, they are set-up that stays outside the exchange itself. */
+enum { MX_HDR = 0, MX_AGREE, MX_KEYS_ALL, MX_SORTED, MX_UNION, MX_TMP, MX_DENSE, MX_VIS, MX_COUNT_ };
+static_assert(MX_COUNT_ <= GSDF_MX_BUFS, "gsdf_ctx::mx is too small");
+int mx_ensure(gsdf_ctx* c, int i, size_t bytes, bool spare) {
+    if (c->mx[i].bytes >= bytes && c->mx[i].p) return GSDF_OK;
+    if (c->mx[i].p) { (void)hipFree(c->mx[i].p); c->mx[i].p = nullptr; c->mx[i].bytes = 0; }      /* no exchange is in flight: every one ends with a sync */
+    const size_t want = std::max<size_t>(spare ? bytes + bytes / 4 : bytes, 256);
+    HIP_TRY(hipMalloc(&c->mx[i].p, want));
+    c->mx[i].bytes = want;
+    return GSDF_OK;
+}
 
 int read_status(gsdf_ctx* c) {
     gsdf_dev_state s;
@@ -160,21 +168,38 @@ int read_status(gsdf_ctx* c) {
     return GSDF_OK;
 }
 
-/* What every rank tells the others before anything is exchanged.  `err` makes local failures collective: a rank that could
- * not prepare (allocation, launch) still takes part in this all-gather, and then ALL ranks return an error together instead
- * of one leaving its peers inside a collective. */
+/* What every rank tells the others before anything sized is exchanged.  `err` makes local failures collective: a rank that
+ * could not prepare (allocation, launch) still takes part in this all-gather, and then ALL ranks return an error together
+ * instead of one leaving its peers inside a collective. */
 struct merge_hdr {
-    long long n_blocks;          /* blocks of this rank's map */
-    long long frames;            /* Sdf::counter_ of this rank: frames it integrated */
+    long long cap_blocks;        /* entries of this rank's block-key array: must be equal on all ranks (same capacity_log2) */
+    long long frames;            /* Sdf::counter_ of this rank: frames it integrated (filled in on the device) */
     long long vis_words;         /* words per voxel of its vis_ bit-vectors, 0 = not enabled */
     long long err;               /* GSDF_ERR_* of its preparation, 0 = fine */
     unsigned long long token;    /* random: a rank finds its own position in the gathered list by it (the callback transport
                                     does not tell a rank its number) */
+    long long dense_blocks;      /* blocks its pack / all-reduce buffers can hold as they are (so that every rank knows whether
+                                    anybody has to allocate once the size of the union is known) */
+    long long pad[2];
 };
+static_assert(sizeof(merge_hdr) == 64, "header layout");
 
-/* second agreement point: every rank reports whether its buffers for the exchange exist */
-int agree(gsdf_ctx* c, transport& tr, long long* scratch_dev /* R + 1 words */, int local_rc, const char* what) {
+/* the header of this rank, completed on the device (Sdf::counter_ lives there): no host read before the first collective */
+__global__ void k_merge_hdr(merge_hdr* out, merge_hdr mine, const gsdf_dev_state* st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { mine.frames = st->frames; *out = mine; }
+}
+/* size of the union: the sorted unique list ends with the EMPTY marker whenever any rank's key array had a free entry */
+__global__ void k_union_size(const unsigned long long* uni, unsigned long long* count) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned long long n = *count;
+        *count = n - ((n > 0 && uni[n - 1] == GSDF_KEY_EMPTY) ? 1ull : 0ull);
+    }
+}
+
+/* agreement point: every rank reports whether its buffers for the next stage exist */
+int agree(gsdf_ctx* c, transport& tr, int local_rc, const char* what) {
     const int R = tr.nranks;
+    long long* scratch_dev = (long long*)c->mx[MX_AGREE].p;          /* R + 1 words */
     const long long mine = local_rc;
     HIP_TRY(hipMemcpyAsync(scratch_dev + R, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
     int rc = tr.allgather(c, scratch_dev + R, scratch_dev, sizeof(long long));
@@ -195,6 +220,12 @@ unsigned long long random_token(const gsdf_ctx* c) {
     return t ? t : 1ull;
 }
 
+/* The exchange.  Host synchronisations: (1) the gathered headers -- nothing sized by another rank's numbers is exchanged before
+ * they were checked --, (2) the size of the union, which the all-reduce's element count needs, (3) the sticky status at the
+ * end; a fourth one only when some rank has to allocate its pack buffers (first exchange of a context, or a larger union than
+ * ever before).  The union itself is made on the device: the ranks' block-key ARRAYS are all-gathered as they are (8 B per
+ * table entry: 0.5 MB at 2^22 records -- no compaction pass, no count to wait for), sorted (rocPRIM radix sort) and
+ * de-duplicated there; empty entries sort to the end.  Every rank computes the same list. */
 int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes_out) {
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = gsdf_flush_pending(c)) return rc;            /* the last frame's fusion may still wait for a successor (gsdf_update_dev) */
@@ -203,50 +234,58 @@ int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes
                                            "a second one would count every rank's frames again); gsdf_reset starts over");
     const size_t cap = c->n_slots / GSDF_BLOCK_VOX;
     const int R = tr.nranks;
-    /* 1. this rank's block ids and frame count.  Failures up to the first all-gather travel in the header. */
-    dev_buf local, hdr_dev, scratch;
-    unsigned long long n_local = 0;
-    gsdf_dev_state st_host;
-    std::memset(&st_host, 0, sizeof(st_host));
+    const size_t n_all = cap * (size_t)R;
+    /* two small buffers are needed to talk at all: without them this rank cannot even report its failure */
+    if (int rc = mx_ensure(c, MX_HDR, (size_t)(R + 1) * sizeof(merge_hdr), false)) return rc;
+    if (int rc = mx_ensure(c, MX_AGREE, (size_t)(R + 1) * sizeof(long long), false)) return rc;
+    /* 1. everything whose size follows from (ranks, capacity) alone is prepared BEFORE the header goes out: a failure travels
+     *    in the header */
+    size_t tmp_sort = 0, tmp_uniq = 0;
     auto prepare = [&]() -> int {
-        HIP_TRY(local.alloc(cap * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
-        gsdf_launch_block_keys(c->stream, c->tab, cap, (unsigned long long*)local.p, c->counter, (long long)cap);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&n_local, c->counter, sizeof(n_local), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(&st_host, c->st, sizeof(st_host), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        return GSDF_OK;
+        if (int rc = mx_ensure(c, MX_KEYS_ALL, n_all * sizeof(unsigned long long), false)) return rc;
+        if (int rc = mx_ensure(c, MX_SORTED, n_all * sizeof(unsigned long long), false)) return rc;
+        if (int rc = mx_ensure(c, MX_UNION, n_all * sizeof(unsigned long long), false)) return rc;
+        HIP_TRY(gsdf_sort_keys_u64(nullptr, &tmp_sort, nullptr, nullptr, n_all, c->stream));
+        HIP_TRY(gsdf_unique_u64(nullptr, &tmp_uniq, nullptr, nullptr, nullptr, n_all, c->stream));
+        return mx_ensure(c, MX_TMP, std::max(tmp_sort, tmp_uniq), false);
     };
     const int prep = prepare();
-    if (prep) n_local = 0;
-    /* two small buffers are needed to talk at all: without them this rank cannot even report its failure */
-    HIP_TRY(hdr_dev.alloc((size_t)(R + 1) * sizeof(merge_hdr)));
-    HIP_TRY(scratch.alloc((size_t)(R + 1) * sizeof(long long)));
-    merge_hdr* hd = (merge_hdr*)hdr_dev.p;
-    const merge_hdr mine = { (long long)n_local, (long long)st_host.frames, (long long)(c->vis ? c->vis_words : 0), (long long)prep,
-                             random_token(c) };
-    HIP_TRY(hipMemcpyAsync(hd + R, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream));
+    const int vw_mine = c->vis ? c->vis_words : 0;
+    auto dense_capacity = [&]() -> long long {      /* blocks the pack buffers hold as they are */
+        long long b = c->mx[MX_DENSE].p ? (long long)(c->mx[MX_DENSE].bytes / (GSDF_BLOCK_VOX * 5 * sizeof(float))) : 0;
+        if (vw_mine) b = std::min(b, c->mx[MX_VIS].p ? (long long)(c->mx[MX_VIS].bytes / (GSDF_BLOCK_VOX * (size_t)vw_mine * sizeof(uint32_t))) : 0ll);
+        return b;
+    };
+    merge_hdr* hd = (merge_hdr*)c->mx[MX_HDR].p;
+    merge_hdr mine;
+    std::memset(&mine, 0, sizeof(mine));
+    mine.cap_blocks = (long long)cap; mine.vis_words = vw_mine; mine.err = prep; mine.token = random_token(c);
+    mine.dense_blocks = dense_capacity();
+    hipLaunchKernelGGL(k_merge_hdr, dim3(1), dim3(64), 0, c->stream, hd + R, mine, c->st);
+    HIP_TRY(hipGetLastError());
     int rc = tr.allgather(c, hd + R, hd, sizeof(merge_hdr));
     if (rc) return rc;
     std::vector<merge_hdr> hdr((size_t)R);
     HIP_TRY(hipMemcpyAsync(hdr.data(), hd, (size_t)R * sizeof(merge_hdr), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                                                          /* (1) */
     if (prep) return prep;
     /* from here on every decision is taken from the gathered headers, i.e. identically on all ranks */
-    long long m = 1, frames_total = 0, frames_before = 0;
+    long long frames_total = 0, frames_before = 0, dense_min = hdr[0].dense_blocks;
     int me = -1, dup = 0;
     for (int r = 0; r < R; ++r) {
         const merge_hdr& h = hdr[(size_t)r];
-        if (h.err) return gsdf_fail((int)h.err, "gsdf_merge_allreduce: rank " + std::to_string(r) + " failed to list its blocks");
-        if (h.n_blocks < 0 || (size_t)h.n_blocks > ((size_t)1 << 40) || h.frames < 0)
+        if (h.err) return gsdf_fail((int)h.err, "gsdf_merge_allreduce: rank " + std::to_string(r) + " failed to prepare its buffers");
+        if (h.cap_blocks != (long long)cap)
+            return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: rank " + std::to_string(r) + " was created with another capacity_log2 "
+                                               "(the ranks exchange their block-key arrays: equal capacities required)");
+        if (h.frames < 0 || h.dense_blocks < 0)
             return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: inconsistent header from rank " + std::to_string(r));
         if (h.vis_words != hdr[0].vis_words)
             return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: gsdf_enable_vis must be called with the same frame count on every rank (or on none)");
         for (int q = 0; q < r; ++q) dup |= hdr[(size_t)q].token == h.token;
         if (h.token == mine.token) me = r;
-        m = std::max(m, h.n_blocks);
         frames_total += h.frames;
+        dense_min = std::min(dense_min, h.dense_blocks);
     }
     if (dup || me < 0) return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: rank tokens collide (retry)");   /* seen by all ranks */
     for (int r = 0; r < me; ++r) frames_before += hdr[(size_t)r].frames;
@@ -254,63 +293,57 @@ int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes
     if (vw && frames_total > 32ll * vw)
         return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: the ranks integrated " + std::to_string(frames_total) +
                                            " frames, gsdf_enable_vis reserved " + std::to_string(32ll * vw) + " bits per voxel");
-    /* 2. the ranks' id lists, padded to the longest one */
-    dev_buf padded, all;
-    auto alloc_lists = [&]() -> int {
-        HIP_TRY(padded.alloc((size_t)m * sizeof(unsigned long long)));
-        HIP_TRY(all.alloc((size_t)m * (size_t)R * sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(padded.p, 0xFF, (size_t)m * sizeof(unsigned long long), c->stream));
-        if (n_local) HIP_TRY(hipMemcpyAsync(padded.p, local.p, (size_t)n_local * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
-        return GSDF_OK;
-    };
-    rc = agree(c, tr, (long long*)scratch.p, alloc_lists(), "allocate its id list");
+    /* 2. the ranks' key arrays -> sorted union, on the device */
+    unsigned long long* keys_all = (unsigned long long*)c->mx[MX_KEYS_ALL].p;
+    unsigned long long* sorted = (unsigned long long*)c->mx[MX_SORTED].p;
+    unsigned long long* uk = (unsigned long long*)c->mx[MX_UNION].p;
+    rc = tr.allgather(c, c->tab.bkeys, keys_all, cap * sizeof(unsigned long long));
     if (rc) return rc;
-    rc = tr.allgather(c, padded.p, all.p, (size_t)m * sizeof(unsigned long long));
-    if (rc) return rc;
-    /* sorted union: a few 10^4 .. 10^5 ids (8 B each), host sort; every rank computes the same list */
-    std::vector<unsigned long long> ids((size_t)m * (size_t)R);
-    HIP_TRY(hipMemcpyAsync(ids.data(), all.p, ids.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<unsigned long long> uni;
-    uni.reserve(ids.size());
-    for (int r = 0; r < R; ++r) uni.insert(uni.end(), ids.begin() + (size_t)r * m, ids.begin() + (size_t)r * m + (size_t)hdr[(size_t)r].n_blocks);
-    std::sort(uni.begin(), uni.end());
-    uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
-    const size_t nu = uni.size();
+    size_t tmp_bytes = c->mx[MX_TMP].bytes;
+    HIP_TRY(gsdf_sort_keys_u64(c->mx[MX_TMP].p, &tmp_bytes, keys_all, sorted, n_all, c->stream));
+    tmp_bytes = c->mx[MX_TMP].bytes;
+    HIP_TRY(gsdf_unique_u64(c->mx[MX_TMP].p, &tmp_bytes, sorted, uk, c->counter, n_all, c->stream));
+    hipLaunchKernelGGL(k_union_size, dim3(1), dim3(64), 0, c->stream, uk, c->counter);
+    HIP_TRY(hipGetLastError());
+    unsigned long long nu64 = 0;
+    HIP_TRY(hipMemcpyAsync(&nu64, c->counter, sizeof(nu64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                                                          /* (2) */
+    const size_t nu = (size_t)nu64;
     const size_t vis_count = nu * GSDF_BLOCK_VOX * (size_t)vw;
     if (n_blocks_out) *n_blocks_out = (int64_t)nu;
     if (bytes_out) *bytes_out = (int64_t)(nu * GSDF_BLOCK_VOX * 5 * sizeof(float) + vis_count * sizeof(uint32_t));
-    /* 3. pack, all-reduce, unpack -- the sums, then the vis_ bit-vectors */
-    dev_buf union_dev, dense, dense_vis;
-    auto alloc_dense = [&]() -> int {
-        HIP_TRY(union_dev.alloc(nu * sizeof(unsigned long long)));
-        HIP_TRY(dense.alloc(nu * GSDF_BLOCK_VOX * 5 * sizeof(float)));
-        if (vw) HIP_TRY(dense_vis.alloc(vis_count * sizeof(uint32_t)));
-        if (nu) HIP_TRY(hipMemcpyAsync(union_dev.p, uni.data(), nu * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-        return GSDF_OK;
-    };
-    rc = agree(c, tr, (long long*)scratch.p, alloc_dense(), "allocate the exchange buffers");
-    if (rc) return rc;
+    /* 3. pack, all-reduce, unpack -- the sums, then the vis_ bit-vectors.  Whether ANY rank has to allocate is known to all of
+     *    them (the headers carry the capacities): only then do they meet once more to agree that it worked */
+    if ((long long)nu > dense_min) {
+        auto alloc_dense = [&]() -> int {
+            if (int r2 = mx_ensure(c, MX_DENSE, nu * GSDF_BLOCK_VOX * 5 * sizeof(float), true)) return r2;
+            if (vw) return mx_ensure(c, MX_VIS, vis_count * sizeof(uint32_t), true);
+            return GSDF_OK;
+        };
+        rc = agree(c, tr, alloc_dense(), "allocate the exchange buffers");
+        if (rc) return rc;
+    }
     if (nu) {
-        const unsigned long long* uk = (const unsigned long long*)union_dev.p;
-        gsdf_launch_pack_blocks(c->stream, c->tab, uk, (long long)nu, (float*)dense.p);
-        if (vw) gsdf_launch_pack_vis(c->stream, c->tab, c->vis, vw, frames_before, uk, (long long)nu, (uint32_t*)dense_vis.p);
+        float* dense = (float*)c->mx[MX_DENSE].p;
+        uint32_t* dense_vis = (uint32_t*)c->mx[MX_VIS].p;
+        gsdf_launch_pack_blocks(c->stream, c->tab, uk, (long long)nu, dense);
+        if (vw) gsdf_launch_pack_vis(c->stream, c->tab, c->vis, vw, frames_before, uk, (long long)nu, dense_vis);
         HIP_TRY(hipGetLastError());
-        rc = tr.allreduce_sum_f32(c, (float*)dense.p, nu * GSDF_BLOCK_VOX * 5);
+        rc = tr.allreduce_sum_f32(c, dense, nu * GSDF_BLOCK_VOX * 5);
         if (rc) return rc;
         if (vw) {
-            rc = tr.allreduce_or_u32(c, (uint32_t*)dense_vis.p, vis_count);
+            rc = tr.allreduce_or_u32(c, dense_vis, vis_count);
             if (rc) return rc;
         }
         c->occ_dirty = true;
-        gsdf_launch_unpack_blocks(c->stream, c->tab, uk, (long long)nu, (const float*)dense.p, c->st);
-        if (vw) gsdf_launch_unpack_vis(c->stream, c->tab, c->vis, vw, uk, (long long)nu, (const uint32_t*)dense_vis.p);
+        gsdf_launch_unpack_blocks(c->stream, c->tab, uk, (long long)nu, dense, c->st);
+        if (vw) gsdf_launch_unpack_vis(c->stream, c->tab, c->vis, vw, uk, (long long)nu, dense_vis);
     }
     /* Sdf::counter_ of the merged map: the frames of all ranks (frame f of rank r is integrated frame frames_before(r) + f) */
     gsdf_launch_set_frames(c->stream, c->st, frames_total);
     HIP_TRY(hipGetLastError());
     c->merged = R > 1;
-    return read_status(c);                                    /* synchronises: the buffers above may go */
+    return read_status(c);                                                                             /* (3) */
 }
 
 } // namespace

@@ -11,10 +11,21 @@
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
 
 hipError_t gsdf_sort_pairs_u64(void* tmp, size_t* tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
                                const uint32_t* vals_in, uint32_t* vals_out, size_t n, hipStream_t s) {
     return rocprim::radix_sort_pairs(tmp, *tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, s);
+}
+
+/* the exchange's union of block ids (gsdf_merge.hip): sort all ranks' key arrays, keep one of each */
+hipError_t gsdf_sort_keys_u64(void* tmp, size_t* tmp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out, size_t n,
+                              hipStream_t s) {
+    return rocprim::radix_sort_keys(tmp, *tmp_bytes, keys_in, keys_out, n, 0, 64, s);
+}
+hipError_t gsdf_unique_u64(void* tmp, size_t* tmp_bytes, const unsigned long long* sorted_in, unsigned long long* out,
+                           unsigned long long* count_out, size_t n, hipStream_t s) {
+    return rocprim::unique(tmp, *tmp_bytes, sorted_in, out, count_out, n, rocprim::equal_to<unsigned long long>(), s);
 }
 
 __global__ __launch_bounds__(256) void k_iota(uint32_t* idx, size_t n) {

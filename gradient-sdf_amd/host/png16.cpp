@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <mutex>
 
 namespace {
@@ -60,7 +61,9 @@ Scratch& scratch() { thread_local Scratch s; return s; }
 struct Header { int width = 0, height = 0, bit_depth = 0, channels = 0; };
 
 /* file -> unfiltered scanlines in scratch().raw: row y starts at (stride + 1) * y + 1 */
-bool decode_rows(const std::string& path, Header& hd, size_t& stride, int& bpp, std::string* err) {
+/* want_w / want_h > 0: the size the caller's buffer was made for -- a file of another size is rejected right behind its IHDR,
+ * before anything is sized by the header's numbers */
+bool decode_rows_impl(const std::string& path, Header& hd, size_t& stride, int& bpp, std::string* err, int want_w, int want_h) {
     Scratch& S = scratch();
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return fail(err, "cannot open file");
@@ -113,7 +116,10 @@ bool decode_rows(const std::string& path, Header& hd, size_t& stride, int& bpp, 
         default: return fail(err, "palette PNG not supported");
     }
     if (hd.width <= 0 || hd.height <= 0 || !idat) return fail(err, "no image data");
+    if (want_w > 0 && (hd.width != want_w || hd.height != want_h)) return fail(err, "frame size differs from --width/--height");
     bpp = hd.channels * hd.bit_depth / 8;
+    /* the header's numbers are untrusted: bound what gets allocated (a corrupt IHDR must not overflow size_t or ask for gigabytes) */
+    if ((unsigned long long)hd.width * (unsigned long long)hd.height * (unsigned long long)bpp > (1ull << 31)) return fail(err, "image too large");
     stride = (size_t)hd.width * bpp;
     const size_t raw_len = (stride + 1) * (size_t)hd.height;
     if (S.raw.size() < raw_len) S.raw.resize(raw_len);
@@ -149,6 +155,14 @@ bool decode_rows(const std::string& path, Header& hd, size_t& stride, int& bpp, 
     }
     return true;
 }
+/* decoder threads must not terminate the process: an allocation failure (file buffer, IDAT, scanlines) becomes an error string */
+bool decode_rows(const std::string& path, Header& hd, size_t& stride, int& bpp, std::string* err, int want_w = 0, int want_h = 0) {
+    try {
+        return decode_rows_impl(path, hd, stride, bpp, err, want_w, want_h);
+    } catch (const std::bad_alloc&) {
+        return fail(err, "out of memory while decoding");
+    }
+}
 }
 
 bool png_read(const std::string& path, PngImage& out, std::string* err) {
@@ -172,8 +186,8 @@ bool png_read_scaled(const std::string& path, float* dst, int width, int height,
     Header hd;
     size_t stride = 0;
     int bpp = 0;
-    if (!decode_rows(path, hd, stride, bpp, err)) return false;
-    if (hd.width != width || hd.height != height) return fail(err, "frame size differs from --width/--height");
+    if (width <= 0 || height <= 0) return fail(err, "bad frame size");
+    if (!decode_rows(path, hd, stride, bpp, err, width, height)) return false;
     const unsigned char* raw = scratch().raw.data();
     for (int y = 0; y < height; ++y) {
         const unsigned char* line = raw + (stride + 1) * (size_t)y + 1;

@@ -107,7 +107,16 @@ int launch_ranks(int argc, char** argv, const Options& opt) {
             std::perror("execv");
             _exit(127);
         }
-        if (pid < 0) { std::perror("fork"); return 1; }
+        if (pid < 0) {
+            /* the ranks already started wait for peers that will never come: release, stop and reap them, remove the segment */
+            std::perror("fork");
+            ShmCollective::abort_all(name);
+            for (pid_t k : kids) kill(k, SIGKILL);                             /* exact pids */
+            for (pid_t k : kids) { int st = 0; (void)waitpid(k, &st, 0); }
+            ShmCollective::destroy(name);
+            std::remove(("/dev/shm/" + name + ".id").c_str());
+            return 1;
+        }
         kids.push_back(pid);
     }
     /* Wait for the ranks.  The first one that fails takes the others with it: the abort flag releases ranks that wait in a
@@ -115,14 +124,16 @@ int launch_ranks(int argc, char** argv, const Options& opt) {
      * grace period -- by their exact pids. */
     int worst = 0;
     size_t left = kids.size();
+    bool stopping = false;                 /* the abort / grace period / kill sequence runs once; afterwards the ranks are only reaped */
     while (left > 0) {
         int st = 0;
         const pid_t pid = waitpid(-1, &st, 0);
         if (pid < 0) break;
         for (pid_t& k : kids) if (k == pid) { k = -1; --left; }
         const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
-        if (code > worst) worst = code;
-        if (code != 0 && left > 0) {
+        if (code > worst && !(stopping && !WIFEXITED(st))) worst = code;      /* ranks this launcher killed do not set the exit code */
+        if (code != 0 && left > 0 && !stopping) {
+            stopping = true;
             std::cerr << "a rank exited with code " << code << ": stopping the other ranks" << std::endl;
             ShmCollective::abort_all(name);
             for (int t = 0; t < 40 && left > 0; ++t) {                       /* 2 s to leave on their own */
@@ -338,10 +349,14 @@ int run(int, char**, Options& opt) {
         T.tic();
         pOpt.reset(new RigidPointOptimizer(tSDF.get()));
         if (lead) T.toc("Create RigidOptimizer");
-        double el = 0.;
+        double el = 0., el_all = 0.;
         {
-            /* staging buffers and decoder threads are set-up, like the map and the optimizer above: the clock of the frame loop
-             * starts behind them and stops before they are released */
+            /* Two clocks.  `el_all` starts BEFORE the staging buffers are created and the decoder threads start (they decode up to
+             * `slots` frames ahead at once), so every frame's load is inside it, as in the reference's loop (main_scan_3d.cpp:213);
+             * it is the number to compare.  `el` starts behind that set-up (page-locked allocations: 15-20 ms) and is the steady
+             * state of the loop; on a short stream the frames decoded ahead make it optimistic.  Both stop before the buffers are
+             * released. */
+            const auto t_all = std::chrono::steady_clock::now();
             FramePipeline pipe(ctx, loader.get(), std::vector<FrameEntry>(all.begin() + (long)lo, all.begin() + (long)hi), opt.width,
                                opt.height, opt.decode_threads);
             const auto t_loop = std::chrono::steady_clock::now();
@@ -370,11 +385,13 @@ int run(int, char**, Options& opt) {
             }
             if (gsdf_sync(ctx) != GSDF_OK) { std::cerr << "engine: " << gsdf_last_error() << std::endl; return 1; }
             el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_loop).count();
+            el_all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_all).count();
         }
         if (lead) {
             std::cout << "Current frame counter: " << tSDF->frame_counter() << std::endl;
-            std::cout << "---------- " << (hi - lo) << " frames loaded + " << (GT_pose ? "fused" : "tracked + fused") << ": " << el << "s ("
-                      << (double)(hi - lo) / el << " frames per second" << (sharded ? ", this rank" : "") << ")." << std::endl;
+            std::cout << "---------- " << (hi - lo) << " frames loaded + " << (GT_pose ? "fused" : "tracked + fused") << ": " << el_all << "s ("
+                      << (double)(hi - lo) / el_all << " frames per second" << (sharded ? ", this rank" : "") << "); behind the set-up of the "
+                      << "staging buffers and decoders: " << el << "s (" << (double)(hi - lo) / el << " frames per second)." << std::endl;
         }
         if (sharded) {
             T.tic();

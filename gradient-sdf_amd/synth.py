@@ -123,8 +123,9 @@ class Sequence:
     """A seeded synthetic depth stream: frame(i) -> (depth float32 HxW metres, R 3x3 f32, t 3 f32)."""
 
     def __init__(self, kind="spheres", W=640, H=480, n_frames=30, seed=0, noise=True,
-                 step_deg=0.5, unit=None):
+                 step_deg=0.5, unit=None, motion=1.0):
         self.kind, self.W, self.H, self.n, self.seed, self.noise = kind, W, H, n_frames, seed, noise
+        self.motion = float(motion)      # "tum": scale of the trajectory's time (0.5 = half the motion between two frames)
         self.K = intrinsics(W, H)
         self.step_deg = step_deg
         if kind == "spheres":
@@ -153,6 +154,7 @@ class Sequence:
             return R.astype(np.float32), pos.astype(np.float32)
         if self.kind == "tum":
             # fr1/xyz-like: +-0.2 m translations, <= ~1.4 cm/frame, < 1 deg rotation
+            i = i * self.motion
             pos = np.array([0.0, -0.65, 0.0]) + 0.2 * np.array([
                 np.sin(2 * np.pi * i / 120.0), np.sin(2 * np.pi * i / 90.0 + 1.0) - np.sin(1.0),
                 np.sin(2 * np.pi * i / 150.0 + 2.0) - np.sin(2.0)])

@@ -88,10 +88,16 @@ int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float*
 int gsdf_update(gsdf_ctx* c, const float* depth_host, const float R[9], const float t[3]);
 /* same with depth already resident in HBM; enqueue only.
  * Runs of this call are pipelined: the fusion of a frame is launched when the NEXT frame arrives (that launch's last workgroups
- * compute the next frame's normals in its otherwise idle tail) or when any other entry point of this header is called on the
- * context -- every one of them launches a waiting fusion first, so results never depend on it.  The caller's contract is the
- * old one: depth_dev must stay valid and unchanged until the fusion has RUN, i.e. until a mark recorded after this call
- * (gsdf_mark) has been reached, or gsdf_sync has returned. */
+ * compute the next frame's normals in its otherwise idle tail) or when any other entry point of this header that touches the
+ * map, the stream or the frame is called on the context -- every one of them launches a waiting fusion first, so results never
+ * depend on it.  The staging entries (gsdf_dev_upload, gsdf_dev_upload_async) do so when their destination overlaps the waiting
+ * fusion's depth image, so one staging buffer may be reused frame after frame (upload -> update_dev -> upload -> ...) exactly as
+ * before; gsdf_dev_alloc / gsdf_host_alloc / gsdf_host_free / gsdf_mark_wait / gsdf_mark_reached / gsdf_upload_wait do not
+ * touch it.  The caller's contract is the old one: depth_dev must stay valid and unchanged until the fusion has RUN, i.e. until
+ * a mark recorded after this call (gsdf_mark) has been reached, or gsdf_sync has returned.
+ * Error reporting lags with the launch: a launch error of frame i's fusion is returned by the call that launches it -- the
+ * gsdf_update_dev of frame i + 1 (which is then NOT queued: call it again after handling the error) or whichever entry point
+ * flushed it; device-side failures (GSDF_ERR_TABLE_FULL, GSDF_ERR_KEY_RANGE) are sticky and reported by gsdf_sync as before. */
 int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const float t[3]);
 
 /* RigidOptimizer::optimize(depth, K) -- RigidOptimizer.h:106, RigidPointOptimizer.cpp:40-99.
@@ -152,6 +158,10 @@ int gsdf_ba_solve_pose(gsdf_ctx* c, float damping);
 int gsdf_ba_solve_dist(gsdf_ctx* c, float damping);
 int gsdf_ba_optimize(gsdf_ctx* c, int max_it, float* energies, int* n_energies, int* converged);
 int gsdf_ba_get_poses(gsdf_ctx* c, float* poses16_host);
+/* what the last energy sweep whose result reached the host counted: voxels that took part (|dist| <= voxel size, :285, seen by
+ * at least one keyframe) and observations (voxel x keyframe pairs that project into the image, :238-260) -- the units of the
+ * sweeps' algorithmic bytes (measurement only; the reference has no counterpart) */
+int gsdf_ba_counters(gsdf_ctx* c, int64_t* voxels, int64_t* observations);
 
 /* additive merge of raw sums into this table (frame-sharded fusion) */
 int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, int64_t n);
@@ -175,8 +185,8 @@ int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t 
 /* The exchange step as ONE call, for C++ hosts (BASELINE.json north_star: "frames shard naturally across the
  * 8 GPUs of one node with a RCCL-over-xGMI all-reduce of per-voxel (weight, weighted-distance, weighted-gradient) before
  * mesh extraction").  Collective: every rank of the communicator calls it with the map it fused from its own frames (the
- * GT-pose branch, main_scan_3d.cpp:250-254); on return every rank's map is the sum of all maps.  Steps: all-gather of the
- * block ids, sorted union, gsdf pack, ONE ncclAllReduce (sum, float32, 1280 B per block of the union) on the context's own
+ * GT-pose branch, main_scan_3d.cpp:250-254; all contexts created with the SAME capacity_log2); on return every rank's map is
+ * the sum of all maps.  Steps: all-gather of the block-key arrays, sorted union on the device, gsdf pack, ONE ncclAllReduce (sum, float32, 1280 B per block of the union) on the context's own
  * stream, gsdf unpack.  nccl_comm: an ncclComm_t of the RCCL already in the process (RCCL is resolved at run time, it is
  * not a link dependency of libgsdf.so).  n_blocks / bytes (nullable): size of the union / of the all-reduced buffers.
  * Also exchanged: Sdf::counter_ (Sdf.h:65) -- afterwards the frames integrated by ALL ranks -- and, when gsdf_enable_vis was

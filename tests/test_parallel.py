@@ -279,6 +279,122 @@ def test_merge_allreduce_over_rccl_one_rank(pkg):
     g.close()
 
 
+# ---- BASELINE configs[3] AS CONFIGURED (640x480, 1 cm voxels, trunc 10, sphere orbit): shards -> ONE exchange -> mesh ------
+
+C4_W, C4_H, C4_RANKS, C4_PER_RANK, C4_CAP = 640, 480, 4, 32, 23
+C4_STEP_DEG = 360.0 * 4 / 2000                      # the 2000-frame job's orbit (tools/run_c4.py, bench.py)
+
+
+def _c4_worker(rank, world, port, out_dir):
+    """One rank of C4 at full frame size: 32 consecutive frames of the sphere orbit fused with the ground-truth poses
+    (main_scan_3d.cpp:250-254) through the pipelined entry, then the C-ABI exchange (gloo callbacks: the ranks share one GPU)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    pkg = graft.package()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = world * C4_PER_RANK
+    seq = pkg.synth.Sequence("spheres", C4_W, C4_H, n_frames=n, seed=0, step_deg=C4_STEP_DEG)
+    vs = np.float32(0.01)
+    g = pkg.GradSdf(vs, np.float32(10) * vs, C4_W, C4_H, seq.K, capacity_log2=C4_CAP, device=0)
+    g.enable_vis(n)
+    lo, hi = pkg.parallel.shard_range(n, rank, world)
+    fr = [seq.frame(i) for i in range(lo, hi)]
+    dev = [g.upload(f[0]) for f in fr]
+    for d, f in zip(dev, fr):
+        g.update_dev(d, f[1], f[2])
+
+    def allgather(send):
+        t = torch.from_numpy(send)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return torch.cat(out).numpy()
+
+    def allreduce(buf):
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t)
+        return t.numpy()
+
+    own = g.count()
+    nb, nbytes = g.merge_allreduce_with(allgather, allreduce, world)
+    keys, pay = g.export(sorted=True, raw=True)
+    kv, vis = g.export_vis()
+    digest = hashlib.sha256(keys.tobytes() + pay.tobytes() + vis.tobytes()).hexdigest()
+    out = dict(own=own, nb=nb, nbytes=nbytes, frames=g.stats()["frames"], digest=digest, n=len(keys))
+    if rank == 0:
+        out.update(keys=keys, pay=pay, vis=vis, tris=g.extract_mesh())
+    np.savez(os.path.join(out_dir, "c4_rank%d.npz" % rank), **out)
+    g.close()
+    dist.destroy_process_group()
+
+
+def _tri_cells(tris, vs):
+    """cube cell of every triangle (a marching-cubes triangle lies inside the cube that emitted it)"""
+    c = np.floor(tris.reshape(-1, 3, 3).mean(axis=1) / vs - 1e-3).astype(np.int64)
+    return c
+
+
+@pytest.mark.gpu
+def test_c4_as_configured_shards_exchange_mesh(pkg, tmp_path):
+    """BASELINE configs[3] at its frame size and voxel size: four ranks x 32 frames of the sphere orbit (640x480, 1 cm, trunc 10,
+    ground-truth poses) -> gsdf_merge_allreduce_with -> every rank holds the map ONE context gets from all 128 frames: key set
+    bit-exact, sums within float re-association (1e-5 relative; the shards add 32 frames each and then the four sums, the single
+    context adds 128 frames in a row), vis_ bit-vectors and Sdf::counter_ equal; and the marching-cubes mesh of the merged map
+    is the mesh of the single map: the same cubes emit triangles (the ones whose corner distance sits within rounding of the
+    iso value may differ: < 0.1 %), vertices within 1e-5 m.  (Bit-for-bit equality of the meshes is not defined: the vertex
+    positions are ratios of sums whose last bits depend on the order of addition.)"""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_c4_worker, args=(C4_RANKS, port, str(tmp_path)), nprocs=C4_RANKS, join=True)
+    z = [np.load(tmp_path / ("c4_rank%d.npz" % r)) for r in range(C4_RANKS)]
+    n = C4_RANKS * C4_PER_RANK
+    assert len({str(a["digest"]) for a in z}) == 1                                 # every rank ends with the same map, bit for bit
+    assert all(int(a["frames"]) == n for a in z)
+    assert all(int(a["own"]) < int(a["n"]) for a in z)                              # the shards really differed
+    assert int(z[0]["nb"]) > 5000 and int(z[0]["nbytes"]) == int(z[0]["nb"]) * 64 * (5 * 4 + ((n + 31) // 32) * 4)
+    # the single context
+    seq = pkg.synth.Sequence("spheres", C4_W, C4_H, n_frames=n, seed=0, step_deg=C4_STEP_DEG)
+    vs = np.float32(0.01)
+    g = pkg.GradSdf(vs, np.float32(10) * vs, C4_W, C4_H, seq.K, capacity_log2=C4_CAP)
+    g.enable_vis(n)
+    for i in range(n):
+        d, R, t = seq.frame(i)
+        g.update_dev(g.upload(d), R, t)
+    keys, pay = g.export(sorted=True, raw=True)
+    kv, vis = g.export_vis()
+    tris = g.extract_mesh()
+    assert g.stats()["frames"] == n
+    g.close()
+    a = z[0]
+    assert len(keys) > 200000
+    assert np.array_equal(a["keys"], keys)                                          # occupancy: bit-exact
+    scale = np.maximum(1.0, np.abs(pay[:, 4:5]))
+    assert (np.abs(a["pay"] - pay) / scale).max() <= 1e-5
+    assert np.array_equal(a["vis"], vis)
+    # the meshes
+    ta, tb = a["tris"], tris
+    assert len(tb) > 20000 and abs(len(ta) - len(tb)) <= 1e-3 * len(tb)
+    ca, cb = _tri_cells(ta, float(vs)), _tri_cells(tb, float(vs))
+    pack = lambda c: ((c[:, 0] + (1 << 20)) << 42) | ((c[:, 1] + (1 << 20)) << 21) | (c[:, 2] + (1 << 20))
+    ka, kb = pack(ca), pack(cb)
+    ua, na = np.unique(ka, return_counts=True)
+    ub, nb_ = np.unique(kb, return_counts=True)
+    common, ia, ib = np.intersect1d(ua, ub, return_indices=True)
+    same_count = common[na[ia] == nb_[ib]]
+    assert len(same_count) >= (1 - 1e-3) * max(len(ua), len(ub))                   # the same cubes emit the same number of triangles
+    # cubes with exactly one triangle in both meshes: the vertices agree (both lists are in sweep order)
+    one = np.intersect1d(ua[na == 1], ub[nb_ == 1])
+    sa = np.flatnonzero(np.isin(ka, one)); sb = np.flatnonzero(np.isin(kb, one))
+    sa = sa[np.argsort(ka[sa], kind="stable")]; sb = sb[np.argsort(kb[sb], kind="stable")]
+    assert len(sa) == len(sb) > 1000
+    dv = np.abs(ta[sa].reshape(-1, 9) - tb[sb].reshape(-1, 9)).max(axis=1)
+    assert np.quantile(dv, 0.999) <= 1e-5 and (dv > 1e-4).mean() <= 1e-3
+
+
 # ---- bench.py --gpus N: the launch path ---------------------------------------------------------------------------------
 
 def _run_bench(extra, timeout=900):

@@ -4,23 +4,33 @@
 # 1. plain bench lines: the driver's window (--steps 20 --warmup 5) and the default window;
 # 2. rocprofv3 --kernel-trace --stats over the driver's command (per-kernel table + min/median/p90 + timeline classes);
 # 3. rocprofv3 --pmc passes over the SAME command, one counter group per pass (FETCH_SIZE and WRITE_SIZE cannot share a pass).
+#   tools/collect_profiles.sh <tag> c3    -> the same for BASELINE configs[2] (1280x960, 5 mm voxels, capacity 2^25: the map is
+#                                            1 GiB of records, outside the Infinity Cache): bench line, kernel trace, PMC passes
 set -u
 tag=${1:-r02}
+cfg=${2:-c2}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/prof_$tag
-mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 DRV="python $root/bench.py --gpus 1 --steps 20 --warmup 5"
+PMCJSON=pmc_latest.json
+if [ "$cfg" = "c3" ]; then
+  tag=${tag}_c3
+  DRV="$DRV --width 1280 --height 960 --voxel-size 0.005 --hash-capacity-log2 25"
+  PMCJSON=pmc_latest_c3.json
+  SKIP_EXTRAS=1
+fi
+out=$root/gpurun_out/prof_$tag
+mkdir -p $out
 if [ -z "${SKIP_BENCH:-}" ]; then
 $DRV > $out/bench_driver_window.json 2> $out/bench_driver_window.err
-GSDF_BENCH_DEBUG=1 python $root/bench.py > $out/bench_default.json 2> $out/bench_default.err
+[ "$cfg" = "c3" ] || GSDF_BENCH_DEBUG=1 python $root/bench.py > $out/bench_default.json 2> $out/bench_default.err
 rm -rf /tmp/kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o bench -- $DRV --cpu-frames 0 > $out/bench_profiled.json 2> $out/rocprof_kernel_trace.err
 cp $(find /tmp/kt -name '*kernel_stats.csv' | head -1) $out/bench_kernel_stats.csv 2>/dev/null
 python $root/tools/trace_summary.py /tmp/kt > $out/bench_kernel_summary.txt 2>&1
 python $root/tools/trace_timeline.py /tmp/kt > $out/bench_kernel_timeline.txt 2>&1
 # the same trace over the default 200-step window (a quarter of its frames does not converge: 25 passes, no fusion)
-rm -rf /tmp/ktd && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktd -o bench -- python $root/bench.py --cpu-frames 0 > $out/bench_default_profiled.json 2> $out/rocprof_kernel_trace_default.err
-python $root/tools/trace_summary.py /tmp/ktd > $out/bench_default_kernel_summary.txt 2>&1
+[ "$cfg" = "c3" ] || { rm -rf /tmp/ktd && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktd -o bench -- python $root/bench.py --cpu-frames 0 > $out/bench_default_profiled.json 2> $out/rocprof_kernel_trace_default.err
+python $root/tools/trace_summary.py /tmp/ktd > $out/bench_default_kernel_summary.txt 2>&1; }
 fi
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
@@ -31,7 +41,8 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum" "
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc$i -o pmc -- $DRV --only-main > /dev/null 2> $out/rocprof_pmc$i.err
 done
 python $root/tools/pmc_summary.py /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4 /tmp/pmc5 > $out/pmc_counters.txt 2> $out/pmc_summary.err
-python $root/tools/pmc_summary.py --json "$DRV --only-main" /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 > $out/pmc_latest.json 2>> $out/pmc_summary.err
+python $root/tools/pmc_summary.py --json "$DRV --only-main" --source "profiles/${tag}_pmc_counters.txt" /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 > $out/$PMCJSON 2>> $out/pmc_summary.err
+if [ -n "${SKIP_EXTRAS:-}" ]; then ls -la $out; exit 0; fi
 # 4. the raycaster: timing against the sample-at-a-time kernel (test build), per-workgroup lifetimes, PMC counters of both
 python $root/tools/raycast_bench.py > $out/raycast_bench.json 2> $out/raycast_bench.err
 GRAFT_REPO_ROOT=$root bash $root/tools/raycast_pmc.sh $tag > /dev/null 2>&1

@@ -28,7 +28,7 @@ assert L.gsdf_debug_trace(g.h, buf, NW) == 0
 t = np.array(list(buf), dtype=np.int64).reshape(NW, 16)
 t0 = t[:, 0].min()
 ts = (t[:, :11] - t0) / 100.0          # us
-tile = t[:, 15]; tx = tile & 0xFFFF; ty = tile >> 16
+tile = t[:, 15]; tx = tile & 0x7FFF; ty = (tile >> 16) & 0x7FFF
 colour = (tx & 1) + 2 * (ty & 1)
 xcc = t[:, 14] >> 32
 hw = t[:, 14] & 0xFFFFFFFF
@@ -60,5 +60,20 @@ for a in edges[:-1]:
     wt = (ts[:, 3] <= m) & (ts[:, 4] > m)
     fl = (ts[:, 2] <= m) & (ts[:, 10] > m) & ~wt
     print("%5.0f  %6d  %6d  %5d  %6d  %6d" % (a, run.sum(), pro.sum(), wk.sum(), wt.sum(), fl.sum()))
+# per CU (XCC, SE, SH, CU of HW_ID): how many workgroups it ran, when its last one ended; slot time used
+cu = (xcc << 16) | (hw & 0xFF00)
+ids = np.unique(cu)
+cnt = np.array([(cu == i).sum() for i in ids]); end = np.array([ts[cu == i, 10].max() for i in ids]); busy = np.array([(ts[cu == i, 10] - ts[cu == i, 0]).sum() for i in ids])
+span = ts[:, 10].max()
+print("CUs seen: %d; workgroups per CU: %s" % (len(ids), dict(zip(*np.unique(cnt, return_counts=True)))))
+print("end of a CU's last workgroup, us: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f" % (end.min(), np.percentile(end, 10), np.median(end), np.percentile(end, 90), end.max()))
+print("slot time used: %.0f of %.0f wg-us (2 slots x %d CUs x %.1f us) = %.2f; mean workgroup life %.1f us" % (busy.sum(), 2 * len(ids) * span, len(ids), span, busy.sum() / (2 * len(ids) * span), (ts[:, 10] - ts[:, 0]).mean()))
+for k in sorted(set(cnt)):
+    print("   CUs with %d workgroups: %d, their last end %.1f us (mean)" % (k, (cnt == k).sum(), end[cnt == k].mean()))
+life = ts[:, 10] - ts[:, 0]
+order = np.argsort(ts[:, 0])
+for a, b in ((0, 512), (512, 1024), (1024, NW)):
+    sel = order[a:b]
+    print("workgroups %4d..%4d by start: start %.1f..%.1f, mean life %.1f, walk %.1f, end %.1f..%.1f" % (a, b - 1, ts[sel, 0].min(), ts[sel, 0].max(), life[sel].mean(), d[sel, 1].mean(), ts[sel, 10].min(), ts[sel, 10].max()))
 np.save(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "fuse_trace.npy"), t)
 g.close()

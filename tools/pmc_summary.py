@@ -4,12 +4,16 @@ Launches that did no work are excluded per kernel and counter: bench.py queues k
 tracker passes and the launch exits at once when optimize() has not ended or did not converge, and k_track_pass launches
 behind the end of optimize() exit at once too.  A dispatch counts as EXECUTED when its value is at least 20 % of the median of
 the non-zero values of that kernel and counter.
-usage: pmc_summary.py [--json "<command>"] dir [dir ...]"""
+usage: pmc_summary.py [--json "<command>" [--source profiles/<file>]] dir [dir ...]"""
 import collections, csv, glob, json, statistics, sys
 args = sys.argv[1:]
 as_json = None
+source = "profiles/<tag>_pmc_counters.txt"
 if args and args[0] == "--json":
     as_json = args[1]
+    args = args[2:]
+if args and args[0] == "--source":       # the committed file the numbers can be recomputed from
+    source = args[1]
     args = args[2:]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for root in args:
@@ -37,7 +41,7 @@ else:
     kf = res[fuse[0]] if fuse else {}
     fetch_kb = kf.get("FETCH_SIZE", (0, 0, 0))[0]
     write_kb = kf.get("WRITE_SIZE", (0, 0, 0))[0]
-    out = {"source": "profiles/<tag>_pmc_counters.txt", "command": as_json,
+    out = {"source": source, "command": as_json,
            "unit_note": "FETCH_SIZE / WRITE_SIZE in KB as reported by rocprofv3 (TCC_EA0_RDREQ / WRREQ based); on gfx950 FETCH_SIZE "
                         "reports half the bytes of wide coalesced streams and is uncalibrated for the scattered 16-byte accesses of this "
                         "kernel (MI355X_MICROARCH.md, HBM section): the figure is an estimate, ratios between kernel versions are exact",
