@@ -17,6 +17,8 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 struct ba_img { int W, H; const float* p; };
 __device__ __forceinline__ const float* ba_px(const ba_img& im, int row, int col) { return im.p + ((size_t)row * im.W + col) * 3; }
@@ -75,7 +77,10 @@ struct ba_args {
     const int* frame_idx;
     float fx, fy, cx, cy, vs, reg_weight;
     float trunc_sq;
+    const uint32_t* gate_list;      /* nullable: slots of the voxels with |dist| <= vs, in slot order (gsdf_ba_compact) */
+    const unsigned long long* gate_count;
 };
+static_assert(sizeof(ba_args) == sizeof(gsdf_ba_dev), "ba_args mirrors gsdf_ba_dev (the launchers memcpy one into the other)");
 
 struct ba_voxel { float dist, w; gsdf_v3 grad, gn, c; };
 
@@ -157,7 +162,9 @@ __global__ __launch_bounds__(256) void k_ba_energy(ba_args a, double* block_E) {
     double E = 0.0;
     unsigned int n_act = 0u, n_obs = 0u;
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x; slot < a.n_slots; slot += stride) {
+    const size_t n_items = a.gate_list ? (size_t)*a.gate_count : a.n_slots;
+    for (size_t item = (size_t)blockIdx.x * 256 + threadIdx.x; item < n_items; item += stride) {
+        const size_t slot = a.gate_list ? (size_t)a.gate_list[item] : item;
         ba_voxel v;
         if (!ba_load_voxel(a, slot, &v)) continue;
         if (fabsf(v.dist) > a.vs) continue;                                   /* :285 */
@@ -242,9 +249,11 @@ __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /*
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const size_t stride = (size_t)gridDim.x * 256;
-    const size_t n_iter = (a.n_slots + stride - 1) / stride;
+    const size_t n_items = a.gate_list ? (size_t)*a.gate_count : a.n_slots;
+    const size_t n_iter = (n_items + stride - 1) / stride;
     for (size_t it = 0; it < n_iter; ++it) {                                   /* uniform trip count: DPP needs whole waves */
-        const size_t slot = it * stride + (size_t)blockIdx.x * 256 + threadIdx.x;
+        const size_t item = it * stride + (size_t)blockIdx.x * 256 + threadIdx.x;
+        const size_t slot = item < n_items ? (a.gate_list ? (size_t)a.gate_list[item] : item) : a.n_slots;
         ba_voxel v;
         bool ok = slot < a.n_slots && ba_load_voxel(a, slot, &v);
         ok = ok && !(fabsf(v.dist) > a.vs);                                    /* :509 */
@@ -313,6 +322,24 @@ __global__ void k_ba_pose_reduce(const float* block_part, int n_blocks, int n_va
     float s = 0.f;
     for (int b = 0; b < n_blocks; ++b) s += block_part[(size_t)b * n_vals + j];   /* fixed order */
     out[j] = s;
+}
+
+/* the gate of getEnergy / solvePose as a predicate over slot numbers: the voxel exists and |dist| <= vs (the same s / w division
+ * and comparison as the sweeps make) */
+struct ba_gate_pred {
+    const unsigned long long* bkeys;
+    const gsdf_payload* vox;
+    float vs;
+    __device__ bool operator()(const uint32_t& slot) const {
+        if (bkeys[slot / GSDF_BLOCK_VOX] == GSDF_KEY_EMPTY) return false;
+        const float2 ws = *reinterpret_cast<const float2*>(vox + slot);        /* w, s */
+        if (!(ws.x > 0.f)) return false;
+        return !(fabsf(ws.y / ws.x) > vs);
+    }
+};
+hipError_t gsdf_ba_compact(hipStream_t s, const gsdf_ba_dev& d, uint32_t* list_out, unsigned long long* count_out, void* tmp, size_t* tmp_bytes) {
+    const ba_gate_pred pred{ d.tab.bkeys, d.tab.vox, d.vs };
+    return rocprim::select(tmp, *tmp_bytes, rocprim::counting_iterator<uint32_t>(0u), list_out, count_out, d.n_slots, pred, s);
 }
 
 #define BA_BLOCKS 512

@@ -91,6 +91,21 @@ static int fuse_far_table(const gsdf_ctx* c) {
     return c->progress && c->progress[3] * 16u > (unsigned int)c->fuse_blocks ? 1 : 0;
 }
 
+/* Auto-grow (gsdf_set_auto_grow): called at the top of the frame entries.  The count in progress[4] lags by a few frames -- a
+ * hint that only has to arrive before the key array is ~95 % full (where the probe budget runs out): the table is doubled
+ * once 45 % of its block entries are in use.  Synchronous when it happens (a few 100 us per doubling, a handful of times
+ * per scan). */
+static int auto_grow_step(gsdf_ctx* c) {
+    if (!c->auto_grow_max || !c->progress) return GSDF_OK;
+    const size_t cap_blocks = c->n_slots / GSDF_BLOCK_VOX;
+    if (c->capacity_log2 < c->auto_grow_max && (size_t)c->progress[4] * 100u > cap_blocks * 45u) {
+        const int rc = gsdf_grow_impl(c, c->capacity_log2 + 1);
+        if (rc) return rc;
+    }
+    if (--c->grow_countdown <= 0) { c->grow_countdown = c->grow_check_every; gsdf_enqueue_block_count(c); }
+    return GSDF_OK;
+}
+
 /* one k_fuse launch: depth + its normal planes `nrm` (3 x N floats) -> the map.  next_depth (nullable): the launch's extra
  * workgroups compute the normals of that frame into next_nrm */
 int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsdf_pose_arg& pose, int use_dev_pose,
@@ -420,6 +435,7 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         if ((env = getenv("GSDF_NEXT_BATCH")) && atoi(env) >= 1) c->next_batch = atoi(env);
         if ((env = getenv("GSDF_PERSIST"))) c->persist = atoi(env);
         if ((env = getenv("GSDF_FAR_TABLE"))) c->far_table = atoi(env);       /* experiments: 0 / 1 pin the fusion kernel's table size */
+        if ((env = getenv("GSDF_GROW_CHECK_EVERY")) && atoi(env) >= 1) c->grow_check_every = atoi(env);   /* frames between two block counts of auto-grow */
     }
     int rc = gsdf_reset(c);
     if (rc != GSDF_OK) { gsdf_destroy(c); return rc; }
@@ -440,9 +456,9 @@ void gsdf_destroy(gsdf_ctx* c) {
     for (hipEvent_t e : c->mark_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->upload_pool) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.second);
-    void* ptrs[] = { c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
+    void* ptrs[] = { c->grow_scratch, c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
-                     c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
+                     c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb, c->ba_gate_list, c->ba_gate_tmp, c->counter2 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& b : c->mx) if (b.p) (void)hipFree(b.p);
     if (c->progress) (void)hipHostFree((void*)c->progress);
@@ -471,7 +487,24 @@ int gsdf_reset(gsdf_ctx* c) {
         HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->merged = false;
+    if (c->progress) c->progress[4] = 0u;                    /* auto-grow's block count (a grown table keeps its size) */
     c->occ_dirty = false;                                    /* the table clear zeroed the filters as well */
+    return GSDF_OK;
+}
+
+int gsdf_set_auto_grow(gsdf_ctx* c, int max_capacity_log2) {
+    GSDF_FLUSH(c);
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    if (max_capacity_log2 != 0 && (max_capacity_log2 < c->capacity_log2 || max_capacity_log2 > 30))
+        return fail(GSDF_ERR_INVALID, "gsdf_set_auto_grow: 0 (off) or a capacity_log2 between the present one and 30");
+    HIP_TRY(hipSetDevice(c->device));
+    if (max_capacity_log2 && !c->grow_scratch) {
+        HIP_TRY(hipMalloc((void**)&c->grow_scratch, 2 * sizeof(unsigned int)));
+        HIP_TRY(hipMemsetAsync(c->grow_scratch, 0, 2 * sizeof(unsigned int), c->stream));
+    }
+    if (max_capacity_log2 && !c->progress) return fail(GSDF_ERR_HIP, "gsdf_set_auto_grow: no pinned progress words on this context");
+    c->auto_grow_max = max_capacity_log2;
+    c->grow_countdown = 0;
     return GSDF_OK;
 }
 
@@ -575,6 +608,7 @@ int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const
     if (rc) return rc;
     if (!depth_dev || !R || !t) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    if ((rc = auto_grow_step(c))) return rc;
     gsdf_pose_arg pose;
     std::memcpy(pose.R, R, sizeof(pose.R));
     std::memcpy(pose.t, t, sizeof(pose.t));
@@ -670,6 +704,7 @@ int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9
     if (std::memcmp(K, c->K, 9 * sizeof(float)) != 0)
         return fail(GSDF_ERR_INVALID, "K differs from the intrinsics given to gsdf_normals_init");
     HIP_TRY(hipSetDevice(c->device));
+    if ((rc = auto_grow_step(c))) return rc;
     rc = enqueue_track(c, depth_dev, num_iterations, conv_threshold, damping, true);   /* main_scan_3d.cpp:258-265 */
     if (rc) return rc;
     HIP_TRY(hipGetLastError());                  /* the frame's log row is written on the device: by the last workgroup of the
@@ -881,7 +916,18 @@ static gsdf_ba_dev ba_dev(gsdf_ctx* c) {
     d.images = c->ba_images; d.R = c->ba_Rt; d.t = c->ba_Rt + 9 * (size_t)c->ba_n; d.frame_idx = c->ba_frame_idx;
     d.fx = c->K[0]; d.fy = c->K[4]; d.cx = c->K[2]; d.cy = c->K[5]; d.vs = c->voxel_size; d.reg_weight = c->ba_reg;
     d.trunc_sq = c->ba_trunc_sq;
+    d.gate_list = c->ba_gate_fresh ? c->ba_gate_list : nullptr;
+    d.gate_count = c->counter2;
     return d;
+}
+/* (re)builds the list of the voxels inside the |dist| <= vs gate, if the distances may have changed since it was made.  Enqueue
+ * only; failures leave the sweeps on their whole-table form (gate_list == nullptr). */
+static void ba_refresh_gate(gsdf_ctx* c) {
+    if (c->ba_gate_fresh || !c->ba_gate_list || !c->counter2) return;
+    gsdf_ba_dev d = ba_dev(c);
+    size_t bytes = c->ba_gate_tmp_bytes;
+    if (gsdf_ba_compact(c->stream, d, c->ba_gate_list, c->counter2, c->ba_gate_tmp, &bytes) == hipSuccess) c->ba_gate_fresh = true;
+    else (void)hipGetLastError();
 }
 static int ba_upload_poses(gsdf_ctx* c) {
     HIP_TRY(hipMemcpyAsync(c->ba_Rt, c->ba_R.data(), c->ba_R.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -911,8 +957,9 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
     if (n <= 0 || n > 64 || !images_bgr_host || !poses16_host || !frame_idx) return fail(GSDF_ERR_INVALID, "bad argument (1..64 keyframes)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    void* old[] = { c->ba_images, c->ba_Rt, c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb };
+    void* old[] = { c->ba_images, c->ba_Rt, c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb, c->ba_gate_list, c->ba_gate_tmp, c->counter2 };
     for (void* p : old) if (p) (void)hipFree(p);
+    c->ba_gate_list = nullptr; c->ba_gate_tmp = nullptr; c->counter2 = nullptr; c->ba_gate_fresh = false;
     c->ba_images = nullptr; c->ba_Rt = nullptr; c->ba_frame_idx = nullptr; c->ba_block_E = nullptr; c->ba_block_part = nullptr; c->ba_Hb = nullptr;
     c->ba_n = n; c->ba_reg = reg_weight;
     const size_t img_bytes = (size_t)n * c->W * c->H * 3 * sizeof(float);
@@ -924,6 +971,19 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
     HIP_TRY(hipMalloc((void**)&c->ba_block_E, (size_t)2 * 3 * gsdf_ba_blocks() * sizeof(double)));
     HIP_TRY(hipMalloc((void**)&c->ba_block_part, (size_t)gsdf_ba_blocks() * n * 27 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->ba_Hb, (size_t)n * 27 * sizeof(float)));
+    {   /* the gate list of the energy / pose sweeps: optional (without it they sweep the whole table) */
+        gsdf_ba_dev d = ba_dev(c);
+        size_t bytes = 0;
+        if (gsdf_ba_compact(c->stream, d, nullptr, nullptr, nullptr, &bytes) == hipSuccess &&
+            hipMalloc((void**)&c->ba_gate_list, c->n_slots * sizeof(uint32_t)) == hipSuccess &&
+            hipMalloc(&c->ba_gate_tmp, bytes ? bytes : 8) == hipSuccess && hipMalloc((void**)&c->counter2, sizeof(unsigned long long)) == hipSuccess) {
+            c->ba_gate_tmp_bytes = bytes;
+        } else {
+            (void)hipGetLastError();
+            if (c->ba_gate_list) { (void)hipFree(c->ba_gate_list); c->ba_gate_list = nullptr; }
+        }
+        c->ba_gate_fresh = false;
+    }
     HIP_TRY(hipMemcpyAsync(c->ba_images, images_bgr_host, img_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->ba_frame_idx, frame_idx, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     c->ba_R.resize(9 * (size_t)n); c->ba_t.resize(3 * (size_t)n);
@@ -937,6 +997,7 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
 
 /* the energy sweep enqueued into set `which` of the per-workgroup sums; ba_energy_read adds a set up in the fixed order */
 static int ba_energy_enqueue(gsdf_ctx* c, int which) {
+    ba_refresh_gate(c);
     gsdf_launch_ba_energy(c->stream, ba_dev(c), c->ba_block_E + (size_t)which * 3 * gsdf_ba_blocks());
     HIP_TRY(hipGetLastError());
     return GSDF_OK;
@@ -953,6 +1014,7 @@ int gsdf_ba_energy(gsdf_ctx* c, float* E) {
     GSDF_FLUSH(c);
     int rc = ba_require(c);
     if (rc) return rc;
+    c->ba_gate_fresh = false;                                 /* the map may have changed since the last BA call */
     if (!E) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     if ((rc = ba_energy_enqueue(c, 0))) return rc;
@@ -971,6 +1033,7 @@ int gsdf_ba_counters(gsdf_ctx* c, int64_t* voxels, int64_t* observations) {
 
 static int ba_dist_enqueue(gsdf_ctx* c, float damping) {
     gsdf_launch_ba_dist(c->stream, ba_dev(c), damping);
+    c->ba_gate_fresh = false;                                 /* the distances moved: voxels may have crossed the gate */
     HIP_TRY(hipGetLastError());
     return GSDF_OK;
 }
@@ -988,6 +1051,7 @@ int gsdf_ba_solve_dist(gsdf_ctx* c, float damping) {
  * or leave the copy queued in front of whatever the caller enqueues next (gsdf_ba_optimize) */
 static int ba_solve_pose(gsdf_ctx* c, bool wait_upload) {
     const int n = c->ba_n;
+    ba_refresh_gate(c);
     gsdf_launch_ba_pose(c->stream, ba_dev(c), c->ba_block_part, c->ba_Hb);
     std::vector<float> hb((size_t)n * 27);
     HIP_TRY(hipMemcpyAsync(hb.data(), c->ba_Hb, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -1023,6 +1087,7 @@ int gsdf_ba_solve_pose(gsdf_ctx* c, float damping) {
     (void)damping;                                            /* unused by the reference as well (:499) */
     int rc = ba_require(c);
     if (rc) return rc;
+    c->ba_gate_fresh = false;                                 /* the map may have changed since the last BA call */
     HIP_TRY(hipSetDevice(c->device));
     return ba_solve_pose(c, true);
 }
@@ -1034,6 +1099,7 @@ int gsdf_ba_optimize(gsdf_ctx* c, int max_it, float* energies, int* n_energies, 
     GSDF_FLUSH(c);
     int rc = ba_require(c);
     if (rc) return rc;
+    c->ba_gate_fresh = false;                                 /* the map may have changed since the last BA call */
     if (!energies || !n_energies || !converged || max_it < 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     int ne = 0;

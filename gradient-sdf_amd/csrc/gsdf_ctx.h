@@ -16,12 +16,15 @@
 
 #define GSDF_SCRATCH_BYTES (256 * 1024)
 #define GSDF_MX_BUFS 8
+#define GSDF_GROW_CHECK_EVERY_DEFAULT 8   /* frames between two counts of the existing blocks (auto-grow) */
 #define GSDF_PROF_SLOTS 5     /* gsdf_profile: 0 normals, 1 fusion, 2 tracking launches, 3 raycast, 4 tracker (whole optimize) */
 
 inline thread_local std::string g_gsdf_err;
 
 struct gsdf_ctx;
 int gsdf_flush_pending(gsdf_ctx* c);               /* gsdf_capi.hip: launch the deferred GT-pose fusion, if one waits */
+int gsdf_grow_impl(gsdf_ctx* c, int new_capacity_log2);      /* gsdf_merge.hip: rehash into a larger table */
+void gsdf_enqueue_block_count(gsdf_ctx* c);        /* gsdf_merge.hip: existing blocks -> pinned word progress[4] */
 
 inline int gsdf_fail(int code, const std::string& msg) {
     g_gsdf_err = msg;
@@ -80,6 +83,12 @@ struct gsdf_ctx {
     long long rc_iters[2] = { 0, 0 };              /* loop iterations of the workgroups' wave 0 as of the last gsdf_raycast_counters */
     void* scratch = nullptr;                       /* device scratch of gsdf_query / gsdf_get_voxels for small batches (GSDF_SCRATCH_BYTES) */
     bool occ_dirty = false;                        /* blocks may have been inserted since the raycaster's filters (gsdf_table::occ) were built */
+    /* the reference's map grows without bound (MapGradPixelSdf.h:65-68); here: gsdf_grow, or by itself when gsdf_set_auto_grow
+     * named a limit -- every few fusions the number of existing blocks is counted into a pinned word, and a frame entry that
+     * finds the key array more than GSDF_GROW_LOAD full doubles the table first */
+    int auto_grow_max = 0;                         /* largest capacity_log2 auto-grow may reach; 0 = off */
+    int grow_countdown = 0, grow_check_every = GSDF_GROW_CHECK_EVERY_DEFAULT;
+    unsigned int* grow_scratch = nullptr;          /* two device words of k_count_blocks */
     bool merged = false;                           /* gsdf_merge_allreduce has run: the map is the sum of all ranks (one-shot) */
     struct mx_buf { void* p = nullptr; size_t bytes = 0; } mx[GSDF_MX_BUFS];   /* scratch of the exchange (gsdf_merge.hip): grows, never shrinks */
     /* PhotoBA (PhotometricOptimizer) */
@@ -93,6 +102,11 @@ struct gsdf_ctx {
     float* ba_block_part = nullptr;
     float* ba_Hb = nullptr;
     std::vector<float> ba_R, ba_t;                 /* host copies of the keyframe poses being optimised */
+    uint32_t* ba_gate_list = nullptr;              /* slots of the voxels with |dist| <= voxel size (the gate of getEnergy / solvePose), slot order */
+    void* ba_gate_tmp = nullptr;                   /* rocPRIM select scratch */
+    size_t ba_gate_tmp_bytes = 0;
+    unsigned long long* counter2 = nullptr;        /* device word: entries of ba_gate_list */
+    bool ba_gate_fresh = false;                    /* the list matches the distances in the table */
     long long ba_last_voxels = 0, ba_last_obs = 0; /* what the last energy sweep read back counted (gsdf_ba_counters) */
     unsigned int track_serial = 0;                 /* optimize() call counter */
     volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */

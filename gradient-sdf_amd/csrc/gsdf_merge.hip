@@ -346,6 +346,102 @@ int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes
     return read_status(c);                                                                             /* (3) */
 }
 
+/* ---- growing the map (gsdf_grow): every block of the old table moves into a table of twice (or more) the entries ---- */
+/* one wave per old entry: lane 0 claims the block's entry in the new key array, the 64 lanes copy its 64 records (and their
+ * vis_ words); the new table is empty and larger, so the probe budget cannot run out */
+__global__ __launch_bounds__(256) void k_rehash(gsdf_table from, gsdf_table to, const uint32_t* vis_from, uint32_t* vis_to, int vw,
+                                                size_t n_blocks_from, gsdf_dev_state* st) {
+    const size_t b = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_blocks_from) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bk = from.bkeys[b];
+    if (bk == GSDF_KEY_EMPTY) return;
+    int nb = -1;
+    if (lane == 0) {
+        const uint32_t h = gsdf_hash(bk) & to.block_mask;
+        nb = gsdf_block_find_or_insert(to, bk, h, to.bkeys[h]);
+        if (nb < 0) atomicOr(&st->status, GSDF_STATUS_TABLE_FULL);
+    }
+    nb = __shfl(nb, 0);
+    if (nb < 0) return;
+    const size_t src = b * GSDF_BLOCK_VOX + lane, dst = (size_t)nb * GSDF_BLOCK_VOX + lane;
+    const uint4* ps = reinterpret_cast<const uint4*>(from.vox + src);
+    uint4* pd = reinterpret_cast<uint4*>(to.vox + dst);
+    pd[0] = ps[0]; pd[1] = ps[1];
+    for (int w = 0; w < vw; ++w) vis_to[dst * vw + w] = vis_from[src * vw + w];
+}
+/* occupied entries of the key array -> one pinned host word (auto-grow: the host looks at it without waiting) */
+__global__ __launch_bounds__(256) void k_count_blocks(const unsigned long long* bkeys, size_t n, unsigned int* scratch, unsigned int* host_word) {
+    __shared__ unsigned int part[4];
+    unsigned int c = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += bkeys[i] != GSDF_KEY_EMPTY ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&scratch[0], part[0] + part[1] + part[2] + part[3]);
+        __threadfence();
+        if (atomicAdd(&scratch[1], 1u) + 1u == gridDim.x) {               /* the last workgroup publishes and resets */
+            __hip_atomic_store(host_word, __hip_atomic_load(&scratch[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&scratch[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&scratch[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+} // namespace
+
+/* enqueue the count of existing blocks into the pinned word progress[4] (gsdf_capi.hip calls it every few fusions when
+ * auto-grow is on) */
+void gsdf_enqueue_block_count(gsdf_ctx* c) {
+    if (!c->progress_dev || !c->grow_scratch) return;
+    const size_t cap = c->n_slots / GSDF_BLOCK_VOX;
+    hipLaunchKernelGGL(k_count_blocks, dim3(64), dim3(256), 0, c->stream, c->tab.bkeys, cap, c->grow_scratch, c->progress_dev + 4);
+    (void)hipGetLastError();
+}
+
+int gsdf_grow_impl(gsdf_ctx* c, int new_capacity_log2) {
+    if (!c) return gsdf_fail(GSDF_ERR_INVALID, "null context");
+    if (new_capacity_log2 <= c->capacity_log2 || new_capacity_log2 > 30)
+        return gsdf_fail(GSDF_ERR_INVALID, "gsdf_grow: the new capacity_log2 must be larger than the present one and <= 30");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = gsdf_flush_pending(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t n_new = (size_t)1 << new_capacity_log2;
+    gsdf_table nt{ nullptr, nullptr, 0, nullptr };
+    uint32_t* nvis = nullptr;
+    auto release = [&]() { if (nt.vox) (void)hipFree(nt.vox); if (nt.bkeys) (void)hipFree(nt.bkeys); if (nt.occ) (void)hipFree(nt.occ); if (nvis) (void)hipFree(nvis); };
+    hipError_t e;
+    if ((e = hipMalloc((void**)&nt.vox, n_new * sizeof(gsdf_payload))) != hipSuccess ||
+        (e = hipMalloc((void**)&nt.bkeys, (n_new / GSDF_BLOCK_VOX) * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc((void**)&nt.occ, n_new / 8 + std::max<size_t>(n_new / GSDF_BLOCK_VOX / 8, 4))) != hipSuccess ||
+        (c->vis && (e = hipMalloc((void**)&nvis, n_new * (size_t)c->vis_words * sizeof(uint32_t))) != hipSuccess)) {
+        release();
+        (void)hipGetLastError();
+        return gsdf_fail(GSDF_ERR_HIP, std::string("gsdf_grow: ") + hipGetErrorString(e));      /* the map is untouched */
+    }
+    nt.block_mask = (uint32_t)(n_new / GSDF_BLOCK_VOX - 1);
+    gsdf_launch_table_clear(c->stream, nt, n_new);
+    if (nvis) HIP_TRY(hipMemsetAsync(nvis, 0, n_new * (size_t)c->vis_words * sizeof(uint32_t), c->stream));
+    const size_t nb_old = c->n_slots / GSDF_BLOCK_VOX;
+    hipLaunchKernelGGL(k_rehash, dim3((unsigned int)((nb_old + 3) / 4)), dim3(256), 0, c->stream, c->tab, nt, c->vis, nvis, c->vis ? c->vis_words : 0,
+                       nb_old, c->st);
+    HIP_TRY(hipGetLastError());
+    int rc = read_status(c);                                   /* synchronises */
+    if (rc) { release(); return rc; }
+    (void)hipFree(c->tab.vox); (void)hipFree(c->tab.bkeys); (void)hipFree(c->tab.occ);
+    if (c->vis) (void)hipFree(c->vis);
+    c->tab = nt; c->vis = nvis;
+    c->n_slots = n_new; c->capacity_log2 = new_capacity_log2;
+    c->occ_dirty = true;                                       /* the raycaster's filters are rebuilt from the keys when it next runs */
+    /* PhotoBA's gate list was sized for the old table: the sweeps fall back to the whole table until the next gsdf_ba_setup */
+    if (c->ba_gate_list) { (void)hipFree(c->ba_gate_list); c->ba_gate_list = nullptr; }
+    c->ba_gate_fresh = false;
+    if (c->progress) c->progress[4] = 0u;
+    return GSDF_OK;
+}
+
+namespace {
 } // namespace
 
 extern "C" {
@@ -385,6 +481,8 @@ int gsdf_rccl_comm_destroy(void* comm) {
     RCCL_TRY(rccl().CommDestroy((ncclComm_t)comm));
     return GSDF_OK;
 }
+
+int gsdf_grow(gsdf_ctx* c, int new_capacity_log2) { return gsdf_grow_impl(c, new_capacity_log2); }
 
 int gsdf_merge_allreduce(gsdf_ctx* c, void* nccl_comm, int64_t* n_blocks, int64_t* bytes) {
     if (!c || !nccl_comm) return gsdf_fail(GSDF_ERR_INVALID, "null argument");

@@ -13,9 +13,11 @@ void MapGradPixelSdf::check(int rc, const char* what) const {
     if (rc != GSDF_OK) throw std::runtime_error(std::string(what) + ": " + gsdf_last_error());
 }
 
-MapGradPixelSdf::MapGradPixelSdf(float voxel_size, float T, int capacity_log2, int device)
+MapGradPixelSdf::MapGradPixelSdf(float voxel_size, float T, int capacity_log2, int device, int max_capacity_log2)
     : voxel_size_(voxel_size), T_(T) {
     check(gsdf_create(&ctx_, voxel_size, T, capacity_log2, device), "gsdf_create");
+    /* tsdf_ of the reference grows as the scan does (MapGradPixelSdf.h:65-68): so does this map, up to max_capacity_log2 */
+    if (max_capacity_log2 > capacity_log2) check(gsdf_set_auto_grow(ctx_, max_capacity_log2), "gsdf_set_auto_grow");
 }
 
 MapGradPixelSdf::~MapGradPixelSdf() { gsdf_destroy(ctx_); }

@@ -26,7 +26,9 @@ class MapGradPixelSdf : public Sdf {
 
 public:
     /* MapGradPixelSdf(voxel_size, T) -- MapGradPixelSdf.h:99-103; capacity/device are new */
-    MapGradPixelSdf(float voxel_size, float T, int capacity_log2 = 22, int device = 0);
+    /* capacity_log2: 2^c voxel records to start with; the table doubles by itself as the map grows, up to 2^max_capacity_log2
+     * (8 GiB of records at 28; pass max == capacity for a fixed table, which then reports GSDF_ERR_TABLE_FULL when it overflows) */
+    MapGradPixelSdf(float voxel_size, float T, int capacity_log2 = 22, int device = 0, int max_capacity_log2 = 28);
     ~MapGradPixelSdf() override;
     MapGradPixelSdf(const MapGradPixelSdf&) = delete;
     MapGradPixelSdf& operator=(const MapGradPixelSdf&) = delete;

@@ -4,7 +4,8 @@
  * --data-type --voxel-size --trunc --save-sdf), same frame loop semantics (GT-pose fusion or track+fuse,
  * :208-281), same outputs (<results>_poses.txt in TUM format, <results>gradient_sdf_mesh_final.ply,
  * _cloud_final.ply, optional sdf text files, :285-311) and the Timer labels.  New flags:
- *   --width/--height (the reference hard-codes 640x480, :183), --hash-capacity (log2 slots), --device,
+ *   --width/--height (the reference hard-codes 640x480, :183), --hash-capacity (log2 voxel records to start with),
+ *   --hash-max-capacity (default 28: the table doubles by itself up to this, like the reference's map grows), --device,
  *   --sync            the reference's call structure literally: one blocking optimize() / update() per frame through the
  *                     facade classes (host-pointer entries; every call copies the frame and waits for the GPU);
  *   (default)         the device-resident loop: PNG decode on host threads into page-locked buffers, asynchronous copy
@@ -47,6 +48,7 @@ struct Options {
     float voxel_size = 0.01f, trunc = 5.f;
     bool save_sdf = false, sync = false;
     int width = 640, height = 480, capacity_log2 = 22, device = 0;
+    int max_capacity_log2 = 28;          /* the table doubles by itself up to this (the reference's map has no capacity) */
     int gpus = 1, rank = -1, decode_threads = 0;
     std::string transport = "rccl", rendezvous;
 };
@@ -60,7 +62,7 @@ bool parse(int argc, char** argv, Options& o) {
         if (a == "--sync") { o.sync = true; continue; }
         if (a == "-h" || a == "--help") {
             std::cout << "Hash Table-Based 3D Scanning (MI355X)\n  --input --results --pose-file --first --last --scan-type"
-                         " --data-type --voxel-size --trunc --save-sdf --width --height --hash-capacity --device"
+                         " --data-type --voxel-size --trunc --save-sdf --width --height --hash-capacity --hash-max-capacity --device"
                          " --sync --decode-threads --gpus --transport rccl|shm\n";
             std::exit(0);
         }
@@ -77,6 +79,7 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "--width") o.width = std::stoi(v);
         else if (a == "--height") o.height = std::stoi(v);
         else if (a == "--hash-capacity") o.capacity_log2 = std::stoi(v);
+        else if (a == "--hash-max-capacity") o.max_capacity_log2 = std::stoi(v);
         else if (a == "--device") o.device = std::stoi(v);
         else if (a == "--gpus") o.gpus = std::stoi(v);
         else if (a == "--rank") o.rank = std::stoi(v);                 /* set by the launcher */
@@ -293,7 +296,7 @@ int run(int, char**, Options& opt) {
             }
             if (i == opt.first) {
                 T.tic();
-                tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device));
+                tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device, std::max(opt.capacity_log2, opt.max_capacity_log2)));
                 T.toc("Create Sdf");
                 T.tic();
                 if (GT_pose) tSDF->update(color, depth, K, SE3(poses[0]), &NEst);          /* poses[0] even if --first > 0 (:242) */
@@ -342,7 +345,9 @@ int run(int, char**, Options& opt) {
         Exchange ex;
         if (sharded && !exchange_prepare(ex, opt, opt.device)) return 1;
         T.tic();
-        tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device));
+        /* frame shards over several ranks exchange their block-key arrays: every rank keeps the capacity it was started with */
+        tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device,
+                                       sharded ? opt.capacity_log2 : std::max(opt.capacity_log2, opt.max_capacity_log2)));
         if (lead) T.toc("Create Sdf");
         tSDF->prepare(opt.width, opt.height, K, &NEst);
         gsdf_ctx* ctx = tSDF->handle();

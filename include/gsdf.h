@@ -70,6 +70,14 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
 void gsdf_destroy(gsdf_ctx* c);
 /* drop all voxels, frame counter := 0 (new: lets one context be reused by bench/tests) */
 int gsdf_reset(gsdf_ctx* c);
+/* The reference's tsdf_ grows without bound (a node hash map, MapGradPixelSdf.h:65-68); this table has a capacity.  gsdf_grow
+ * moves every block into a table of 2^new_capacity_log2 records (synchronous; the map -- voxels, vis_ bit-vectors, frame counter
+ * -- is unchanged, only the room differs; on failure the old table stays).  gsdf_set_auto_grow lets the frame entries
+ * (gsdf_update_dev / gsdf_update / gsdf_track_and_fuse_dev) do that by themselves: the table is doubled when ~45 % of its block
+ * entries are in use (counted on the device every few frames, read without waiting), up to max_capacity_log2; 0 switches it
+ * off, which is the default -- then GSDF_ERR_TABLE_FULL reports a map that outgrew its table, as before. */
+int gsdf_grow(gsdf_ctx* c, int new_capacity_log2);
+int gsdf_set_auto_grow(gsdf_ctx* c, int max_capacity_log2);
 
 /* Sdf::set_zmin / Sdf::set_zmax -- Sdf.h:123-129 (defaults 0.5 / 3.5) */
 int gsdf_set_zrange(gsdf_ctx* c, float zmin, float zmax);

@@ -148,8 +148,17 @@ def test_scan3d_c1_thirty_frames_tracked(pkg, O, tmp_path):
             if conv:
                 conv_o.add(i)
                 o.update(d, O.quat_to_R(pose[3:]), pose[:3])
-        worst = max(worst, float(np.abs(pf[i, 1:4] - pose[:3]).max()), float(np.abs(np.abs(pf[i, 4:8]) - np.abs(pose[3:])).max()))
-    # Gauss-Newton ends within one threshold-sized (1e-3) step of the same point on both sides (see the 4-frame test above)
+        err = max(float(np.abs(pf[i, 1:4] - pose[:3]).max()), float(np.abs(np.abs(pf[i, 4:8]) - np.abs(pose[3:])).max()))
+        if i == 1:
+            # the first tracked frame starts from IDENTICAL state on both sides (frame 0 fused at the identity, pose_ = SE3()):
+            # here the north_star bar applies as it stands
+            assert err < 1e-4, err
+        worst = max(worst, err)
+    # The ACCUMULATED trajectory: from frame 2 on each side tracks against the map its own earlier poses built and starts from
+    # its own previous pose, so a convergence decision that falls differently on one borderline frame (|xi|^2 within rounding
+    # of 1e-6) leaves the two runs one threshold-sized (1e-3) Gauss-Newton step apart from there on.  2e-3 bounds that drift;
+    # every frame of this sequence FROM IDENTICAL STATE is held to 1e-4 in
+    # tests/test_gpu_parity.py::test_c1_every_frame_from_identical_state.
     assert worst < 2e-3, worst
     assert len(conv_cli ^ conv_o) <= 2, (sorted(conv_cli), sorted(conv_o))          # borderline frames may flip
     assert len(conv_o) >= 20
