@@ -943,10 +943,16 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             if ((have >> e) & 1u) k0[e] = a.tab.bkeys[home[e]];                   /* 512 KB of block keys: L2 hits */
         unsigned long long TF = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
         if (pass == 0) GSDF_TRACE(a, tr, 3);                          /* keys unpacked, home-entry loads issued */
-        /* meanwhile one wave waits for the adjacent tiles of lower colour (lane j watches neighbour j) */
-        if (wave == 0 && L.ordered && pass == 0) {
-            bool need = false;
-            const unsigned int* flag = my_flag;
+        /* Meanwhile one wave looks after the adjacent tiles of lower colour (lane j watches neighbour j).  Their flags have
+         * normally been published long ago (they were dispatched a colour earlier), so the first look is only REQUESTED here and
+         * examined behind this wave's own block lookups: the load's round trip (an agent-scope access, ~0.5 us) runs under the
+         * lookups' instead of in front of them -- wave 0 was the wave every flush waited for at the barrier below.  Only when a
+         * flag is not there yet does the wave poll. */
+        bool need = false;
+        const unsigned int* flag = my_flag;
+        unsigned int first_look = 0u;
+        const bool watcher = wave == 0 && L.ordered && pass == 0;
+        if (watcher) {
             if (lane < 8) {
                 const int j = lane < 4 ? lane : lane + 1;             /* 3x3 neighbourhood without the centre */
                 const int nx = tile_x + (j % 3) - 1, ny = tile_y + (j / 3) - 1;
@@ -955,20 +961,9 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
                     flag = a.tile_flags + (size_t)ny * a.ntx + nx;
                 }
             }
-            const unsigned long long t0 = wall_clock64();
-            bool ok = !need;
-            for (;;) {
-                if (!ok) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag;
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(FUSE_POLL_SLEEP);
-                /* 2 ms at 100 MHz: give up, defer instead (the test build can make every wait expire at once) */
-                if (wall_clock64() - t0 > 200000ull || GSDF_EXPERIMENT(a.debug, 8192)) {
-                    if (lane == 0) { L.ordered = 0u; atomicAdd(&a.st->fuse_timeouts, 1u); }
-                    break;
-                }
-            }
+            first_look = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (pass == 0) GSDF_TRACE(a, tr, 4);                          /* neighbours of lower colour have published (wave 0) */
+        if (pass == 0) GSDF_TRACE(a, tr, 4);                          /* (wave 0) the flags are requested */
         {
             /* the blocks of this lane's entries, looked up (and inserted) together: the probe chains overlap */
             int blk[NE];
@@ -981,6 +976,20 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             }
         }
         if (pass == 0) GSDF_TRACE(a, tr, 5);                          /* wave 0: its blocks looked up */
+        if (watcher) {
+            const unsigned long long t0 = wall_clock64();
+            bool ok = !need || first_look == a.tag;
+            for (;;) {
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(FUSE_POLL_SLEEP);
+                /* 2 ms at 100 MHz: give up, defer instead (the test build can make every wait expire at once) */
+                if (wall_clock64() - t0 > 200000ull || GSDF_EXPERIMENT(a.debug, 8192)) {
+                    if (lane == 0) { L.ordered = 0u; atomicAdd(&a.st->fuse_timeouts, 1u); }
+                    break;
+                }
+                if (!ok) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag;
+            }
+        }
         __syncthreads();                                              /* the wait above is over (or timed out) */
         if (pass == 0) GSDF_TRACE(a, tr, 6);                          /* every wave has its blocks */
         if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 0], T - TF); TF = T; }

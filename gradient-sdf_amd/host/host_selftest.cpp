@@ -44,6 +44,22 @@ int main(int argc, char** argv) {
             std::string err;
             CHECK(!png_read_scaled(dir + "/tf.png", fl.data(), W + 1, H, 0.0002f, &err) && err.find("differs") != std::string::npos);
         }
+        /* a corrupt header (width and height patched to 2^31 - 1 / 2^30): rejected by its numbers -- against the caller's frame
+         * size right behind the IHDR, against the allocation bound otherwise -- before anything is sized by them */
+        {
+            CHECK(png_write_gray16(dir + "/bad.png", W, H, px.data()));
+            std::fstream f(dir + "/bad.png", std::ios::in | std::ios::out | std::ios::binary);
+            const unsigned char huge[8] = { 0x7f, 0xff, 0xff, 0xff, 0x40, 0x00, 0x00, 0x00 };
+            f.seekp(16);                                    /* IHDR data: width, height */
+            f.write((const char*)huge, 8);
+            f.close();
+            std::vector<float> fl((size_t)W * H, -1.f);
+            std::string err;
+            CHECK(!png_read_scaled(dir + "/bad.png", fl.data(), W, H, 0.0002f, &err) && err.find("differs") != std::string::npos);
+            PngImage im3;
+            err.clear();
+            CHECK(!png_read(dir + "/bad.png", im3, &err) && err.find("too large") != std::string::npos);
+        }
     }
     {   /* pose file */
         std::ofstream f(dir + "/pose.txt");
