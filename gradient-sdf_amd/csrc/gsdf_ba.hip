@@ -201,7 +201,10 @@ __global__ __launch_bounds__(256) void k_ba_energy(ba_args a, double* block_E) {
 }
 
 /* ---- solveDist ---- */
-__global__ __launch_bounds__(256) void k_ba_dist(ba_args a, float damping) {
+/* block_cnt (nullable): [2][gridDim.x] -- the workgroup's voxels with at least one observation and their observations */
+__global__ __launch_bounds__(256) void k_ba_dist(ba_args a, float damping, double* block_cnt) {
+    __shared__ double red[2][4];
+    unsigned int n_act = 0u, n_obs = 0u;
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x; slot < a.n_slots; slot += stride) {
         ba_voxel v;
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(256) void k_ba_dist(ba_args a, float damping) {
             sDD = gsdf_v3{ sDD.x + Jd.x * Jd.x, sDD.y + Jd.y * Jd.y, sDD.z + Jd.z * Jd.z };
         }
         if (!Nj) continue;
+        n_act += 1u; n_obs += (unsigned int)Nj;
         const float inv_Nj = (float)(1. / (double)(float)Nj);
         float H_dd = gsdf_sum3(sDD.x, sDD.y, sDD.z) - inv_Nj * gsdf_sum3(sD.x * sD.x, sD.y * sD.y, sD.z * sD.z);
         const float b_d = gsdf_sum3(sAD.x, sAD.y, sAD.z) - inv_Nj * gsdf_sum3(sA.x * sD.x, sA.y * sD.y, sA.z * sD.z);
@@ -238,6 +242,13 @@ __global__ __launch_bounds__(256) void k_ba_dist(ba_args a, float damping) {
             gsdf_payload* P = &a.tab.vox[slot];
             P->s = (v.dist - damping * b_d / H_dd) * v.w;
         }
+    }
+    if (block_cnt) {                                                            /* wave-uniform: a kernel argument */
+        double cA = (double)n_act, cO = (double)n_obs;
+        for (int off = 32; off > 0; off >>= 1) { cA += __shfl_down(cA, off); cO += __shfl_down(cO, off); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cA; red[1][threadIdx.x >> 6] = cO; }
+        __syncthreads();
+        if (threadIdx.x < 2) block_cnt[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
     }
 }
 
@@ -347,9 +358,9 @@ void gsdf_launch_ba_energy(hipStream_t s, const gsdf_ba_dev& d, double* block_E)
     ba_args a; std::memcpy(&a, &d, sizeof(a));
     hipLaunchKernelGGL(k_ba_energy, dim3(BA_BLOCKS), dim3(256), 0, s, a, block_E);
 }
-void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping) {
+void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping, double* block_cnt) {
     ba_args a; std::memcpy(&a, &d, sizeof(a));
-    hipLaunchKernelGGL(k_ba_dist, dim3(BA_BLOCKS), dim3(256), 0, s, a, damping);
+    hipLaunchKernelGGL(k_ba_dist, dim3(BA_BLOCKS), dim3(256), 0, s, a, damping, block_cnt);
 }
 void gsdf_launch_ba_pose(hipStream_t s, const gsdf_ba_dev& d, float* block_part, float* out) {
     ba_args a; std::memcpy(&a, &d, sizeof(a));

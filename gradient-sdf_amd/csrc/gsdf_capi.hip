@@ -1031,8 +1031,8 @@ int gsdf_ba_counters(gsdf_ctx* c, int64_t* voxels, int64_t* observations) {
     return GSDF_OK;
 }
 
-static int ba_dist_enqueue(gsdf_ctx* c, float damping) {
-    gsdf_launch_ba_dist(c->stream, ba_dev(c), damping);
+static int ba_dist_enqueue(gsdf_ctx* c, float damping, double* block_cnt = nullptr) {
+    gsdf_launch_ba_dist(c->stream, ba_dev(c), damping, block_cnt);
     c->ba_gate_fresh = false;                                 /* the distances moved: voxels may have crossed the gate */
     HIP_TRY(hipGetLastError());
     return GSDF_OK;
@@ -1042,8 +1042,15 @@ int gsdf_ba_solve_dist(gsdf_ctx* c, float damping) {
     int rc = ba_require(c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    if ((rc = ba_dist_enqueue(c, damping))) return rc;
+    /* the stand-alone entry also counts what the sweep visited (gsdf_ba_counters); gsdf_ba_optimize's sweeps do not */
+    double* cnt = c->ba_block_E + (size_t)3 * gsdf_ba_blocks();
+    if ((rc = ba_dist_enqueue(c, damping, cnt))) return rc;
+    std::vector<double> h((size_t)2 * gsdf_ba_blocks());
+    HIP_TRY(hipMemcpyAsync(h.data(), cnt, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    double a = 0.0, o = 0.0;
+    for (size_t i = 0; i < (size_t)gsdf_ba_blocks(); ++i) { a += h[i]; o += h[(size_t)gsdf_ba_blocks() + i]; }
+    c->ba_last_voxels = (long long)a; c->ba_last_obs = (long long)o;
     return GSDF_OK;
 }
 

@@ -206,7 +206,7 @@ struct gsdf_ba_dev {
  * *tmp_bytes is set) */
 hipError_t gsdf_ba_compact(hipStream_t s, const gsdf_ba_dev& d, uint32_t* list_out, unsigned long long* count_out, void* tmp, size_t* tmp_bytes);
 void gsdf_launch_ba_energy(hipStream_t s, const gsdf_ba_dev& d, double* block_E);
-void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping);
+void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping, double* block_cnt /* nullable: [2][gsdf_ba_blocks()] voxels, observations */);
 void gsdf_launch_ba_pose(hipStream_t s, const gsdf_ba_dev& d, float* block_part, float* out);
 int  gsdf_ba_blocks(void);
 

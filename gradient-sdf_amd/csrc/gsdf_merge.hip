@@ -232,9 +232,9 @@ int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes
     if (c->merged && tr.nranks > 1)
         return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: this map already holds the sum of all ranks (the exchange is one-shot: "
                                            "a second one would count every rank's frames again); gsdf_reset starts over");
-    const size_t cap = c->n_slots / GSDF_BLOCK_VOX;
+    size_t cap = c->n_slots / GSDF_BLOCK_VOX;
     const int R = tr.nranks;
-    const size_t n_all = cap * (size_t)R;
+    size_t n_all = cap * (size_t)R;
     /* two small buffers are needed to talk at all: without them this rank cannot even report its failure */
     if (int rc = mx_ensure(c, MX_HDR, (size_t)(R + 1) * sizeof(merge_hdr), false)) return rc;
     if (int rc = mx_ensure(c, MX_AGREE, (size_t)(R + 1) * sizeof(long long), false)) return rc;
@@ -275,10 +275,7 @@ int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes
     for (int r = 0; r < R; ++r) {
         const merge_hdr& h = hdr[(size_t)r];
         if (h.err) return gsdf_fail((int)h.err, "gsdf_merge_allreduce: rank " + std::to_string(r) + " failed to prepare its buffers");
-        if (h.cap_blocks != (long long)cap)
-            return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: rank " + std::to_string(r) + " was created with another capacity_log2 "
-                                               "(the ranks exchange their block-key arrays: equal capacities required)");
-        if (h.frames < 0 || h.dense_blocks < 0)
+        if (h.cap_blocks <= 0 || (h.cap_blocks & (h.cap_blocks - 1)) || h.cap_blocks > (1ll << 24) || h.frames < 0 || h.dense_blocks < 0)
             return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: inconsistent header from rank " + std::to_string(r));
         if (h.vis_words != hdr[0].vis_words)
             return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: gsdf_enable_vis must be called with the same frame count on every rank (or on none)");
@@ -293,6 +290,27 @@ int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes
     if (vw && frames_total > 32ll * vw)
         return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: the ranks integrated " + std::to_string(frames_total) +
                                            " frames, gsdf_enable_vis reserved " + std::to_string(32ll * vw) + " bits per voxel");
+    /* The ranks exchange their block-key ARRAYS, so the tables must be of one size.  They usually are; where they are not (one
+     * rank's table grew during its scan: gsdf_set_auto_grow), the smaller ones grow to the largest capacity first -- every rank
+     * knows from the headers that this happens, and they meet once more to agree that it worked. */
+    long long cap_max = 0;
+    bool any_grow = false;
+    for (int r = 0; r < R; ++r) { cap_max = std::max(cap_max, hdr[(size_t)r].cap_blocks); any_grow |= hdr[(size_t)r].cap_blocks != hdr[0].cap_blocks; }
+    if (any_grow) {
+        int grc = GSDF_OK;
+        if ((long long)cap < cap_max) {
+            int lg = 0;
+            while (((size_t)1 << lg) < (size_t)cap_max * GSDF_BLOCK_VOX) ++lg;
+            grc = gsdf_grow_impl(c, lg);
+        }
+        if (!grc) {
+            cap = c->n_slots / GSDF_BLOCK_VOX;
+            n_all = cap * (size_t)R;
+            grc = prepare();
+        }
+        rc = agree(c, tr, grc, "grow its table to the largest rank's capacity");
+        if (rc) return rc;
+    }
     /* 2. the ranks' key arrays -> sorted union, on the device */
     unsigned long long* keys_all = (unsigned long long*)c->mx[MX_KEYS_ALL].p;
     unsigned long long* sorted = (unsigned long long*)c->mx[MX_SORTED].p;

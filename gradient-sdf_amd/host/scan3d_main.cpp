@@ -345,9 +345,7 @@ int run(int, char**, Options& opt) {
         Exchange ex;
         if (sharded && !exchange_prepare(ex, opt, opt.device)) return 1;
         T.tic();
-        /* frame shards over several ranks exchange their block-key arrays: every rank keeps the capacity it was started with */
-        tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device,
-                                       sharded ? opt.capacity_log2 : std::max(opt.capacity_log2, opt.max_capacity_log2)));
+        tSDF.reset(new MapGradPixelSdf(opt.voxel_size, truncation, opt.capacity_log2, opt.device, std::max(opt.capacity_log2, opt.max_capacity_log2)));
         if (lead) T.toc("Create Sdf");
         tSDF->prepare(opt.width, opt.height, K, &NEst);
         gsdf_ctx* ctx = tSDF->handle();

@@ -166,9 +166,10 @@ int gsdf_ba_solve_pose(gsdf_ctx* c, float damping);
 int gsdf_ba_solve_dist(gsdf_ctx* c, float damping);
 int gsdf_ba_optimize(gsdf_ctx* c, int max_it, float* energies, int* n_energies, int* converged);
 int gsdf_ba_get_poses(gsdf_ctx* c, float* poses16_host);
-/* what the last energy sweep whose result reached the host counted: voxels that took part (|dist| <= voxel size, :285, seen by
- * at least one keyframe) and observations (voxel x keyframe pairs that project into the image, :238-260) -- the units of the
- * sweeps' algorithmic bytes (measurement only; the reference has no counterpart) */
+/* what the last gsdf_ba_energy / gsdf_ba_solve_dist call (or the last energy sweep of gsdf_ba_optimize) counted: voxels that took
+ * part (energy: |dist| <= voxel size, :285, seen by at least one keyframe; distance sweep: every voxel with an observation) and
+ * observations (voxel x keyframe pairs that project into the image, :238-260) -- the units of the sweeps' algorithmic bytes
+ * (measurement only; the reference has no counterpart) */
 int gsdf_ba_counters(gsdf_ctx* c, int64_t* voxels, int64_t* observations);
 
 /* additive merge of raw sums into this table (frame-sharded fusion) */
@@ -193,8 +194,8 @@ int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t 
 /* The exchange step as ONE call, for C++ hosts (BASELINE.json north_star: "frames shard naturally across the
  * 8 GPUs of one node with a RCCL-over-xGMI all-reduce of per-voxel (weight, weighted-distance, weighted-gradient) before
  * mesh extraction").  Collective: every rank of the communicator calls it with the map it fused from its own frames (the
- * GT-pose branch, main_scan_3d.cpp:250-254; all contexts created with the SAME capacity_log2); on return every rank's map is
- * the sum of all maps.  Steps: all-gather of the block-key arrays, sorted union on the device, gsdf pack, ONE ncclAllReduce (sum, float32, 1280 B per block of the union) on the context's own
+ * GT-pose branch, main_scan_3d.cpp:250-254); on return every rank's map is the sum of all maps (and every rank's table has the
+ * capacity of the largest one: ranks whose tables are smaller grow first, gsdf_grow).  Steps: all-gather of the block-key arrays, sorted union on the device, gsdf pack, ONE ncclAllReduce (sum, float32, 1280 B per block of the union) on the context's own
  * stream, gsdf unpack.  nccl_comm: an ncclComm_t of the RCCL already in the process (RCCL is resolved at run time, it is
  * not a link dependency of libgsdf.so).  n_blocks / bytes (nullable): size of the union / of the all-reduced buffers.
  * Also exchanged: Sdf::counter_ (Sdf.h:65) -- afterwards the frames integrated by ALL ranks -- and, when gsdf_enable_vis was

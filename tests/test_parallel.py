@@ -117,7 +117,8 @@ def _gpu_worker(rank, world, port, out_dir):
     W, H, n = 320, 240, 8
     seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=9, step_deg=3.0)
     vs = np.float32(0.02)
-    g = pkg.GradSdf(vs, np.float32(5) * vs, W, H, seq.K, capacity_log2=20, device=0)
+    # (rank 1's table is twice the size of rank 0's -- as if it had grown during its scan: the exchange brings rank 0's up first)
+    g = pkg.GradSdf(vs, np.float32(5) * vs, W, H, seq.K, capacity_log2=20 + rank, device=0)
     g.enable_vis(40)                                     # vis_ takes part in the exchange (bits = frames of ALL ranks)
     lo, hi = pkg.parallel.shard_range(n, rank, world)
     for i in range(lo, hi):

@@ -66,9 +66,10 @@ def main():
     t_pose = med(g.ba_solve_pose, 1)              # (moves the poses: once, then restored by the next setup)
     g.ba_setup(imgs, Pp, kf)
     t_dist = med(g.ba_solve_dist, 1)
+    act_d, obs_d = g.ba_counters()                # the distance sweep has no |dist| gate: every voxel with an observation
     b_energy = 32.0 * n_vox + 4.0 * vw * act + 48.0 * obs
     b_pose = b_energy + 96.0 * obs
-    b_dist = 32.0 * n_vox + 4.0 * vw * n_vox + 144.0 * obs + 4.0 * n_vox
+    b_dist = 32.0 * n_vox + 4.0 * vw * n_vox + 144.0 * obs_d + 4.0 * act_d
     out["sweeps"] = {
         "voxels_taking_part": act, "observations": obs, "observations_per_voxel": round(obs / max(act, 1), 2),
         "energy": {"ms": round(t_energy * 1e3, 3), "algorithmic_bytes": round(b_energy), "achieved_GBs": round(b_energy / t_energy / 1e9, 1),
@@ -76,7 +77,9 @@ def main():
         "pose": {"ms": round(t_pose * 1e3, 3), "algorithmic_bytes": round(b_pose), "achieved_GBs": round(b_pose / t_pose / 1e9, 1),
                  "frac_of_hbm_peak": round(b_pose / t_pose / 1e9 / HBM_PEAK_GBS, 4), "note": "incl. the 50 6x6 host solves and the pose upload"},
         "dist": {"ms": round(t_dist * 1e3, 3), "algorithmic_bytes": round(b_dist), "achieved_GBs": round(b_dist / t_dist / 1e9, 1),
-                 "frac_of_hbm_peak": round(b_dist / t_dist / 1e9 / HBM_PEAK_GBS, 4), "note": "all voxels (no |dist| gate, :326-388)"},
+                 "frac_of_hbm_peak": round(b_dist / t_dist / 1e9 / HBM_PEAK_GBS, 4), "voxels_taking_part": act_d, "observations": obs_d,
+                 "note": "all voxels (no |dist| gate, :326-388); its 144 B per observation are served by the caches for the most part (neighbouring voxels "
+                         "sample neighbouring pixels of the same 50 images, 184 MB): the figure is an L2-side rate, not HBM traffic"},
     }
     # ---- optimize() end to end, from the perturbed poses on the fused map ----
     g.reset()

@@ -50,9 +50,10 @@ for p in range(12):
     print(line)
     if (rows[:, 4] > 0).any():                 # head in parts: sums + state arrived | solved | pose handed to the other waves
         m = rows[:, 4] > 0
-        line2 = "          head: sums and state arrive after %.2f, solve %.2f, hand-over %.2f" % (
-            np.median((rows[m, 4] - rows[m, 0]) / 100.0), np.median((rows[m, 5] - rows[m, 4]) / 100.0) if (rows[m, 5] > 0).all() else -1,
-            np.median((rows[m, 1] - np.maximum(rows[m, 5], rows[m, 4])) / 100.0))
+        ho = rows[m, 1] > 0                      # a head-only launch (optimize() ended in this head) has no hand-over to a gather
+        line2 = "          head: sums and state arrive after %.2f, solve %.2f" % (
+            np.median((rows[m, 4] - rows[m, 0]) / 100.0), np.median((rows[m, 5] - rows[m, 4]) / 100.0) if (rows[m, 5] > 0).all() else -1)
+        line2 += ", hand-over %.2f" % np.median((rows[m, 1][ho] - np.maximum(rows[m, 5], rows[m, 4])[ho]) / 100.0) if ho.any() else " (head-only launch: optimize() ended here)"
         if has_g.any():
             line2 += " | tail: wave 0's sums %.2f, waits %.2f for the slowest wave, workgroup sum + atomics issued %.2f; ends %.2f after the first workgroup's end" % (
                 np.median((rows[has_g, 6] - rows[has_g, 2]) / 100.0), np.median((rows[has_g, 7] - rows[has_g, 6]) / 100.0),
