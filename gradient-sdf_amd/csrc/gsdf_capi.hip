@@ -995,7 +995,7 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
     return ba_upload_poses(c);
 }
 
-/* the energy sweep enqueued into set `which` of the per-workgroup sums; ba_energy_read adds a set up in the fixed order */
+/* the energy sweep enqueued into set `which` of the per-workgroup sums; ba_energy_sum adds a set up in the fixed order */
 static int ba_energy_enqueue(gsdf_ctx* c, int which) {
     ba_refresh_gate(c);
     gsdf_launch_ba_energy(c->stream, ba_dev(c), c->ba_block_E + (size_t)which * 3 * gsdf_ba_blocks());
