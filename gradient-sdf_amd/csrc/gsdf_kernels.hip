@@ -330,8 +330,12 @@ static_assert(FUSE_TH % 4 == 0 && FUSE_TH >= 8 && FUSE_TH <= 32, "tile height");
  *         geometry 68 -> 63 us, of near scenes 62 -> 63 us (the bigger table clear competes with the CU's other walk).
  * The host picks per launch from what the previous fusions reported (tiles that did not fit the small table). */
 #define FUSE_LCAP LCAP
+#ifndef FUSE_LCAP_NEAR
 #define FUSE_LCAP_NEAR 2048
+#endif
+#ifndef FUSE_LCAP_FAR
 #define FUSE_LCAP_FAR 2560
+#endif
 #ifndef FUSE_POLL_SLEEP
 #define FUSE_POLL_SLEEP 8                  /* x 64 cycles between two looks at the neighbours' flags */
 #endif
@@ -343,8 +347,8 @@ static_assert(FUSE_TH % 4 == 0 && FUSE_TH >= 8 && FUSE_TH <= 32, "tile height");
 #define FUSE_NB (FUSE_LCAP / FUSE_BSLOTS)
 /* A tile whose voxels fit uses only the first FUSE_LCAP_SMALL entries (512 buckets: the bucket index is a mask, and the flush
  * has a slot less per lane to look at); the full table is for far tiles, which would otherwise be walked in two bands */
-#define FUSE_LCAP_SMALL 2048
-#define FUSE_DUAL (FUSE_LCAP == 2560 && FUSE_BSLOTS == 4)
+#define FUSE_LCAP_SMALL FUSE_LCAP_NEAR
+#define FUSE_DUAL (FUSE_LCAP == FUSE_LCAP_FAR && FUSE_LCAP_FAR != FUSE_LCAP_NEAR && FUSE_BSLOTS == 4)
 #define FUSE_LKEY_EMPTY 0xFFFFFFFFu      /* LDS keys are 32-bit: voxel coordinates relative to the tile origin, 10 bits each */
 #define FUSE_LKEY_DEFER 0x80000000u      /* flush: the entry goes to the deferred list, low 31 bits = voxel record index */
 #define FUSE_LPROBE (48 / FUSE_BSLOTS)   /* buckets probed before a sample takes the deferred route */
@@ -423,6 +427,9 @@ struct fuse_args {
 };
 #define FUSE_RESOLVE_INLINE 8192u       /* deferred entries the last workgroup adds itself even when a resolve launch follows */
 
+/* workgroups of fewer than 512 threads (8-row tiles, a build experiment) cannot take the normals role: the launcher then
+ * computes the next frame's normals with k_normals in front of the fusion */
+#define FUSE_CARRIES_NORMALS (FUSE_THREADS >= NRM_TX * NRM_TY)
 template <int LCAP>
 struct fuse_lds {
     uint32_t key[FUSE_LCAP] __attribute__((aligned(16)));
@@ -526,12 +533,14 @@ template <int LCAP, bool NEXT_NORMALS>
 __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     __shared__ fuse_lds<LCAP> L;
     const int tid = threadIdx.x;
-    if (NEXT_NORMALS && (int)blockIdx.x >= a.n_tiles) {       /* the next frame's normals, in the tail of this launch */
+    if constexpr (NEXT_NORMALS && FUSE_CARRIES_NORMALS) {
+    if ((int)blockIdx.x >= a.n_tiles) {                       /* the next frame's normals, in the tail of this launch */
         static_assert(sizeof(nrm_lds) <= sizeof(fuse_lds<LCAP>), "the normals tile works in the fusion table's LDS");
         const int t = (int)blockIdx.x - a.n_tiles;
         normals_tile<FUSE_THREADS>(*reinterpret_cast<nrm_lds*>(&L), t % a.nrm_ntx, t / a.nrm_ntx, a.g.W, a.g.H, a.nrm_r, a.nc, a.nrm_depth, a.nrm_x,
                      a.nrm_y, a.nrm_z);
         return;
+    }
     }
     /* main_scan_3d.cpp:261: if (conv) update.  The launch may have been queued before optimize() ended (the host
      * issues it behind every batch of passes): it runs only once the pose iteration is done AND converged; the
@@ -812,7 +821,8 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
              * (best 3-D lattice for this modulus, found by search), so buckets fill evenly, rarely
              * overflow, and the distinct voxels of one wave instruction never compete for a bucket: counted on
              * tiles of the bench stream, 1.004 probes per sample.  (The HBM table keeps the full 64-bit finaliser.) */
-            static_assert((FUSE_BSLOTS == 2 && FUSE_NB == 1024) || (FUSE_BSLOTS == 4 && (FUSE_NB == 512 || FUSE_NB == 480 || FUSE_NB == 640)), "lattice constants exist for 1024 x 2, 512 x 4, 480 x 4 and 640 x 4");
+            static_assert((FUSE_BSLOTS == 2 && FUSE_NB == 1024) || (FUSE_BSLOTS == 4 && (FUSE_NB == 512 || FUSE_NB == 480 || FUSE_NB == 640 || FUSE_NB == 256 || FUSE_NB == 320)),
+                          "lattice constants exist for 1024 x 2, 512 x 4, 480 x 4, 640 x 4 (16-row tiles) and 256 x 4, 320 x 4 (8-row tiles)");
             uint32_t bk;
             if (FUSE_BSLOTS == 2) bk = gsdf_mad_u24(lz3, 75u, gsdf_mad_u24(ly3, 86u, lx3)) & 1023u;
             else if (FUSE_NB == 640 && (big || !FUSE_DUAL)) {          /* x + 253 y + 541 z (mod 640): min distance 9.3; 1.000 probes per sample on the densest tiles */
@@ -820,11 +830,17 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
                 bk = hx - 640u * __umulhi(hx, 6710887u);                /* exact for hx < 2^21 */
                 bk = bk < 640u ? bk : 0u;                               /* keys outside the local range: any bucket, never used */
             }
+            else if (FUSE_NB == 320 && (big || !FUSE_DUAL)) {          /* x + 299 y + 271 z (mod 320): min distance 7.3 (8-row tiles, far) */
+                const uint32_t hx = gsdf_mad_u24(lz3, 271u, gsdf_mad_u24(ly3, 299u, lx3));         /* < 2^20 for local keys */
+                bk = hx - 320u * __umulhi(hx, 13421773u);               /* exact for hx < 2^25 */
+                bk = bk < 320u ? bk : 0u;
+            }
             else if (FUSE_NB == 480) {                                 /* x + 313 y + 195 z (mod 480): min distance 8.1; 1.12 probes per sample on the densest tiles */
                 const uint32_t hx = gsdf_mad_u24(lz3, 195u, gsdf_mad_u24(ly3, 313u, lx3));         /* < 2^20 for local keys */
                 bk = hx - 480u * __umulhi(hx, 8947849u);                /* exact for hx < 2^20 */
                 bk = bk < 480u ? bk : 0u;                               /* keys outside the local range: any bucket, never used */
             }
+            else if (FUSE_LCAP_SMALL == 1024) bk = gsdf_mad_u24(lz3, 73u, gsdf_mad_u24(ly3, 136u, lx3)) & 255u;   /* x + 136 y + 73 z (mod 256): min distance 6.9 (8-row tiles) */
             else bk = gsdf_mad_u24(lz3, 143u, gsdf_mad_u24(ly3, 98u, lx3)) & 511u;
             /* 2.-4. look the voxel up in the LDS table: one read per bucket; the first slot that holds the key or is empty
              *    decides (used slots are a prefix: entries are never removed and inserts take the first empty slot), at
@@ -1201,7 +1217,11 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     a.n_tiles = n;
     a.nrm_depth = next_depth; a.nrm_x = next_nx; a.nrm_y = next_ny; a.nrm_z = next_nz;
     a.nrm_r = win / 2; a.nrm_ntx = (g.W + NRM_TX - 1) / NRM_TX;
-    const int extra = next_depth ? a.nrm_ntx * ((g.H + NRM_TY - 1) / NRM_TY) : 0;
+    int extra = next_depth ? a.nrm_ntx * ((g.H + NRM_TY - 1) / NRM_TY) : 0;
+    if (extra && !FUSE_CARRIES_NORMALS) {
+        gsdf_launch_normals(s, g, win, nc, next_depth, next_nx, next_ny, next_nz, nullptr, nullptr);
+        extra = 0;
+    }
     if (extra) {
         if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
         else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
