@@ -125,6 +125,7 @@ def load(path=None):
         "gsdf_ba_optimize": (C.c_int, [vp, C.c_int, fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "gsdf_ba_get_poses": (C.c_int, [vp, fp]),
         "gsdf_ba_counters": (C.c_int, [vp, i64p, i64p]),
+        "gsdf_merge_prepare": (C.c_int, [vp, C.c_int]),
         "gsdf_grow": (C.c_int, [vp, C.c_int]),
         "gsdf_set_auto_grow": (C.c_int, [vp, C.c_int]),
         "gsdf_merge_raw": (C.c_int, [vp, i32p, fp, C.c_int64]),
@@ -164,6 +165,8 @@ def load(path=None):
         "gsdf_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), i64p]),
     }
     for name, (res, args) in sig.items():
+        if os.environ.get("GSDF_LIB_OLD") and not hasattr(L, name):
+            continue                   # tools only: an older build of the library under A/B (GSDF_LIB=..., GSDF_LIB_OLD=1)
         f = getattr(L, name)       # AttributeError if the .so does not export a declared symbol
         f.restype = res
         f.argtypes = args
@@ -176,7 +179,7 @@ ABI_SYMBOLS = [
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
     "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
-    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow",
+    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow", "gsdf_merge_prepare",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
     "gsdf_merge_allreduce", "gsdf_merge_allreduce_with", "gsdf_rccl_unique_id", "gsdf_rccl_comm_init", "gsdf_rccl_comm_count",
@@ -406,6 +409,9 @@ class GradSdf:
         ne, conv = C.c_int(0), C.c_int(0)
         self._chk(self.L.gsdf_ba_optimize(self.h, int(max_it), _fp(e), C.byref(ne), C.byref(conv)))
         return bool(conv.value), e[:ne.value]
+
+    def merge_prepare(self, nranks):
+        self._chk(self.L.gsdf_merge_prepare(self.h, int(nranks)))
 
     def grow(self, new_capacity_log2):
         self._chk(self.L.gsdf_grow(self.h, int(new_capacity_log2)))

@@ -502,6 +502,40 @@ int gsdf_rccl_comm_destroy(void* comm) {
 
 int gsdf_grow(gsdf_ctx* c, int new_capacity_log2) { return gsdf_grow_impl(c, new_capacity_log2); }
 
+/* Set-up of the exchange that does not depend on the other ranks' data, for hosts that keep it out of a timed region (like the
+ * communicator): the scratch sized by (ranks, capacity), the pack buffers for twice the blocks this map holds now, and one run of
+ * the sort / unique kernels (their code is loaded on first use: ~10 ms).  Optional -- the exchange does all of it itself. */
+int gsdf_merge_prepare(gsdf_ctx* c, int nranks) {
+    if (!c || nranks < 1) return gsdf_fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t cap = c->n_slots / GSDF_BLOCK_VOX, n_all = cap * (size_t)nranks;
+    if (int rc = mx_ensure(c, MX_HDR, (size_t)(nranks + 1) * sizeof(merge_hdr), false)) return rc;
+    if (int rc = mx_ensure(c, MX_AGREE, (size_t)(nranks + 1) * sizeof(long long), false)) return rc;
+    if (int rc = mx_ensure(c, MX_KEYS_ALL, n_all * sizeof(unsigned long long), false)) return rc;
+    if (int rc = mx_ensure(c, MX_SORTED, n_all * sizeof(unsigned long long), false)) return rc;
+    if (int rc = mx_ensure(c, MX_UNION, n_all * sizeof(unsigned long long), false)) return rc;
+    size_t tmp_sort = 0, tmp_uniq = 0;
+    HIP_TRY(gsdf_sort_keys_u64(nullptr, &tmp_sort, nullptr, nullptr, n_all, c->stream));
+    HIP_TRY(gsdf_unique_u64(nullptr, &tmp_uniq, nullptr, nullptr, nullptr, n_all, c->stream));
+    if (int rc = mx_ensure(c, MX_TMP, std::max(tmp_sort, tmp_uniq), false)) return rc;
+    /* one run on this map's own keys (the other ranks' parts of the buffer: empty entries) */
+    unsigned long long* keys_all = (unsigned long long*)c->mx[MX_KEYS_ALL].p;
+    HIP_TRY(hipMemsetAsync(keys_all, 0xFF, n_all * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipMemcpyAsync(keys_all, c->tab.bkeys, cap * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+    size_t tb = c->mx[MX_TMP].bytes;
+    HIP_TRY(gsdf_sort_keys_u64(c->mx[MX_TMP].p, &tb, keys_all, (unsigned long long*)c->mx[MX_SORTED].p, n_all, c->stream));
+    tb = c->mx[MX_TMP].bytes;
+    HIP_TRY(gsdf_unique_u64(c->mx[MX_TMP].p, &tb, (unsigned long long*)c->mx[MX_SORTED].p, (unsigned long long*)c->mx[MX_UNION].p, c->counter, n_all, c->stream));
+    hipLaunchKernelGGL(k_union_size, dim3(1), dim3(64), 0, c->stream, (unsigned long long*)c->mx[MX_UNION].p, c->counter);
+    unsigned long long n_mine = 0;
+    HIP_TRY(hipMemcpyAsync(&n_mine, c->counter, sizeof(n_mine), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t guess = std::min<size_t>(cap, std::max<size_t>(2 * (size_t)n_mine, 1024));
+    if (int rc = mx_ensure(c, MX_DENSE, guess * GSDF_BLOCK_VOX * 5 * sizeof(float), false)) return rc;
+    if (c->vis) if (int rc = mx_ensure(c, MX_VIS, guess * GSDF_BLOCK_VOX * (size_t)c->vis_words * sizeof(uint32_t), false)) return rc;
+    return GSDF_OK;
+}
+
 int gsdf_merge_allreduce(gsdf_ctx* c, void* nccl_comm, int64_t* n_blocks, int64_t* bytes) {
     if (!c || !nccl_comm) return gsdf_fail(GSDF_ERR_INVALID, "null argument");
     if (!rccl().ok) return gsdf_fail(GSDF_ERR_INVALID, rccl().why);

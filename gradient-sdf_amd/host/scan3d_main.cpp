@@ -349,6 +349,7 @@ int run(int, char**, Options& opt) {
         if (lead) T.toc("Create Sdf");
         tSDF->prepare(opt.width, opt.height, K, &NEst);
         gsdf_ctx* ctx = tSDF->handle();
+        if (sharded) (void)gsdf_merge_prepare(ctx, opt.gpus);         /* the exchange's scratch and sort kernels: set-up, like the communicator */
         T.tic();
         pOpt.reset(new RigidPointOptimizer(tSDF.get()));
         if (lead) T.toc("Create RigidOptimizer");

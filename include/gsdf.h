@@ -206,6 +206,10 @@ int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t 
  * until gsdf_reset.  Failures are collective: a rank that cannot prepare its part reports that through the first all-gather
  * and every rank returns the error, none is left waiting inside a collective. */
 int gsdf_merge_allreduce(gsdf_ctx* c, void* nccl_comm, int64_t* n_blocks, int64_t* bytes);
+/* Optional set-up of the exchange outside a timed region (like the communicator): the scratch buffers for `nranks` ranks and one
+ * run of the union's sort kernels, whose code is loaded on first use (~10 ms in the first exchange of a process otherwise).
+ * Not collective. */
+int gsdf_merge_prepare(gsdf_ctx* c, int nranks);
 /* communicator plumbing for hosts that do not link RCCL themselves (the Scan3D CLI): ncclGetUniqueId / ncclCommInitRank
  * (on `device`) / ncclCommDestroy.  Create the communicator once, outside any timed region. */
 int gsdf_rccl_unique_id(char id128[128]);

@@ -221,3 +221,86 @@ def test_second_statement_of_the_first_tracker_pass(pkg, O):
     assert np.array_equal(mine.view(np.uint32), tr[:28].view(np.uint32))           # E, g, H: the same bits
     xi = np.linalg.solve(np.array(Hm, np.float64), np.array(g, np.float64))        # H.llt().solve(g), in double
     assert np.abs(xi - tr[29:35]).max() <= 1e-3 * np.abs(xi).max()                 # (the float LLT of a 6x6 with condition ~1e4)
+
+
+# ---- PhotoBA: getEnergy, written once more from ps_optimizer/PhotometricOptimizer.cpp:57-77 (interpolateImage), :236-260
+# ---- (getIntensity), :273-321 (getEnergy) ---------------------------------------------------------------------------------
+
+def interpolate_image(m, n, img):
+    """interpolateImage(m, n, img): m indexes ROWS, n COLUMNS (the caller passes (n, m)); weights mix double and float, every
+    term is rounded to float (cv::Vec3f * double), the four terms are added left to right; BGR -> RGB"""
+    x, y = int(math.floor(float(m))), int(math.floor(float(n)))
+    H, W = img.shape[:2]
+    if (x + 1) < H and (y + 1) < W:
+        w1 = (y + 1.0 - float(n)) * float(f32(m - f32(x))); w2 = (y + 1.0 - float(n)) * (x + 1.0 - float(m))
+        w3 = float(f32(f32(n - f32(y)) * f32(m - f32(x))))            # float * float: the product is rounded to float (the others are double)
+        w4 = float(f32(n - f32(y))) * (x + 1.0 - float(m))
+        t = [f32(f32(f32(f32(w1 * float(img[x + 1, y, k])) + f32(w2 * float(img[x, y, k]))) + f32(w3 * float(img[x + 1, y + 1, k]))) +
+                 f32(w4 * float(img[x, y + 1, k]))) for k in range(3)]
+    elif (y + 1) < W and x >= H:
+        t = [f32(f32((y + 1.0 - float(n)) * float(img[x, y, k])) + f32(float(f32(n - f32(y))) * float(img[x, y + 1, k]))) for k in range(3)]
+    elif y >= W and (x + 1) < H:
+        t = [f32(f32(float(f32(m - f32(x))) * float(img[x + 1, y, k])) + f32((x + 1.0 - float(m)) * float(img[x, y, k]))) for k in range(3)]
+    else:
+        t = [img[min(x, H - 1), min(y, W - 1), k] for k in range(3)]     # (the reference indexes out of bounds here; cannot happen behind getIntensity's test)
+    return [t[2], t[1], t[0]]
+
+
+def get_energy(keys, pay, vis, K, vs, images, poses, frame_idx):
+    """PhotometricOptimizer::getEnergy as a double sum of its float terms (the reference adds them into one float in hash-map
+    order, which leaves its own value uncertain at 1e-3: the oracle offers this order-free sum as gsdfo_ba_energy_f64)"""
+    K = K.astype(np.float32); vs = f32(vs)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    Himg, Wimg = images[0].shape[:2]
+    E = 0.0
+    n_obs = 0
+    for (kx, ky, kz), p, vw in zip(keys, pay, vis):
+        dist, grad = p[0], [p[1], p[2], p[3]]
+        if abs(float(dist)) > float(vs):                                                   # :285
+            continue
+        gn = normalized(grad)
+        c = [f32(vs * f32(int(kx))), f32(vs * f32(int(ky))), f32(vs * f32(int(kz)))]
+        A = []
+        for i, f in enumerate(frame_idx):
+            if not (int(vw[f >> 5]) >> (f & 31)) & 1:                                     # :293
+                continue
+            R = poses[i][:3, :3].astype(np.float32); t = poses[i][:3, 3].astype(np.float32)
+            d = [f32(f32(c[j] - f32(dist * gn[j])) - t[j]) for j in range(3)]              # :247
+            pt = [sum3(R[0, j] * d[0], R[1, j] * d[1], R[2, j] * d[2]) for j in range(3)]  # Rt * d
+            z_inv = f32(1.0 / float(pt[2]))
+            m = f32(f32(f32(fx * pt[0]) * z_inv) + cx); n = f32(f32(f32(fy * pt[1]) * z_inv) + cy)
+            if m < 0 or m >= Wimg or n < 0 or n >= Himg:                                   # :253
+                continue
+            A.append(interpolate_image(n, m, images[i]))                                   # :257: (n, m)
+        if not A:
+            continue
+        n_obs += len(A)
+        mean = [f32(0)] * 3
+        for a in A:
+            mean = [f32(mean[j] + a[j]) for j in range(3)]
+        inv = f32(1.0 / float(f32(len(A))))
+        mean = [f32(inv * mean[j]) for j in range(3)]
+        for a in A:
+            r = [f32(a[j] - mean[j]) for j in range(3)]
+            E += float(sum3(r[0] * r[0], r[1] * r[1], r[2] * r[2]))                        # :316
+    return E, n_obs
+
+
+def test_second_statement_of_the_photoba_energy(pkg, O):
+    W, H, n = 48, 36, 4
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=5, noise=False)
+    vs = np.float32(0.04); T = np.float32(5) * vs
+    o = O.Oracle(vs, T, W, H, seq.K)
+    for i in range(n):
+        o.update(*seq.frame(i))
+    imgs = np.stack([pkg.synth.render_color_bgr(seq, i) for i in range(n)])
+    P = np.stack([pkg.synth.pose16(*seq.pose(i)) for i in range(n)])
+    P[1:, :3, 3] += np.float32(0.01)                                 # poses off their truth: the energy is far from its minimum
+    idx = np.arange(n)
+    keys, pay = o.export()
+    vis = o.export_vis(1)
+    E2, n_obs = get_energy(keys, pay, vis, seq.K, vs, imgs, P, idx)
+    ba = O.PhotoBA(o, imgs, P, idx)
+    E_o = ba.energy_f64()
+    assert n_obs > 1000 and E2 > 0
+    assert abs(E2 - E_o) <= 1e-9 * E_o                               # the same float terms, summed in double in two orders

@@ -6,7 +6,7 @@ sums) lists + additive merge) -- then the marching-cubes export on the device.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/run_c4.py --frames 2000
 
 One process per GPU; with N = 1 the exchange is skipped.  Prints one JSON line on rank 0."""
-import argparse, ctypes, json, os, sys, time
+import argparse, ctypes, gc, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,16 +37,39 @@ def main():
     lo, hi = pkg.parallel.shard_range(args.frames, rank, world)
     g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=23, device=local)
     chunk, t_fuse = 64, 0.0
+    # 64 staging buffers, allocated ONCE and refilled chunk by chunk.  (Allocating and freeing them per chunk -- what this tool
+    # did until round 4 -- makes every other chunk take 15-30 ms instead of 2.7 with the libraries built since the exchange
+    # links rocPRIM's select / sort: the stall is on the device side of the first synchronisation after the re-allocation, with
+    # no fusion time-outs or deferred entries; the round-3 library does not show it, buffers that stay do not either.)
+    nbytes = W * H * 4
+    slots = []
+    for _ in range(chunk):
+        p = ctypes.c_void_p()
+        g._chk(g.L.gsdf_dev_alloc(g.h, ctypes.byref(p), nbytes)); g._dev.append(p); slots.append(p)
     for c0 in range(lo, hi, chunk):                      # stage frames in HBM chunk by chunk
         fr = [seq.frame(i) for i in range(c0, min(c0 + chunk, hi))]
-        dev = [g.upload(f[0]) for f in fr]
+        dev = slots[:len(fr)]
+        for p, f in zip(dev, fr):
+            a = np.ascontiguousarray(f[0], np.float32)
+            g._chk(g.L.gsdf_dev_upload(g.h, p, a.ctypes.data_as(ctypes.c_void_p), nbytes))
+        gc.collect(); gc.disable()     # (a generation-2 collection of this process takes 30-40 ms and used to land inside chunks)
         g.sync(); t0 = time.perf_counter()
-        for d, f in zip(dev, fr):
+        worst = (0.0, "")
+        for j, (d, f) in enumerate(zip(dev, fr)):
+            ta = time.perf_counter()
             g.update_dev(d, f[1], f[2])
+            tb = time.perf_counter()
+            if j % 32 == 31:
+                g.sync()             # as bench.py does: long unsynchronised runs of launches make the HIP runtime stall the host (10-40 ms, sporadically)
+            tc = time.perf_counter()
+            worst = max(worst, (tb - ta, "update_dev %d" % j), (tc - tb, "sync %d" % j))
+        if os.environ.get("GSDF_C4_DEBUG"):
+            print("   slowest call: %s %.2f ms" % (worst[1], worst[0] * 1e3), file=sys.stderr)
         g.sync(); t_fuse += time.perf_counter() - t0
-        for d in dev:
-            g.L.gsdf_dev_free(g.h, d)
-        g._dev = []
+        gc.enable()
+        if os.environ.get("GSDF_C4_DEBUG"):
+            st = g.stats()
+            print("chunk at frame %d: %.2f ms for %d frames | timeouts %d deferred %d" % (c0, (time.perf_counter() - t0) * 1e3, len(dev), st["fuse_timeouts"], st["n_deferred"]), file=sys.stderr, flush=True)
     exchanged = 0
     comm = None
     if (world > 1 or args.force_exchange) and args.exchange == "c-abi":
@@ -58,6 +81,7 @@ def main():
             idt = idt.cuda() if args.dist_backend == "nccl" else idt
             dist.broadcast(idt, src=0)
         comm = pkg.binding.rccl_comm_init(world, bytes(idt.cpu().numpy().tobytes()), rank, local)
+        g.merge_prepare(world)               # like the communicator: set-up outside the timed exchange
         if world > 1:
             dist.barrier()
     t0 = time.perf_counter()
