@@ -39,8 +39,10 @@ def main():
     chunk, t_fuse = 64, 0.0
     # 64 staging buffers, allocated ONCE and refilled chunk by chunk.  (Allocating and freeing them per chunk -- what this tool
     # did until round 4 -- makes every other chunk take 15-30 ms instead of 2.7 with the libraries built since the exchange
-    # links rocPRIM's select / sort: the stall is on the device side of the first synchronisation after the re-allocation, with
-    # no fusion time-outs or deferred entries; the round-3 library does not show it, buffers that stay do not either.)
+    # links rocPRIM's select / sort (bisected: the same sources without those two kernels' code object do not show it, nor does
+    # the round-3 library; no rocPRIM kernel has run at that point): the stall is on the device side of the first
+    # synchronisation after the re-allocation, with no fusion time-outs or deferred entries -- freeing and mapping 77 MB of
+    # device memory per chunk is at the mercy of where the runtime's allocator places it.  Buffers that stay do not show it.)
     nbytes = W * H * 4
     slots = []
     for _ in range(chunk):
