@@ -1,4 +1,5 @@
 #include "frame_pipeline.h"
+#include "png16.h"
 
 #include <algorithm>
 
@@ -19,6 +20,14 @@ FramePipeline::FramePipeline(gsdf_ctx* ctx, const ImageLoader* loader, std::vect
             break;
         }
         s.host = (float*)h; s.dev = (float*)d;
+    }
+    png_warm_up();                                     /* the inflate library's dlopen belongs to the set-up, not to the first frame */
+    /* ... and so does the creation of the copy stream and its first transfer (the DMA queue's one-time set-up: 15-20 ms that
+     * the first next() used to wait for) */
+    if (error_.empty() && !slots_.empty() && slots_[0].host && slots_[0].dev) {
+        int64_t id = 0;
+        slots_[0].host[0] = 0.f;
+        if (gsdf_dev_upload_ahead(ctx_, slots_[0].dev, slots_[0].host, (int64_t)sizeof(float), &id) == GSDF_OK) (void)gsdf_upload_wait(ctx_, id);
     }
     if (error_.empty())
         for (int t = 0; t < threads; ++t) threads_.emplace_back(&FramePipeline::worker, this);

@@ -165,6 +165,8 @@ bool decode_rows(const std::string& path, Header& hd, size_t& stride, int& bpp, 
 }
 }
 
+void png_warm_up() { (void)deflate_lib(); }
+
 bool png_read(const std::string& path, PngImage& out, std::string* err) {
     Header hd;
     size_t stride = 0;

@@ -13,6 +13,8 @@ struct PngImage {
     std::vector<uint16_t> first_channel;      /* row-major, host byte order */
 };
 
+/* looks the inflate library up now (dlopen, a few ms the first time) instead of inside the first decode */
+void png_warm_up();
 bool png_read(const std::string& path, PngImage& out, std::string* err = nullptr);
 /* the decoder threads' path: first channel of a width x height image as float * unit (cv::Mat::convertTo(CV_32FC1, unit),
  * ImageLoader.h:167-172) straight into dst, without the intermediate image */
