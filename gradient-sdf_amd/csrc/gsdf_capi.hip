@@ -106,6 +106,13 @@ static int auto_grow_step(gsdf_ctx* c) {
     return GSDF_OK;
 }
 
+/* the tile statistics that belong to a set of normal planes (written by whatever computes the normals, read by the set's k_fuse) */
+static uint32_t* stats_of(const gsdf_ctx* c, const float* nrm) {
+    const size_t N = (size_t)c->W * c->H;
+    const size_t set = (size_t)(nrm - c->normals) / (3 * N);
+    return c->tile_stats + set * (size_t)c->fuse_blocks * 4;
+}
+
 /* one k_fuse launch: depth + its normal planes `nrm` (3 x N floats) -> the map.  next_depth (nullable): the launch's extra
  * workgroups compute the normals of that frame into next_nrm */
 int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsdf_pose_arg& pose, int use_dev_pose,
@@ -128,7 +135,8 @@ int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsd
                          /* many tiles did not fit the small LDS table lately (far geometry): the kernel with the larger one.
                           * Like the note above a hint that lags by a launch or two, never a condition for correctness. */
                          fuse_far_table(c),
-                         next_depth, next_nrm, next_nrm ? next_nrm + N : nullptr, next_nrm ? next_nrm + 2 * N : nullptr, c->win);
+                         next_depth, next_nrm, next_nrm ? next_nrm + N : nullptr, next_nrm ? next_nrm + 2 * N : nullptr, c->win,
+                         stats_of(c, nrm), next_nrm ? stats_of(c, next_nrm) : nullptr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
@@ -143,7 +151,7 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
         nrm = c->normals + (size_t)c->nrm_parity * 3 * N;
         c->nrm_parity ^= 1;
         prof_scope ps(c, 0);
-        gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr);
+        gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr, stats_of(c, nrm));
     }
     return launch_fuse(c, depth_dev, nrm, pose, use_dev_pose, nullptr, nullptr);
 }
@@ -192,6 +200,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
         nj.nc = c->ncache();
         nj.nx = c->normals + 6 * N; nj.ny = c->normals + 7 * N; nj.nz = c->normals + 8 * N;          /* set 2 */
         nj.deferred_count = c->deferred_count;
+        nj.stats = stats_of(c, nj.nx);
         nj.r = c->win / 2; nj.ntx = 0;
         nj.tile_first = 0; nj.tile_count = 0;
     }
@@ -456,7 +465,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     for (hipEvent_t e : c->mark_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->upload_pool) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.second);
-    void* ptrs[] = { c->grow_scratch, c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
+    void* ptrs[] = { c->tile_stats, c->grow_scratch, c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb, c->ba_gate_list, c->ba_gate_tmp, c->counter2 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -522,11 +531,11 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
         return fail(GSDF_ERR_INVALID, "W,H > 0 and odd window <= 15 required");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    void* old[] = { c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log, c->deferred,
+    void* old[] = { c->tile_stats, c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log, c->deferred,
                     c->deferred_count, c->tile_flags, c->tile_order, c->fuse_ticket, c->track_rows, c->track_abort };
     for (void* p : old) if (p) (void)hipFree(p);
     c->track_rows = nullptr; c->track_abort = nullptr;
-    c->tile_flags = nullptr; c->tile_order = nullptr;
+    c->tile_flags = nullptr; c->tile_order = nullptr; c->tile_stats = nullptr;
     c->planes = c->depth_stage = c->normals = nullptr; c->partials = nullptr;
     c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr; c->fuse_ticket = nullptr;
     c->W = W; c->H = H; c->win = win;
@@ -550,6 +559,9 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
         HIP_TRY(hipMemsetAsync(c->track_abort, 0, sizeof(unsigned int), c->stream));
     }
     c->fuse_blocks = gsdf_fuse_grid_blocks(W, H);
+    /* per set of normal planes: the statistics of the frame's fusion tiles (depth range, valid pixels), written with the normals */
+    HIP_TRY(hipMalloc((void**)&c->tile_stats, (size_t)3 * c->fuse_blocks * 4 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(c->tile_stats, 0, (size_t)3 * c->fuse_blocks * 4 * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMalloc((void**)&c->blk_counters, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipMalloc((void**)&c->tile_flags, (size_t)c->fuse_blocks * sizeof(unsigned int)));
@@ -594,7 +606,7 @@ int gsdf_normals_compute(gsdf_ctx* c, const float* depth_host, float* nx, float*
     const size_t N = (size_t)c->W * c->H;
     HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     float* set2 = c->normals + 6 * N;
-    gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), c->depth_stage, set2, set2 + N, set2 + 2 * N, nullptr, nullptr);
+    gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), c->depth_stage, set2, set2 + N, set2 + 2 * N, nullptr, nullptr, stats_of(c, set2));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(nx, set2, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(ny, set2 + N, N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -629,7 +641,7 @@ int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const
     c->nrm_parity ^= 1;
     float* nrm = c->normals + (size_t)set * 3 * N;
     if (!c->pending.valid) {
-        gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr);
+        gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr, stats_of(c, nrm));
         HIP_TRY(hipGetLastError());
     } else {
         const float* pn = c->normals + (size_t)c->pending.set * 3 * N;

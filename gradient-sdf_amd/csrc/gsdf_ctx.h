@@ -58,7 +58,8 @@ struct gsdf_ctx {
     float K[9] = { 0 };
     float* planes = nullptr;                       /* 11 planes */
     float* depth_stage = nullptr;                  /* H2D staging for host-pointer entry points */
-    float* normals = nullptr;                      /* 3 planes */
+    float* normals = nullptr;                      /* 3 sets of 3 planes */
+    uint32_t* tile_stats = nullptr;                /* per set: [fuse_blocks][4] statistics of the frame's fusion tiles (gsdf_kernels.hip: gsdf_tile_stats) */
     /* tracker */
     gsdf_dev_state* st = nullptr;
     double* partials = nullptr;                    /* 3 rotating buffers of tracker partial sums */

@@ -85,7 +85,8 @@ void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int 
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
                          const float* depth, float* nx, float* ny, float* nz,
                          unsigned int* deferred_count /* nullable: cleared for the k_fuse that follows */,
-                         gsdf_dev_state* st_rw /* nullable: snapshot of the frame counter for k_fuse */);
+                         gsdf_dev_state* st_rw /* nullable: snapshot of the frame counter for k_fuse */,
+                         uint32_t* tile_stats /* nullable: [gsdf_fuse_grid_blocks][4], the frame's tile statistics for its k_fuse */);
 /* use_dev_pose: take R,t from st->R / st->pose7 and skip the launch unless st->converged */
 void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
                       const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
@@ -103,7 +104,9 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       unsigned int* host_note /* nullable, 2 pinned host words: length of the deferred list, tiles too big for the small LDS table */,
                       int far_table /* use the kernel with the larger LDS table */,
                       const float* next_depth /* nullable: the launch also computes the normals of this (the next) frame ... */,
-                      float* next_nx, float* next_ny, float* next_nz /* ... into these planes */, int win);
+                      float* next_nx, float* next_ny, float* next_nz /* ... into these planes */, int win,
+                      const uint32_t* tile_stats /* this frame's tile statistics (written with its normals) */,
+                      uint32_t* next_tile_stats /* the next frame's, written by the launch's normals workgroups */);
 int  gsdf_fuse_grid_blocks(int W, int H);
 void gsdf_fuse_tile_order(int W, int H, uint32_t* order_host /* [gsdf_fuse_grid_blocks] */);
 /* per-launch parameters of one Gauss-Newton pass (RigidOptimizer.h:57-62) */
@@ -121,6 +124,7 @@ struct gsdf_normals_job {
     gsdf_ncache nc;
     float *nx, *ny, *nz;
     unsigned int* deferred_count; /* cleared for the k_fuse of this frame */
+    uint32_t* stats;              /* the frame's tile statistics for its k_fuse ([tiles of 16 x 16 pixels][4], see gsdf_kernels.hip) */
     int r, ntx;                   /* window radius; tiles per image row (set by the launcher) */
     int tile_first, tile_count;   /* the tiles this launch computes: [tile_first, tile_first + tile_count); count 0 = all the rest */
 };

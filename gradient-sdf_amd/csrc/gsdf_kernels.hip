@@ -214,15 +214,38 @@ void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int 
 struct nrm_lds {
     float prod[3][NRM_TY + 2 * NRM_RMAX][NRM_TX + 2 * NRM_RMAX + 1];
     double rows[3][NRM_TY + 2 * NRM_RMAX][NRM_TX];
+    unsigned int stat[2][4];             /* per 16-pixel half of the tile: smallest / largest valid depth (float bits), valid pixels */
+};
+/* The gates of MapGradPixelSdf::update on one pixel (MapGradPixelSdf.cpp:87, :95, :98): does the fusion walk its ray?  ONE
+ * function for the fusion kernel and for the normals stage, which tells the fusion kernel ahead of time how many pixels of each
+ * of its tiles are valid and what their depth range is (gsdf_tile_stats below) -- the two must agree bit for bit. */
+__device__ __forceinline__ bool gsdf_fuse_pixel_valid(float z, float x0, float y0, float ninv, float nx, float ny, float nz, float zmin, float zmax) {
+    bool valid = !(z <= zmin || z >= zmax);                                     /* :87 */
+    const gsdf_v3 n = { nx, ny, nz }, xy = { x0, y0, 1.f };
+    if ((double)gsdf_dot3(n, n) < .1) valid = false;                            /* :95 (same comparison as the reference: NaN passes) */
+    const float nd = gsdf_dot3(n, xy);
+    if (nd * nd * ninv < .25) valid = false;                                    /* :98 */
+    return valid;
+}
+/* Statistics of a frame's 16 x 16-pixel fusion tiles, written by whatever computes the frame's normals (k_normals, the normals
+ * workgroups of the tracker launches, the tail of the previous fusion launch): [tile_y][tile_x][4] = smallest valid depth,
+ * largest valid depth (float bits; 0x7F800000 / 0 without a valid pixel), number of valid pixels, unused.  The fusion kernel
+ * makes its tile-wide decisions from them while its pixel loads are still in flight. */
+struct gsdf_tile_stats {
+    uint32_t* rows;                      /* nullable */
+    int ntx;                             /* fusion tiles per image row */
+    float zmin, zmax;                    /* Sdf::z_min_ / z_max_ */
 };
 template <int NT = NRM_THREADS>          /* threads of the calling workgroup (>= NRM_TX * NRM_TY) */
 __device__ __forceinline__ void normals_tile(nrm_lds& S, int tile_x, int tile_y, int W, int H, int r, const gsdf_ncache& nc,
                                              const float* __restrict__ depth, float* __restrict__ nx, float* __restrict__ ny,
-                                             float* __restrict__ nz) {
+                                             float* __restrict__ nz, const gsdf_tile_stats ts = gsdf_tile_stats{ nullptr, 0, 0.f, 0.f }) {
     const int tx0 = tile_x * NRM_TX, ty0 = tile_y * NRM_TY;
     const int PW = NRM_TX + 2 * r, PH = NRM_TY + 2 * r;
     const int tid = threadIdx.x;
     static_assert(NT >= NRM_TX * NRM_TY, "one lane per pixel of the tile in the last stage");
+    static_assert(NRM_TX == 32 && NRM_TY == 16, "two 16 x 16 fusion tiles per normals tile");
+    if (tid < 2) { S.stat[tid][0] = 0x7F800000u; S.stat[tid][1] = 0u; S.stat[tid][2] = 0u; }
     for (int idx = tid; idx < PW * PH; idx += NT) {
         const int ly = idx / PW, lx = idx - ly * PW;
         const int gy = reflect101(ty0 + ly - r, H), gx = reflect101(tx0 + lx - r, W);
@@ -247,39 +270,68 @@ __device__ __forceinline__ void normals_tile(nrm_lds& S, int tile_x, int tile_y,
     __syncthreads();
     const int x = tid & (NRM_TX - 1), y = tid / NRM_TX;
     const int px = tx0 + x, py = ty0 + y;
-    if (y >= NRM_TY || px >= W || py >= H) return;
-    double b1 = 0, b2 = 0, b3 = 0;
-    for (int dy = 0; dy <= 2 * r; ++dy) {
-        b1 += S.rows[0][y + dy][x];
-        b2 += S.rows[1][y + dy][x];
-        b3 += S.rows[2][y + dy][x];
+    const bool inside = y < NRM_TY && px < W && py < H;
+    if (!inside && !ts.rows) return;
+    bool valid = false;
+    float z = 0.f;
+    if (inside) {
+        double b1 = 0, b2 = 0, b3 = 0;
+        for (int dy = 0; dy <= 2 * r; ++dy) {
+            b1 += S.rows[0][y + dy][x];
+            b2 += S.rows[1][y + dy][x];
+            b3 += S.rows[2][y + dy][x];
+        }
+        const size_t i = (size_t)py * W + px;
+        const float c1 = (float)b1, c2 = (float)b2, c3 = (float)b3;
+        const float q11 = nc.q11[i], q12 = nc.q12[i], q13 = nc.q13[i], q22 = nc.q22[i], q23 = nc.q23[i], q33 = nc.q33[i];
+        const float vx = (c1 * q11 + c2 * q12) + c3 * q13;      /* :195-197 */
+        const float vy = (c1 * q12 + c2 * q22) + c3 * q23;
+        const float vz = (c1 * q13 + c2 * q23) + c3 * q33;
+        const float n = sqrtf((vx * vx + vy * vy) + vz * vz);   /* :199 */
+        const float ox = vx / n, oy = vy / n, oz = vz / n;      /* :201-203 */
+        nx[i] = ox; ny[i] = oy; nz[i] = oz;
+        if (ts.rows) {
+            z = depth[i];
+            valid = gsdf_fuse_pixel_valid(z, nc.x0[i], nc.y0[i], nc.ninv[i], ox, oy, oz, ts.zmin, ts.zmax);
+        }
     }
-    const size_t i = (size_t)py * W + px;
-    const float c1 = (float)b1, c2 = (float)b2, c3 = (float)b3;
-    const float q11 = nc.q11[i], q12 = nc.q12[i], q13 = nc.q13[i], q22 = nc.q22[i], q23 = nc.q23[i], q33 = nc.q33[i];
-    const float vx = (c1 * q11 + c2 * q12) + c3 * q13;      /* :195-197 */
-    const float vy = (c1 * q12 + c2 * q22) + c3 * q23;
-    const float vz = (c1 * q13 + c2 * q23) + c3 * q33;
-    const float n = sqrtf((vx * vx + vy * vy) + vz * vz);   /* :199 */
-    nx[i] = vx / n; ny[i] = vy / n; nz[i] = vz / n;         /* :201-203 */
+    if (!ts.rows) return;                                   /* (uniform: a kernel argument) */
+    /* the two fusion tiles of this normals tile: depth range and number of their valid pixels (every wave reduces its 64 lanes
+     * with DPP, lane 0 adds them to the workgroup's six words) */
+    const int lane = tid & 63;
+    const int half = (lane >> 4) & 1;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool mine = valid && half == h;
+        unsigned int lo = mine ? __float_as_uint(z) : 0x7F800000u, hi = mine ? __float_as_uint(z) : 0u;
+        wave_uminmax(lo, hi);
+        const unsigned int cnt = (unsigned int)__popcll(__ballot(mine));
+        if (lane == 0 && cnt) { atomicMin(&S.stat[h][0], lo); atomicMax(&S.stat[h][1], hi); atomicAdd(&S.stat[h][2], cnt); }
+    }
+    __syncthreads();
+    if (tid < 2 && 2 * tile_x + tid < ts.ntx) {
+        uint32_t* o = ts.rows + 4 * ((size_t)tile_y * ts.ntx + 2 * tile_x + tid);
+        o[0] = S.stat[tid][0]; o[1] = S.stat[tid][1]; o[2] = S.stat[tid][2]; o[3] = 0u;
+    }
 }
 
 __global__ __launch_bounds__(NRM_THREADS) void k_normals(gsdf_frame_geom g, int r, gsdf_ncache nc,
                                                          const float* __restrict__ depth, float* __restrict__ nx,
                                                          float* __restrict__ ny, float* __restrict__ nz,
-                                                         unsigned int* deferred_count, gsdf_dev_state* st_rw) {
+                                                         unsigned int* deferred_count, gsdf_dev_state* st_rw, gsdf_tile_stats ts) {
     if (deferred_count && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         *deferred_count = 0u;                                  /* fresh list for k_fuse */
         if (st_rw) st_rw->frame_cur = st_rw->frames;           /* counter_ seen by every workgroup of k_fuse */
     }
     __shared__ nrm_lds S;
-    normals_tile(S, blockIdx.x, blockIdx.y, g.W, g.H, r, nc, depth, nx, ny, nz);
+    normals_tile(S, blockIdx.x, blockIdx.y, g.W, g.H, r, nc, depth, nx, ny, nz, ts);
 }
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
                          const float* depth, float* nx, float* ny, float* nz,
-                         unsigned int* deferred_count, gsdf_dev_state* st_rw) {
+                         unsigned int* deferred_count, gsdf_dev_state* st_rw, uint32_t* tile_stats) {
     dim3 grid((g.W + NRM_TX - 1) / NRM_TX, (g.H + NRM_TY - 1) / NRM_TY);
-    hipLaunchKernelGGL(k_normals, grid, dim3(NRM_THREADS), 0, s, g, win / 2, nc, depth, nx, ny, nz, deferred_count, st_rw);
+    const gsdf_tile_stats ts = { tile_stats, (g.W + 15) / 16, g.zmin, g.zmax };
+    hipLaunchKernelGGL(k_normals, grid, dim3(NRM_THREADS), 0, s, g, win / 2, nc, depth, nx, ny, nz, deferred_count, st_rw, ts);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -382,6 +434,11 @@ static_assert(FUSE_TH % 4 == 0 && FUSE_TH >= 8 && FUSE_TH <= 32, "tile height");
 #define FUSE_SPREAD 1                    /* spread lane -> (pixel, slice) mapping, see k_fuse */
 #endif
 #define FUSE_NSTAT (FUSE_SPREAD ? FUSE_NWAVES : 4) /* waves of a workgroup that hold distinct pixels */
+/* tile statistics from the normals stage (normals tiles are 32 x 16 pixels = two fusion tiles): the standard tile shape only;
+ * other shapes (build experiments) reduce them from their own pixels */
+#ifndef FUSE_STATS_AHEAD
+#define FUSE_STATS_AHEAD (FUSE_T == 16 && FUSE_TH == 16)
+#endif
 typedef uint32_t gsdf_u32x4 __attribute__((ext_vector_type(4)));
 typedef float gsdf_f2 __attribute__((ext_vector_type(2)));           /* packed f32 arithmetic (v_pk_*_f32): two results per issue slot */
 /* a * b + c with a, b < 2^24 (b uniform): full rate, where the 32-bit v_mul_lo_u32 is quarter rate */
@@ -423,6 +480,8 @@ struct fuse_args {
     int n_tiles;                        /* fusion workgroups of this launch */
     const float* nrm_depth;             /* nullable: depth image of the next frame */
     float *nrm_x, *nrm_y, *nrm_z;       /* its normal planes (the other set) */
+    uint32_t* nrm_stats;                /* ... and its tile statistics (gsdf_tile_stats) */
+    const uint32_t* tile_stats;         /* THIS frame's tile statistics, written with its normals */
     int nrm_r, nrm_ntx;                 /* window radius, normals tiles per image row */
 };
 #define FUSE_RESOLVE_INLINE 8192u       /* deferred entries the last workgroup adds itself even when a resolve launch follows */
@@ -538,7 +597,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         static_assert(sizeof(nrm_lds) <= sizeof(fuse_lds<LCAP>), "the normals tile works in the fusion table's LDS");
         const int t = (int)blockIdx.x - a.n_tiles;
         normals_tile<FUSE_THREADS>(*reinterpret_cast<nrm_lds*>(&L), t % a.nrm_ntx, t / a.nrm_ntx, a.g.W, a.g.H, a.nrm_r, a.nc, a.nrm_depth, a.nrm_x,
-                     a.nrm_y, a.nrm_z);
+                     a.nrm_y, a.nrm_z, gsdf_tile_stats{ a.nrm_stats, (a.g.W + 15) / 16, a.g.zmin, a.g.zmax });
         return;
     }
     }
@@ -582,8 +641,18 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     const long long frame_cur = a.vis ? a.st->frame_cur : 0;   /* Sdf::counter_ of this update (snapshot by k_normals) */
     const int wave = tid >> 6, lane = tid & 63;
     const int zslice = wave >> 2;
+    (void)zslice;
     const int lx = lane & 7, ly = lane >> 3;
     const int tile_x = (int)(tile_id & 0xFFFFu), tile_y = (int)(tile_id >> 16);
+#if FUSE_STATS_AHEAD
+    /* The tile's depth range and its number of valid pixels come from the normals stage of this frame (gsdf_tile_stats): three
+     * words, requested now.  Wave 0 makes the tile-wide decisions from them while the seven pixel planes are still on their way
+     * -- they used to be reduced from the arrived pixels (DPP, LDS, a barrier) and the decisions (~200 dependent instructions
+     * of one wave) followed behind that: 1.9 us of every tile's prologue, exposed whenever all workgroups of the chip start
+     * together (the first dispatch round) or run alone (the last). */
+    const uint32_t* tsr = a.tile_stats + 4 * ((size_t)tile_y * a.ntx + tile_x);
+    const unsigned int ts_zmin = tsr[0], ts_zmax = tsr[1], ts_nval = tsr[2];
+#endif
     bool valid = false;
     float z = 0.f;
     gsdf_v3 Rxy = { 0.f, 0.f, 0.f }, Rn = { 0.f, 0.f, 0.f };   /* Rn carries the fixed-point scale: w * Rn is the scaled term */
@@ -594,13 +663,10 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             z = zr;
             const gsdf_v3 xy = { x0r, y0r, 1.f };                          /* :90 */
             const gsdf_v3 n = { nxr, nyr, nzr };                           /* :92 */
-            valid = !(z <= g.zmin || z >= g.zmax);                         /* MapGradPixelSdf.cpp:87 */
+            valid = gsdf_fuse_pixel_valid(z, x0r, y0r, ninv, nxr, nyr, nzr, g.zmin, g.zmax);   /* MapGradPixelSdf.cpp:87, :95, :98 */
             Rxy = gsdf_matvec(R, xy);                                      /* :91 */
             const gsdf_v3 rn = gsdf_matvec(R, n);                          /* :93 */
             Rn = gsdf_v3{ rn.x * FUSE_FIX_G, rn.y * FUSE_FIX_G, rn.z * FUSE_FIX_G };         /* exact (power of two) */
-            if ((double)gsdf_dot3(n, n) < .1) valid = false;               /* :95 (same comparison as the reference: NaN passes) */
-            const float nd = gsdf_dot3(n, xy);
-            if (nd * nd * ninv < .25) valid = false;                       /* :98 */
         }
     };
     auto load_pixel = [&](int px, int py, const float* dp, const float* x0p, const float* y0p, const float* nip,
@@ -656,6 +722,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             dmax[0] = fmaxf(dmax[0], d.x); dmax[1] = fmaxf(dmax[1], d.y); dmax[2] = fmaxf(dmax[2], d.z);
         }
     }
+#if !FUSE_STATS_AHEAD
     if (GSDF_EXPERIMENT(a.debug, 64)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSDF_TRACE(a, tr, 11); }   /* pixel loads arrived */
     finish_pixel(inside0, raw[0], raw[1], raw[2], raw[3], raw[4], raw[5], raw[6]);
     /* depth range of the tile and the number of valid pixels: one entry per wave that holds distinct pixels */
@@ -668,6 +735,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     }
     __syncthreads();
     GSDF_TRACE(a, tr, 12);                                            /* tile statistics reduced */
+#endif
     const int nk_all = 2 * g.factor + 1;
     const int colour = (tile_x & 1) + 2 * (tile_y & 1);
     unsigned int* my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
@@ -678,6 +746,10 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     int ox = 0, oy = 0, oz = 0;
     bool range_ok = false;
     if (wave == 0) {
+#if FUSE_STATS_AHEAD
+        const unsigned int zmin_bits = ts_zmin, zmax_bits = ts_zmax;
+        const float n_valid = (float)ts_nval;
+#else
         unsigned int zmin_bits = L.st_min[0], zmax_bits = L.st_max[0];
         float n_valid = L.st_cnt[0];
 #pragma unroll
@@ -685,6 +757,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             zmin_bits = min(zmin_bits, L.st_min[i]); zmax_bits = max(zmax_bits, L.st_max[i]);
             n_valid += L.st_cnt[i];                                   /* small integers: exact in any order */
         }
+#endif
         /* (1) of the flush comment below: may this tile write its voxels itself? */
         const float D = 1.7421f * g.vs;
         const float s_min = __uint_as_float(zmin_bits) - (float)g.factor * g.vs - 2.f * D;
@@ -743,6 +816,12 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
                    oz >= -GSDF_KEY_OFF && oz + 1023 < GSDF_KEY_OFF;
         if (lane == 0) { L.dec[0] = n_pass; L.dec[1] = big; L.dec[2] = ox; L.dec[3] = oy; L.dec[4] = oz; L.dec[5] = range_ok ? 1 : 0; }
     }
+#if FUSE_STATS_AHEAD
+    /* (wave 0 has decided while the loads were in flight; now everybody takes its pixel) */
+    if (GSDF_EXPERIMENT(a.debug, 64)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSDF_TRACE(a, tr, 11); }   /* (wave 0: decisions made and) pixel loads arrived */
+    finish_pixel(inside0, raw[0], raw[1], raw[2], raw[3], raw[4], raw[5], raw[6]);
+    GSDF_TRACE(a, tr, 12);
+#endif
     __syncthreads();
     n_pass = __builtin_amdgcn_readfirstlane(L.dec[0]); big = __builtin_amdgcn_readfirstlane(L.dec[1]);
     ox = __builtin_amdgcn_readfirstlane(L.dec[2]); oy = __builtin_amdgcn_readfirstlane(L.dec[3]); oz = __builtin_amdgcn_readfirstlane(L.dec[4]);
@@ -1201,8 +1280,9 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       unsigned int tag, unsigned int* tile_flags, const uint32_t* tile_order, float* log_rows,
                       long long max_rows, uint32_t* vis, int vis_words, int debug, unsigned int* ticket, int resolve_follows,
                       unsigned int* host_note, int far_table, const float* next_depth, float* next_nx, float* next_ny, float* next_nz,
-                      int win) {
+                      int win, const uint32_t* tile_stats, uint32_t* next_tile_stats) {
     fuse_args a;
+    a.tile_stats = tile_stats; a.nrm_stats = next_tile_stats;
     a.host_note = host_note;
     a.ticket = ticket; a.log_rows = use_dev_pose ? log_rows : nullptr; a.max_rows = max_rows; a.resolve_follows = resolve_follows;
     a.vis = vis; a.vis_words = vis_words;
@@ -1219,7 +1299,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     a.nrm_r = win / 2; a.nrm_ntx = (g.W + NRM_TX - 1) / NRM_TX;
     int extra = next_depth ? a.nrm_ntx * ((g.H + NRM_TY - 1) / NRM_TY) : 0;
     if (extra && !FUSE_CARRIES_NORMALS) {
-        gsdf_launch_normals(s, g, win, nc, next_depth, next_nx, next_ny, next_nz, nullptr, nullptr);
+        gsdf_launch_normals(s, g, win, nc, next_depth, next_nx, next_ny, next_nz, nullptr, nullptr, next_tile_stats);
         extra = 0;
     }
     if (extra) {
@@ -1523,7 +1603,8 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
             *nj.deferred_count = 0u;                            /* fresh list for the k_fuse of this frame */
             st->frame_cur = st->frames;                         /* counter_ seen by every workgroup of k_fuse */
         }
-        normals_tile(*reinterpret_cast<nrm_lds*>(dyn_lds), t % nj.ntx, t / nj.ntx, g.W, g.H, nj.r, nj.nc, depth, nj.nx, nj.ny, nj.nz);
+        normals_tile(*reinterpret_cast<nrm_lds*>(dyn_lds), t % nj.ntx, t / nj.ntx, g.W, g.H, nj.r, nj.nc, depth, nj.nx, nj.ny, nj.nz,
+                     gsdf_tile_stats{ nj.stats, (g.W + 15) / 16, g.zmin, g.zmax });
         return;
     }
     /* test build, debug bit 64 of the tracker flags: time stamps of thread 0 in rows 2048 + pass * 512 + workgroup of the
@@ -1740,7 +1821,8 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_all(gsdf_frame_geom 
             *nj.deferred_count = 0u;                            /* fresh list for the k_fuse of this frame */
             st->frame_cur = st->frames;                         /* counter_ seen by every workgroup of k_fuse */
         }
-        normals_tile(*reinterpret_cast<nrm_lds*>(dyn_lds), t % nj.ntx, t / nj.ntx, g.W, g.H, nj.r, nj.nc, depth, nj.nx, nj.ny, nj.nz);
+        normals_tile(*reinterpret_cast<nrm_lds*>(dyn_lds), t % nj.ntx, t / nj.ntx, g.W, g.H, nj.r, nj.nc, depth, nj.nx, nj.ny, nj.nz,
+                     gsdf_tile_stats{ nj.stats, (g.W + 15) / 16, g.zmin, g.zmax });
         return;
     }
     constexpr int NW = GSDF_TRACK_BLOCK / 64;
