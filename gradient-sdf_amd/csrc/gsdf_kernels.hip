@@ -2175,6 +2175,11 @@ void gsdf_launch_get_voxels(hipStream_t s, gsdf_table tab, const int32_t* keys, 
  *  Measured and rejected: looking RC_B samples ahead per lane (their lookups issued together, the state machine consuming
  *  them while the predicted positions hold): 8x fewer dependent round trips, but 20 % MORE instructions (speculative work
  *  beyond a hit or a change of step), 118-136 registers (two rounds of waves) -- 138-200 us against 121.
+ *  Round 4, the same idea without the registers: once half of a wave's rays have ended (the slowest waves spend 40 % of their
+ *  iterations like that, profiles/r04_raycast_helper_lanes.txt), 2 / 4 / 8 lanes per remaining ray look up its next positions
+ *  and the ray takes the results in order through ds_bpermute -- bit-identical output, the slowest waves' iterations 67 -> 54,
+ *  and the launch no shorter (125 us with the second loop in the kernel, helping or not, against 119 without it): a band
+ *  sample's own step (normalisation, divisions: ~150 dependent instructions) is as long as its lookup.
  * Counters (for the roofline entry): samples the definition evaluated and records it read, one row per workgroup.
  * ---------------------------------------------------------------------------------------------- */
 struct rc_ray_state {
@@ -2241,10 +2246,19 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
     st.prev_ok = false; st.done = !live;
     unsigned int n_samp = 0u, n_rec = 0u;
     unsigned int it_fast = 0u, it_slow = 0u;                          /* wave-uniform loop counts: cell skips taken / all iterations */
+#ifdef GSDF_EXPERIMENTS
+    unsigned int it_le32 = 0u, it_le16 = 0u, it_le8 = 0u, lanes_sum = 0u;
+#endif
     for (;;) {
         const bool active = !st.done && st.s < zmax;
         if (!__any(active)) break;
         ++it_slow;
+#ifdef GSDF_EXPERIMENTS
+        {   /* how full the wave is, iteration by iteration (tools/raycast_bench.py): iterations with <= 32 / 16 / 8 rays left */
+            const unsigned int na = (unsigned int)__popcll(__ballot(active));
+            it_le32 += na <= 32u; it_le16 += na <= 16u; it_le8 += na <= 8u; lanes_sum += na;
+        }
+#endif
         const float s = st.s;
         const gsdf_v3 p = { s * d.x + pose.t[0], s * d.y + pose.t[1], s * d.z + pose.t[2] };
         const float qx = inv_vs * p.x, qy = inv_vs * p.y, qz = inv_vs * p.z;
@@ -2322,6 +2336,11 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
     __shared__ unsigned int rc_it[4];
     const float ts = wave_sum((float)n_samp), tr = wave_sum((float)n_rec);           /* < 2^24 per wave: exact */
     if (lane == 0) { rc_cnt[wave][0] = ts; rc_cnt[wave][1] = tr; rc_it[wave] = it_slow; }
+#ifdef GSDF_EXPERIMENTS
+    __shared__ unsigned long long rc_fill[4];
+    if (lane == 0) rc_fill[wave] = (unsigned long long)it_le32 | ((unsigned long long)it_le16 << 12) | ((unsigned long long)it_le8 << 24) |
+                                   ((unsigned long long)lanes_sum << 36);
+#endif
     __syncthreads();
     if (wg_counts && threadIdx.x == 0) {
         unsigned long long* row = wg_counts + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
@@ -2330,6 +2349,11 @@ __global__ __launch_bounds__(256) void k_raycast(gsdf_table tab, float vs, float
         row[2] += it_fast; row[3] += it_slow;                           /* lane 0 of wave 0: cell skips / loop iterations */
         row[4] = t_begin; row[5] = wall_clock64();                      /* life of the workgroup, 100 MHz ticks (last launch) */
         row[6] = max(max(rc_it[0], rc_it[1]), max(rc_it[2], rc_it[3]));   /* loop iterations of its slowest wave (last launch) */
+#ifdef GSDF_EXPERIMENTS
+        int sw = 0;
+        for (int i = 1; i < 4; ++i) if (rc_it[i] > rc_it[sw]) sw = i;
+        row[7] = rc_fill[sw];                                           /* fill of that wave: le32 | le16 << 12 | le8 << 24 | lane sum << 36 */
+#endif
     }
 }
 

@@ -56,12 +56,24 @@ def main():
             itf, its = rows[:, 2].astype(np.float64) / (reps + 0), rows[:, 3].astype(np.float64) / (reps + 0)
             itmax = rows[:, 6].astype(np.float64)
             order = np.argsort(-life)[:8]
+            fill = rows[:, 7]                   # test build: how full the slowest wave of each workgroup was, iteration by iteration
+            le32, le16, le8 = (fill & 0xFFF).astype(np.float64), ((fill >> 12) & 0xFFF).astype(np.float64), ((fill >> 24) & 0xFFF).astype(np.float64)
+            lsum = (fill >> 36).astype(np.float64)
+            slow_wg = itmax >= np.percentile(itmax, 90)
+            fill_stats = {"slowest_decile_iters_mean": round(float(itmax[slow_wg].mean()), 1),
+                          "slowest_decile_iters_le32_mean": round(float(le32[slow_wg].mean()), 1),
+                          "slowest_decile_iters_le16_mean": round(float(le16[slow_wg].mean()), 1),
+                          "slowest_decile_iters_le8_mean": round(float(le8[slow_wg].mean()), 1),
+                          "slowest_decile_lane_fill": round(float((lsum[slow_wg] / np.maximum(64.0 * itmax[slow_wg], 1)).mean()), 3),
+                          "all_lane_fill": round(float((lsum / np.maximum(64.0 * itmax, 1)).mean()), 3),
+                          "all_iters_le32_frac": round(float(le32.sum() / max(itmax.sum(), 1)), 3)}
             wg_stats = {"life_us_mean": round(float(life.mean()), 1), "life_us_p50": round(float(np.median(life)), 1), "life_us_max": round(float(life.max()), 1),
                         "last_start_us": round(float(start.max()), 1), "last_end_us": round(float((start + life).max()), 1),
                         "iters_fast_mean": round(float(itf.mean()), 2), "iters_slow_mean": round(float(its.mean()), 2), "iters_slow_max": float(its.max()),
                         "slowest_wave_iters_mean": round(float(itmax.mean()), 1), "slowest_wave_iters_max": float(itmax.max()),
                         "us_per_iteration_of_slowest_wave_p50": round(float(np.median(life / np.maximum(itmax, 1))), 3),
                         "corr_life_iters": round(float(np.corrcoef(life, itmax)[0, 1]), 3),
+                        "slowest_wave_fill": fill_stats,
                         "slowest": [{"wg": int(i), "life_us": round(float(life[i]), 1), "start_us": round(float(start[i]), 1), "fast": float(itf[i]), "slow": float(its[i]),
                                      "samples": int(rows[i, 0] // reps), "slowest_wave_iters": float(itmax[i])} for i in order]}
         us = pr["ms"] * 1e3 / max(pr["launches"], 1)
