@@ -927,8 +927,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             int slot = -1;
             bool pend = act && local && !GSDF_EXPERIMENT(a.debug, 2);
             if (GSDF_EXPERIMENT(a.debug, 32)) { if (act) slot = (int)(FUSE_BSLOTS * bk + (key & (FUSE_BSLOTS - 1))); pend = false; }   /* experiment: no lookup */
-            for (int probe = 0; probe < FUSE_LPROBE; ++probe) {
-                if (__builtin_amdgcn_ballot_w64(pend) == 0ull) break;
+            for (int probe = 0; probe < FUSE_LPROBE && pend; ++probe) {       /* a divergent loop: lanes leave it as they find their slot */
                 ++dbg_go;
                 int pos;
                 bool hit;
