@@ -128,8 +128,15 @@ def render_frames(kind, W, H, indices, seed, **kw):
     if workers > 1 and "torch" not in sys.modules:
         try:
             import multiprocessing as mp
-            with mp.get_context("fork").Pool(workers) as pool:
-                return seq, pool.map(seq.frame, indices, chunksize=max(1, len(indices) // (4 * workers)))
+            pool = mp.get_context("fork").Pool(workers)
+            try:
+                frames = pool.map(seq.frame, indices, chunksize=max(1, len(indices) // (4 * workers)))
+            finally:
+                # close + join, not the context manager's terminate(): under rocprofv3 a worker that gets SIGTERM runs the
+                # profiler's signal handler and may never exit -- the parent then waits for it for good (seen once in a PMC pass)
+                pool.close()
+                pool.join()
+            return seq, frames
         except Exception:                                       # noqa: BLE001 -- any pool trouble: render serially
             pass
     return seq, [seq.frame(i) for i in indices]

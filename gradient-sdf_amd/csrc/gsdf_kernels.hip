@@ -439,6 +439,18 @@ static_assert(FUSE_TH % 4 == 0 && FUSE_TH >= 8 && FUSE_TH <= 32, "tile height");
 #ifndef FUSE_STATS_AHEAD
 #define FUSE_STATS_AHEAD (FUSE_T == 16 && FUSE_TH == 16)
 #endif
+/* wave priorities inside k_fuse (s_setprio 0..3): two workgroups share a CU, one usually walking (VALU issue) while the other is
+ * in a latency-bound phase whose few instructions should not queue behind the walk */
+#ifndef FUSE_PRIO_START
+#define FUSE_PRIO_START -1
+#endif
+#ifndef FUSE_PRIO_WALK
+#define FUSE_PRIO_WALK -1
+#endif
+#ifndef FUSE_PRIO_FLUSH
+#define FUSE_PRIO_FLUSH -1
+#endif
+#define FUSE_SETPRIO(n) do { if ((n) >= 0) __builtin_amdgcn_s_setprio((n) < 0 ? 0 : (n)); } while (0)
 typedef uint32_t gsdf_u32x4 __attribute__((ext_vector_type(4)));
 typedef float gsdf_f2 __attribute__((ext_vector_type(2)));           /* packed f32 arithmetic (v_pk_*_f32): two results per issue slot */
 /* a * b + c with a, b < 2^24 (b uniform): full rate, where the 32-bit v_mul_lo_u32 is quarter rate */
@@ -592,6 +604,7 @@ template <int LCAP, bool NEXT_NORMALS>
 __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     __shared__ fuse_lds<LCAP> L;
     const int tid = threadIdx.x;
+    FUSE_SETPRIO(FUSE_PRIO_START);
     if constexpr (NEXT_NORMALS && FUSE_CARRIES_NORMALS) {
     if ((int)blockIdx.x >= a.n_tiles) {                       /* the next frame's normals, in the tail of this launch */
         static_assert(sizeof(nrm_lds) <= sizeof(fuse_lds<LCAP>), "the normals tile works in the fusion table's LDS");
@@ -863,6 +876,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     nk = max(nk, __shfl_xor(nk, 32));
 #endif
     nk = __builtin_amdgcn_readfirstlane(nk);
+    FUSE_SETPRIO(FUSE_PRIO_WALK);                    /* the walk is instruction issue: it yields to waves that are in their flush or prologue */
     if (nk > 0 && __any(valid)) {                    /* waves without any valid pixel skip the walk */
         /* One sample per lane and iteration (2, 3, 4 or 6 samples in flight were measured slower: registers).  The loop
          * is bound by VALU issue when both workgroups of a CU walk, so it is written for instruction count: x and y go
@@ -986,6 +1000,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             }
         }
     }
+    FUSE_SETPRIO(FUSE_PRIO_FLUSH);                   /* the flush is a chain of round trips with few instructions between them */
     if (GSDF_EXPERIMENT(a.debug, 128) && lane == 0) {
         atomicAdd(&a.st->n_hit, (unsigned long long)dbg_go);
         atomicAdd(&a.st->dbg[0], (unsigned long long)dbg_full); atomicAdd(&a.st->dbg[1], (unsigned long long)dbg_lost);

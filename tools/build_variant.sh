@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/gradient-sdf_amd/csrc
 out=$src/variants
 tmp=$(mktemp -d)
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -mllvm -amdgpu-set-wave-priority"
 for f in gsdf_kernels gsdf_ba gsdf_capi gsdf_merge gsdf_sort; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $src/$f.hip -o $tmp/$f.o &
 done
