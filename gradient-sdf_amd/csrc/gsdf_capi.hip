@@ -233,7 +233,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
         if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("tracking launch: ") + hipGetErrorString(e));
         return GSDF_OK;
     }
-    int k = 0;
+    int k = 0, batch_no = 0;
     int batch = adaptive ? c->first_batch : iters + 1;
     while (k <= iters) {
         const int last = std::min(iters, k + batch - 1);
@@ -258,10 +258,17 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
             prof_scope ps(c, 2);
             gsdf_launch_track_pass(c->stream, g, depth_dev, c->tab, c->st, c->partials, c->track_blocks, tp, job);
         }
-        if (fuse_after) {
+        /* The fusion is queued behind the FIRST batch unseen (the usual frame ends there and must not wait for the host) and
+         * behind the last one (nothing follows it).  Behind the batches in between it would nearly always be a gated launch
+         * that finds optimize() still running -- 3 us each, 3 per frame that never converges -- so there it is queued only
+         * once the progress word says that optimize() has ended (the frame that converges late pays the host's look). */
+        bool fuse_queued = false;
+        if (fuse_after && (batch_no == 0 || last == iters || !c->lazy_fuse)) {
             const int rc = enqueue_fuse(c, depth_dev, unused, 1, true);           /* main_scan_3d.cpp:261-265 */
             if (rc) return rc;
+            fuse_queued = true;
         }
+        ++batch_no;
         if (last == iters) break;                            /* the head-only launch always ends optimize() */
         int ended = follow_progress(c, tp.serial, last);
         if (ended < 0) {                                     /* the device is far behind: wait for it properly */
@@ -271,7 +278,13 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
                 return fail(GSDF_ERR_HIP, "tracking: device state read failed");
             ended = s.done;
         }
-        if (ended) break;
+        if (ended) {
+            if (fuse_after && !fuse_queued) {
+                const int rc = enqueue_fuse(c, depth_dev, unused, 1, true);
+                if (rc) return rc;
+            }
+            break;
+        }
         batch = c->next_batch;
     }
     hipError_t e = hipGetLastError();
@@ -442,6 +455,7 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
             if (n >= 2 && b >= 0 && a + b <= 100) c->nrm_split2 = b;
         }
         if ((env = getenv("GSDF_NEXT_BATCH")) && atoi(env) >= 1) c->next_batch = atoi(env);
+        if ((env = getenv("GSDF_LAZY_FUSE"))) c->lazy_fuse = atoi(env);
         if ((env = getenv("GSDF_PERSIST"))) c->persist = atoi(env);
         if ((env = getenv("GSDF_FAR_TABLE"))) c->far_table = atoi(env);       /* experiments: 0 / 1 pin the fusion kernel's table size */
         if ((env = getenv("GSDF_GROW_CHECK_EVERY")) && atoi(env) >= 1) c->grow_check_every = atoi(env);   /* frames between two block counts of auto-grow */

@@ -117,6 +117,7 @@ struct gsdf_ctx {
     int first_batch = 5, next_batch = 8;           /* launches per batch: 5 cover the usual <= 4 passes + their last head; a frame that needs
                                                       more is most likely one that runs all 25 (pass counts on the bench stream: 142 x <= 6, 7 x 7..22,
                                                       51 x 25) -- batches of 8 behind the first: 6 656 -> 6 815 frames/s on the default window (4 / 12 / 21: 6 656 / 6 780 / 6 760) */
+    int lazy_fuse = 1;                             /* the frame's fusion is queued behind the first and the last batch of passes only; in between once optimize() has ended */
     unsigned long long* trace = nullptr;           /* test build: per-workgroup time stamps of k_fuse (gsdf_debug_flags & 64) */
     int debug = 0;                                 /* path-forcing / measurement switches (gsdf_debug_flags; test build only) */
     float* frame_log = nullptr;
