@@ -439,8 +439,10 @@ static_assert(FUSE_TH % 4 == 0 && FUSE_TH >= 8 && FUSE_TH <= 32, "tile height");
 #ifndef FUSE_STATS_AHEAD
 #define FUSE_STATS_AHEAD (FUSE_T == 16 && FUSE_TH == 16)
 #endif
-/* wave priorities inside k_fuse (s_setprio 0..3): two workgroups share a CU, one usually walking (VALU issue) while the other is
- * in a latency-bound phase whose few instructions should not queue behind the walk */
+/* Hand-placed wave priorities inside k_fuse (s_setprio 0..3 at the kernel's start, in front of the walk, in front of the flush):
+ * build parameters for the experiment only, default none.  The library is compiled with -amdgpu-set-wave-priority, which keeps a
+ * wave at priority 3 until its last batch of loads is issued (in k_fuse: up to the flush's record loads) and at 0 behind that:
+ * +2 % frames/s; every hand-placed ranking of the phases on top of it lost that gain again ("Kernels"). */
 #ifndef FUSE_PRIO_START
 #define FUSE_PRIO_START -1
 #endif
@@ -876,7 +878,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     nk = max(nk, __shfl_xor(nk, 32));
 #endif
     nk = __builtin_amdgcn_readfirstlane(nk);
-    FUSE_SETPRIO(FUSE_PRIO_WALK);                    /* the walk is instruction issue: it yields to waves that are in their flush or prologue */
+    FUSE_SETPRIO(FUSE_PRIO_WALK);                    /* (build experiment, default none: see FUSE_PRIO_*) */
     if (nk > 0 && __any(valid)) {                    /* waves without any valid pixel skip the walk */
         /* One sample per lane and iteration (2, 3, 4 or 6 samples in flight were measured slower: registers).  The loop
          * is bound by VALU issue when both workgroups of a CU walk, so it is written for instruction count: x and y go
@@ -1000,7 +1002,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             }
         }
     }
-    FUSE_SETPRIO(FUSE_PRIO_FLUSH);                   /* the flush is a chain of round trips with few instructions between them */
+    FUSE_SETPRIO(FUSE_PRIO_FLUSH);                   /* (build experiment, default none) */
     if (GSDF_EXPERIMENT(a.debug, 128) && lane == 0) {
         atomicAdd(&a.st->n_hit, (unsigned long long)dbg_go);
         atomicAdd(&a.st->dbg[0], (unsigned long long)dbg_full); atomicAdd(&a.st->dbg[1], (unsigned long long)dbg_lost);
