@@ -38,7 +38,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum" "
   rm -rf /tmp/pmc$i
   # --only-main: the fused+tracked windows and the roofline replays.  (The sharded flavour creates an RCCL communicator, and
   # rocprofv3's counter collection, which serialises dispatches, does not get along with RCCL's kernels: the pass hung.)
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc$i -o pmc -- $DRV --only-main > /dev/null 2> $out/rocprof_pmc$i.err
+  timeout 240 rocprofv3 --pmc $grp --output-format csv -d /tmp/pmc$i -o pmc -- $DRV --only-main > /dev/null 2> $out/rocprof_pmc$i.err
 done
 python $root/tools/pmc_summary.py /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4 /tmp/pmc5 > $out/pmc_counters.txt 2> $out/pmc_summary.err
 python $root/tools/pmc_summary.py --json "$DRV --only-main" --source "profiles/${tag}_pmc_counters.txt" /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 > $out/$PMCJSON 2>> $out/pmc_summary.err
