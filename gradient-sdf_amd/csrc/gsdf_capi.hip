@@ -596,9 +596,15 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     HIP_TRY(hipMemsetAsync(c->fuse_ticket, 0, 2 * sizeof(unsigned int), c->stream));
     c->frame_log_cap = 1 << 16;
     HIP_TRY(hipMalloc((void**)&c->frame_log, (size_t)c->frame_log_cap * 10 * sizeof(float)));
-    gsdf_launch_normals_cache(c->stream, W, H, c->K, win, c->planes);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        double* scratch = nullptr;                           /* the row sums of the six moment planes, in double */
+        HIP_TRY(hipMalloc((void**)&scratch, gsdf_normals_cache_scratch_bytes(W, H)));
+        gsdf_launch_normals_cache(c->stream, W, H, c->K, win, c->planes, scratch);
+        const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(c->stream);
+        (void)hipFree(scratch);
+        HIP_TRY(e1);
+        HIP_TRY(e2);
+    }
     return GSDF_OK;
 }
 

@@ -81,7 +81,9 @@ struct __attribute__((aligned(16))) gsdf_deferred {
 
 void gsdf_launch_table_clear(hipStream_t s, gsdf_table tab, size_t n_slots);
 void gsdf_launch_occ_rebuild(hipStream_t s, gsdf_table tab);      /* block / cell filters of the raycaster from the key array */
-void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int win, float* planes11);
+/* scratch: gsdf_normals_cache_scratch_bytes(W, H) of device memory, free again once the stream has run the two kernels */
+size_t gsdf_normals_cache_scratch_bytes(int W, int H);
+void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int win, float* planes11, double* scratch);
 void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const gsdf_ncache& nc,
                          const float* depth, float* nx, float* ny, float* nz,
                          unsigned int* deferred_count /* nullable: cleared for the k_fuse that follows */,

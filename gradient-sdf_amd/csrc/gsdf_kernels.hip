@@ -147,56 +147,97 @@ void gsdf_launch_occ_rebuild(hipStream_t s, gsdf_table tab) {
 }
 
 /* ------------------------------------------------------------------------------------------------
- * NormalEstimator::cache -- all in double, one thread per pixel, separable summation order
- * (row sums ascending dx, then ascending dy) identical to the oracle's box_sum.
+ * NormalEstimator::cache (NormalEstimator.h:81-154) -- all in double, once per context.
+ *
+ * The six moment planes go through cv::boxFilter(.., normalize = false) (:109-114), whose generic path keeps RUNNING
+ * sums in double (OpenCV 4 box_filter: RowSum  s += S[i+k] - S[i];  ColumnSum  s0 = SUM + Sp, SUM = s0 - Sm, down the
+ * whole image).  Q = M^-1 (:116-125) amplifies the last bits of M by the condition of an 11 x 11 window's moment matrix
+ * (1e8 and more): summed freshly per pixel instead, 10 % of the Q floats come out different and normals move by up to
+ * 1e-2 (measured).  So the cache is built in OpenCV's order -- two sequential scans, k_ncache_rows (one
+ * lane per image row and moment) and k_ncache_cols (one lane per image column, all six moments, then Q) -- identical,
+ * operation for operation, to the oracle's box_sum(mode 1).  It runs once; its time (~1 ms) does not matter.
  * ---------------------------------------------------------------------------------------------- */
-__global__ __launch_bounds__(256) void k_normals_cache(int W, int H, double fx_inv, double fy_inv, double cx,
-                                                       double cy, int r, float* __restrict__ out) {
-    const int u = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int v = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (u >= W || v >= H) return;
-    double M11 = 0, M12 = 0, M13 = 0, M22 = 0, M23 = 0, M33 = 0;
-    for (int dy = -r; dy <= r; ++dy) {
-        const int vv = reflect101(v + dy, H);
-        const double y = fy_inv * ((double)vv - cy);
-        const double y_sq = y * y;
-        double h11 = 0, h12 = 0, h13 = 0, h22 = 0, h23 = 0, h33 = 0;
-        for (int dx = -r; dx <= r; ++dx) {
-            const int uu = reflect101(u + dx, W);
-            const double x = fx_inv * ((double)uu - cx);
-            const double x_sq = x * x, xy = x * y;
-            const double n_sq = 1. + x_sq + y_sq;
-            const double ni = 1. / n_sq;
-            h11 += x_sq * ni; h12 += xy * ni; h13 += x * ni;
-            h22 += y_sq * ni; h23 += y * ni;  h33 += ni;
-        }
-        M11 += h11; M12 += h12; M13 += h13; M22 += h22; M23 += h23; M33 += h33;
+__device__ __forceinline__ double ncache_moment(int m, int u, int v, double fx_inv, double fy_inv, double cx, double cy) {
+    const double x = fx_inv * ((double)u - cx);                /* :94,98 */
+    const double y = fy_inv * ((double)v - cy);                /* :96,100 */
+    const double x_sq = x * x, y_sq = y * y;
+    const double n_sq = 1. + x_sq + y_sq;                      /* :104 */
+    const double ni = 1. / n_sq;                               /* :105 */
+    switch (m) {                                               /* :106-114 */
+    case 0: return x_sq * ni;
+    case 1: return (x * y) * ni;
+    case 2: return x * ni;
+    case 3: return y_sq * ni;
+    case 4: return y * ni;
+    default: return ni;
     }
-    const double det = M11 * (M22 * M33) + 2 * (M12 * (M23 * M13)) -
-                       (M13 * (M13 * M22) + M12 * (M12 * M33) + M23 * (M23 * M11));
-    const double det_inv = 1. / det;
-    const double x = fx_inv * ((double)u - cx);
-    const double y = fy_inv * ((double)v - cy);
-    const double n_sq = 1. + x * x + y * y;
-    const double ni = 1. / n_sq;
-    const size_t N = (size_t)W * H, i = (size_t)v * W + u;
-    out[0 * N + i] = (float)x;
-    out[1 * N + i] = (float)y;
-    out[2 * N + i] = (float)(x * ni);
-    out[3 * N + i] = (float)(y * ni);
-    out[4 * N + i] = (float)ni;
-    out[5 * N + i] = (float)(det_inv * (M22 * M33 - M23 * M23));
-    out[6 * N + i] = (float)(det_inv * (M13 * M23 - M12 * M33));
-    out[7 * N + i] = (float)(det_inv * (M12 * M23 - M13 * M22));
-    out[8 * N + i] = (float)(det_inv * (M11 * M33 - M13 * M13));
-    out[9 * N + i] = (float)(det_inv * (M12 * M13 - M11 * M23));
-    out[10 * N + i] = (float)(det_inv * (M11 * M22 - M12 * M12));
 }
-void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int win, float* planes11) {
+__global__ __launch_bounds__(64) void k_ncache_rows(int W, int H, double fx_inv, double fy_inv, double cx, double cy, int r,
+                                                    double* __restrict__ rows /* [6][H][W] */) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= 6 * H) return;
+    const int m = t / H, v = t - m * H, win = 2 * r + 1;
+    double* out = rows + ((size_t)m * H + v) * W;
+    /* RowSum over the BORDER_REFLECT_101-extended row: ext[i] = S[reflect101(i - r)] */
+    double s = 0.0;
+    for (int i = 0; i < win; ++i) s += ncache_moment(m, reflect101(i - r, W), v, fx_inv, fy_inv, cx, cy);
+    out[0] = s;
+    for (int i = 0; i < W - 1; ++i) {
+        s += ncache_moment(m, reflect101(i + win - r, W), v, fx_inv, fy_inv, cx, cy) -
+             ncache_moment(m, reflect101(i - r, W), v, fx_inv, fy_inv, cx, cy);
+        out[i + 1] = s;
+    }
+}
+__global__ __launch_bounds__(64) void k_ncache_cols(int W, int H, double fx_inv, double fy_inv, double cx, double cy, int r,
+                                                    const double* __restrict__ rows, float* __restrict__ out) {
+    const int u = blockIdx.x * 64 + threadIdx.x;
+    if (u >= W) return;
+    const size_t N = (size_t)W * H;
+    const int win = 2 * r + 1;
+    double SUM[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int j = 0; j < win - 1; ++j) {                        /* ColumnSum, first call: the first k - 1 rows of the window */
+        const size_t row = (size_t)reflect101(j - r, H) * W + u;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) SUM[m] += rows[m * N + row];
+    }
+    for (int v = 0; v < H; ++v) {
+        const size_t rp = (size_t)reflect101(v + r, H) * W + u, rm = (size_t)reflect101(v - r, H) * W + u;
+        double M[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const double s0 = SUM[m] + rows[m * N + rp];
+            M[m] = s0;
+            SUM[m] = s0 - rows[m * N + rm];
+        }
+        const double M11 = M[0], M12 = M[1], M13 = M[2], M22 = M[3], M23 = M[4], M33 = M[5];
+        const double det = M11 * (M22 * M33) + 2 * (M12 * (M23 * M13)) -
+                           (M13 * (M13 * M22) + M12 * (M12 * M33) + M23 * (M23 * M11));      /* :116-117 */
+        const double det_inv = 1. / det;                                                      /* :118 */
+        const double x = fx_inv * ((double)u - cx);
+        const double y = fy_inv * ((double)v - cy);
+        const double n_sq = 1. + x * x + y * y;
+        const double ni = 1. / n_sq;
+        const size_t i = (size_t)v * W + u;
+        out[0 * N + i] = (float)x;                                                            /* :128-132 */
+        out[1 * N + i] = (float)y;
+        out[2 * N + i] = (float)(x * ni);
+        out[3 * N + i] = (float)(y * ni);
+        out[4 * N + i] = (float)ni;
+        out[5 * N + i] = (float)(det_inv * (M22 * M33 - M23 * M23));                          /* :120-125 */
+        out[6 * N + i] = (float)(det_inv * (M13 * M23 - M12 * M33));
+        out[7 * N + i] = (float)(det_inv * (M12 * M23 - M13 * M22));
+        out[8 * N + i] = (float)(det_inv * (M11 * M33 - M13 * M13));
+        out[9 * N + i] = (float)(det_inv * (M12 * M13 - M11 * M23));
+        out[10 * N + i] = (float)(det_inv * (M11 * M22 - M12 * M12));
+    }
+}
+size_t gsdf_normals_cache_scratch_bytes(int W, int H) { return (size_t)6 * W * H * sizeof(double); }
+void gsdf_launch_normals_cache(hipStream_t s, int W, int H, const float* K, int win, float* planes11, double* scratch) {
     const double fx_inv = 1. / (double)K[0], fy_inv = 1. / (double)K[4];
-    dim3 grid((W + 31) / 32, (H + 7) / 8);
-    hipLaunchKernelGGL(k_normals_cache, grid, dim3(256), 0, s, W, H, fx_inv, fy_inv, (double)K[2], (double)K[5],
-                       win / 2, planes11);
+    hipLaunchKernelGGL(k_ncache_rows, dim3((6 * H + 63) / 64), dim3(64), 0, s, W, H, fx_inv, fy_inv, (double)K[2], (double)K[5],
+                       win / 2, scratch);
+    hipLaunchKernelGGL(k_ncache_cols, dim3((W + 63) / 64), dim3(64), 0, s, W, H, fx_inv, fy_inv, (double)K[2], (double)K[5],
+                       win / 2, (const double*)scratch, planes11);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1382,80 +1423,124 @@ void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st) { hipLaunchKernel
 #endif
 
 /* One Gauss-Newton step from the 29 sums (RigidPointOptimizer.cpp:86-98): solve, test, apply.  `passes` counts
- * this pass.  Identical arithmetic wherever it runs (every workgroup computes it redundantly). */
-/* The head's solve is executed by ONE wave whose 64 lanes would all do the same scalar work; it was 2.5 us of a 10 us
- * pass (~1900 dependent instructions: 6 correctly rounded square roots, 27 divisions, four sinf / cosf).  These two
- * helpers spread it over lanes WITHOUT changing a single operation or its order, so the result is bit-identical to
- * gsdf_llt_solve6 / gsdf_se3_exp_mul in every lane:
- *  - the Cholesky factorisation holds row i of L in lane i: column k of all rows (the dot product with row k, the
- *    division by the pivot) is one instruction sequence instead of 5 - k, the entries of row k reach the other lanes
- *    as wave-uniform values (v_readlane), which are also what the triangular solves then use;
- *  - sinf / cosf of theta / 2 and of theta are evaluated once, lanes with bit 0 set taking theta. */
+ * this pass.  Identical arithmetic wherever it runs (every workgroup computes it redundantly).
+ *
+ * The head's solve is executed by ONE wave whose 64 lanes all do the same scalar work, at the top of every launch with a
+ * cold instruction cache: through round 4 it reproduced gsdf_llt_solve6 / gsdf_se3_exp_mul bit for bit (6 correctly
+ * rounded square roots, 27 divisions, four full-range sinf / cosf: ~1 200 dependent instructions, 2.3-2.9 us of a 9.5 us
+ * pass) -- exactness that bought no parity, because its INPUTS already differ from the oracle's in their last bits
+ * (pairwise float / f64 group sums here, one sequential float sum there).  The common case is now the same algorithm in
+ * <= 1-ulp forms (trk_llt_solve6_fast, trk_se3_exp_mul_fast below): hardware reciprocal / reciprocal square root with one
+ * Newton step through FMA, FMA dot products, and sin / cos as short polynomials for rotation steps below 0.1 rad.  The
+ * exact forms stay for what the fast ones do not cover: a non-positive pivot (Eigen stops the factorisation there and
+ * solves on what it has), theta^2 below Sophus' epsilon (its series branch) and rotation steps of 0.1 rad or more. */
 __device__ __forceinline__ float trk_lane_value(float v, int lane_const) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
 }
-__device__ __forceinline__ void trk_llt_solve6_wave(const float* Hm, const float* g, float* x) {
-    const int lane = (int)(threadIdx.x & 63u);
-    float Lr[6];                                               /* row min(lane, 5) of the matrix being factorised */
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        float v = Hm[6 * 5 + j];
-#pragma unroll
-        for (int r = 4; r >= 0; --r) v = lane == r ? Hm[6 * r + j] : v;
-        Lr[j] = v;
-    }
-    float Lu[36];                                              /* the factor, wave-uniform; lower triangle used */
+/* 1 / x and 1 / sqrt(x): v_rcp_f32 / v_rsq_f32 (1 ulp) + one Newton step in FMA arithmetic => below 1 ulp */
+__device__ __forceinline__ float trk_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.f), r, r);
+}
+__device__ __forceinline__ float trk_rsq(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float e = __builtin_fmaf(-(x * r), 0.5f * r, 0.5f);      /* (1 - x r^2) / 2 */
+    return __builtin_fmaf(r, e, r);
+}
+/* H.llt().solve(g) (RigidPointOptimizer.cpp:86) in the structure of Eigen's unblocked llt_inplace and unrolled triangular
+ * solves -- pivot = A(k,k) - (sum of squares), column = (A21 - A20 * A10^T) / pivot root, rhs(i) = (rhs(i) - dot) / diagonal
+ * -- with the reciprocal root of the pivot kept in the diagonal, so that every division is a multiplication.
+ * Returns false (x untouched) when a pivot is not positive: the caller takes the exact path then. */
+__device__ __forceinline__ bool trk_llt_solve6_fast(const float* Hm, const float* g, float* x) {
+    float L[36];                                               /* lower triangle; L(k,k) holds 1 / sqrt(pivot) */
     bool positive = true;                                      /* every pivot so far was > 0 (or NaN) */
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        float s = Lr[k];                                       /* lane k: the pivot; lanes i > k: L(i,k) before the division */
+        float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < k; ++j) s -= Lr[j] * Lu[6 * k + j];
-        float d = trk_lane_value(s, k);
+        for (int j = 0; j < k; ++j) sq = __builtin_fmaf(L[6 * k + j], L[6 * k + j], sq);
+        const float d = Hm[6 * k + k] - sq;
         positive = positive && !(d <= 0.f);
-        d = sqrtf(d);
-        Lu[6 * k + k] = d;
-        const float q = s / d;
-        Lr[k] = lane > k ? q : Lr[k];
+        const float ri = trk_rsq(d);
+        L[6 * k + k] = ri;
 #pragma unroll
-        for (int i = k + 1; i < 6; ++i) Lu[6 * i + k] = trk_lane_value(Lr[k], i);
+        for (int i = k + 1; i < 6; ++i) {
+            float c = 0.f;
+#pragma unroll
+            for (int j = 0; j < k; ++j) c = __builtin_fmaf(L[6 * i + j], L[6 * k + j], c);
+            L[6 * i + k] = (Hm[6 * i + k] - c) * ri;
+        }
     }
-    if (!positive) {                   /* Eigen's llt_inplace stops at a non-positive pivot and the solves run on what is there: */
-        gsdf_llt_solve6(Hm, g, x);     /* rare (no overlap: all-zero H), and the straight-line code above assumed otherwise */
-        return;
-    }
+    if (!positive) return false;
     float y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        float s = g[i];
+        float c = 0.f;
 #pragma unroll
-        for (int j = 0; j < i; ++j) s -= Lu[6 * i + j] * y[j];
-        y[i] = s / Lu[6 * i + i];
+        for (int j = 0; j < i; ++j) c = __builtin_fmaf(L[6 * i + j], y[j], c);
+        y[i] = (g[i] - c) * L[6 * i + i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
-        float s = y[i];
+        float c = 0.f;
 #pragma unroll
-        for (int j = i + 1; j < 6; ++j) s -= Lu[6 * j + i] * x[j];
-        x[i] = s / Lu[6 * i + i];
+        for (int j = i + 1; j < 6; ++j) c = __builtin_fmaf(L[6 * j + i], x[j], c);
+        x[i] = (y[i] - c) * L[6 * i + i];
     }
+    return true;
 }
+/* The exact forms, spread over lanes WITHOUT changing a single operation or its order (bit-identical to gsdf_llt_solve6 /
+ * gsdf_se3_exp_mul in every lane).  Rare paths since round 5. */
 __device__ __forceinline__ void trk_se3_exp_mul_wave(const float* xi, float* pose7) {
     float trig[4] = { 0.f, 1.f, 0.f, 1.f };
     const float theta_sq = gsdf_se3_theta_sq(xi);
     if (!(theta_sq < GSDF_SOPHUS_EPS * GSDF_SOPHUS_EPS)) {
         const float theta = sqrtf(theta_sq), half = 0.5f * theta;
-        const float arg = (threadIdx.x & 1u) ? theta : half;
+        const float arg = (threadIdx.x & 1u) ? theta : half;   /* sinf / cosf of theta / 2 and of theta evaluated once: odd lanes take theta */
         const float sn = sinf(arg), cs = cosf(arg);
         trig[0] = trk_lane_value(sn, 0); trig[1] = trk_lane_value(cs, 0);
         trig[2] = trk_lane_value(sn, 1); trig[3] = trk_lane_value(cs, 1);
     }
     gsdf_se3_exp_mul_trig(xi, pose7, trig);
 }
+/* sin / cos for |x| < 0.1: Taylor polynomials whose first omitted terms are below 3e-14 / 3e-13 relative, in FMA Horner form */
+__device__ __forceinline__ float trk_sin_small(float x, float x2) {
+    float p = __builtin_fmaf(x2, -1.f / 5040.f, 1.f / 120.f);
+    p = __builtin_fmaf(x2, p, -1.f / 6.f);
+    return __builtin_fmaf(x, x2 * p, x);
+}
+__device__ __forceinline__ float trk_cos_small(float x2) {
+    float p = __builtin_fmaf(x2, -1.f / 720.f, 1.f / 24.f);
+    p = __builtin_fmaf(x2, p, -0.5f);
+    return __builtin_fmaf(x2, p, 1.f);
+}
+/* pose7 = SE3::exp(xi) * pose7 with Sophus' formulas as written (gsdf_se3_exp_mul_trig) in <= 1-ulp forms, for
+ * eps^2 <= theta^2 < 0.01; everything else goes through the exact path. */
+__device__ __forceinline__ void trk_se3_exp_mul_fast(const float* xi, float* pose7) {
+    const float theta_sq = gsdf_se3_theta_sq(xi);
+    if (__builtin_expect(!(theta_sq >= GSDF_SOPHUS_EPS * GSDF_SOPHUS_EPS && theta_sq < 0.01f), 0)) {
+        trk_se3_exp_mul_wave(xi, pose7);
+        return;
+    }
+    const float rth = trk_rsq(theta_sq);                       /* 1 / theta */
+    const float theta = theta_sq * rth, half = 0.5f * theta;
+    const float tsq = theta * theta, hsq = half * half;
+    const float rth2 = rth * rth;
+    const float imag = trk_sin_small(half, hsq) * rth;         /* sin(theta / 2) / theta */
+    const float real = trk_cos_small(hsq);
+    const float a = (1.f - trk_cos_small(tsq)) * rth2;         /* (1 - cos theta) / theta^2 */
+    const float b = (theta - trk_sin_small(theta, tsq)) * (rth2 * rth);   /* (theta - sin theta) / theta^3 */
+    float qn[4];
+    gsdf_se3_exp_mul_parts(xi, pose7, imag, real, false, a, b, qn);
+    const float rl = trk_rsq(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pose7[3 + i] = qn[i] * rl;
+}
 
 /* called by a full wave (all 64 lanes active, same arguments in every lane) */
 __device__ __forceinline__ void trk_solve_update(const float* tot, float damping, float conv_sq, int passes, int max_passes,
-                                                 int no_solve, float pose[7], int* done, int* converged) {
+                                                 int no_solve, bool exact_solve /* test build: the round-4 arithmetic */,
+                                                 float pose[7], int* done, int* converged) {
     float gvec[6], Hm[36];
 #pragma unroll
     for (int i = 0; i < 6; ++i) gvec[i] = tot[1 + i];
@@ -1466,7 +1551,8 @@ __device__ __forceinline__ void trk_solve_update(const float* tot, float damping
         for (int j = i; j < 6; ++j) { Hm[6 * i + j] = tot[q]; Hm[6 * j + i] = tot[q]; ++q; }
     float xi[6];
     if (no_solve) { for (int i = 0; i < 6; ++i) xi[i] = 1.f; }            /* experiment switch */
-    else trk_llt_solve6_wave(Hm, gvec, xi);                               /* RigidPointOptimizer.cpp:86 */
+    else if (exact_solve || __builtin_expect(!trk_llt_solve6_fast(Hm, gvec, xi), 0))
+        gsdf_llt_solve6(Hm, gvec, xi);                                    /* RigidPointOptimizer.cpp:86 */
 #pragma unroll
     for (int i = 0; i < 6; ++i) xi[i] = damping * xi[i];
     const float nrm = gsdf_sum3(xi[0] * xi[0], xi[1] * xi[1], xi[2] * xi[2]) +
@@ -1483,7 +1569,8 @@ __device__ __forceinline__ void trk_solve_update(const float* tot, float damping
             float mxi[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) mxi[i] = -xi[i];
-            trk_se3_exp_mul_wave(mxi, pose);
+            if (exact_solve) trk_se3_exp_mul_wave(mxi, pose);
+            else trk_se3_exp_mul_fast(mxi, pose);
         }
         if (passes >= max_passes) *done = 1;                              /* :98 return false */
     }
@@ -1707,7 +1794,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
                 float tot[GSDF_TRACK_NSUM];                               /* the 29 sums, in every lane */
 #pragma unroll
                 for (int i = 0; i < GSDF_TRACK_NSUM; ++i) tot[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(totv), i));
-                trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, GSDF_EXPERIMENT(tp.debug, 1), pose, &done, &converged);
+                trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, GSDF_EXPERIMENT(tp.debug, 1), GSDF_EXPERIMENT(tp.debug, 4), pose, &done, &converged);
                 if (trk_tr && threadIdx.x == 0) trk_tr[5] = wall_clock64() + (unsigned long long)(pose[0] != pose[0]);               /* solved */
                 if (blockIdx.x == 0 && tid == 0) {
                     gsdf_trk_buf& o = st->trk[k & 1];
@@ -1975,7 +2062,7 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK) void k_track_all(gsdf_frame_geom 
         }
         /* ---- one Gauss-Newton step (every wave of every workgroup computes it: identical bits) ---- */
         passes = k + 1;
-        trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, GSDF_EXPERIMENT(tp.debug, 1), pose, &done, &converged);
+        trk_solve_update(tot, tp.damping, tp.conv_sq, passes, tp.max_passes, GSDF_EXPERIMENT(tp.debug, 1), GSDF_EXPERIMENT(tp.debug, 4), pose, &done, &converged);
         hits = tot[28];
         hit_total += (unsigned long long)tot[28];
         if (trk_tr && tid == 0 && k < 12) trk_tr[16 * 512 * k + 4] = wall_clock64();        /* solved */

@@ -108,16 +108,50 @@ GSDF_HD void gsdf_R_to_quat(const float* m, float* q /*x y z w*/) {
 GSDF_HD float gsdf_se3_theta_sq(const float* xi) { return gsdf_sum3(xi[3] * xi[3], xi[4] * xi[4], xi[5] * xi[5]); }
 #define GSDF_SOPHUS_EPS 1e-5f                                   /* Sophus::Constants<float>::epsilon() */
 
+/* The part of pose7 = SE3::exp(xi) * pose7 behind the scalar coefficients (Sophus SE3::exp and the SE3 group product):
+ * imag / real = the quaternion factors of SO3::expAndTheta, V = so3.matrix() when theta_small, else I + a Om + b Om^2.
+ * Writes the new translation into pose7[0..2] and the product quaternion, NOT yet normalised, into qn. */
+GSDF_HD void gsdf_se3_exp_mul_parts(const float* xi, float* pose7, float imag, float real, bool theta_small, float a, float b,
+                                    float* qn) {
+    const gsdf_v3 ups = { xi[0], xi[1], xi[2] };
+    const gsdf_v3 om = { xi[3], xi[4], xi[5] };
+    const float qe[4] = { imag * om.x, imag * om.y, imag * om.z, real };
+    const float Om[9] = { 0.f, -om.z, om.y, om.z, 0.f, -om.x, -om.y, om.x, 0.f };
+    float Om2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            Om2[3 * i + j] = gsdf_sum3(Om[3 * i] * Om[j], Om[3 * i + 1] * Om[3 + j], Om[3 * i + 2] * Om[6 + j]);
+    float V[9];
+    if (theta_small) {
+        gsdf_quat_to_R(qe, V);
+    } else {
+        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + a * Om[i] + b * Om2[i];
+    }
+    const gsdf_v3 te = gsdf_matvec(V, ups);
+    const float ax = qe[0], ay = qe[1], az = qe[2], aw = qe[3];
+    const float bx = pose7[3], by = pose7[4], bz = pose7[5], bw = pose7[6];
+    qn[3] = aw * bw - ax * bx - ay * by - az * bz;
+    qn[0] = aw * bx + ax * bw + ay * bz - az * by;
+    qn[1] = aw * by + ay * bw + az * bx - ax * bz;
+    qn[2] = aw * bz + az * bw + ax * by - ay * bx;
+    const gsdf_v3 qv = { ax, ay, az };
+    const gsdf_v3 tt = { pose7[0], pose7[1], pose7[2] };
+    gsdf_v3 uv = gsdf_cross3(qv, tt);
+    uv.x += uv.x; uv.y += uv.y; uv.z += uv.z;
+    const gsdf_v3 c2 = gsdf_cross3(qv, uv);
+    pose7[0] = te.x + (tt.x + aw * uv.x + c2.x);
+    pose7[1] = te.y + (tt.y + aw * uv.y + c2.y);
+    pose7[2] = te.z + (tt.z + aw * uv.z + c2.z);
+}
+
 /* pose7 = SE3::exp(xi) * pose7 -- Sophus SO3::expAndTheta, SE3::exp and the SE3 group product
  * (RigidPointOptimizer.cpp:95 calls it with -xi).  pose7 = tx ty tz qx qy qz qw.
  * trig = { sinf(theta / 2), cosf(theta / 2), sinf(theta), cosf(theta) } with theta = sqrtf(theta_sq); read only when
- * theta_sq >= eps^2.  (The tracker's head evaluates the four in two lanes at once, trk_solve_update.) */
+ * theta_sq >= eps^2.  EXACT form: correctly rounded roots and divisions. */
 GSDF_HD void gsdf_se3_exp_mul_trig(const float* xi, float* pose7, const float* trig) {
     const float eps = GSDF_SOPHUS_EPS;
-    const gsdf_v3 ups = { xi[0], xi[1], xi[2] };
-    const gsdf_v3 om = { xi[3], xi[4], xi[5] };
     const float theta_sq = gsdf_se3_theta_sq(xi);
-    float theta, imag, real;
+    float theta, imag, real, a = 0.f, b = 0.f;
     if (theta_sq < eps * eps) {
         theta = 0.f;
         const float theta_po4 = theta_sq * theta_sq;
@@ -128,40 +162,15 @@ GSDF_HD void gsdf_se3_exp_mul_trig(const float* xi, float* pose7, const float* t
         imag = trig[0] / theta;
         real = trig[1];
     }
-    const float qe[4] = { imag * om.x, imag * om.y, imag * om.z, real };
-    const float Om[9] = { 0.f, -om.z, om.y, om.z, 0.f, -om.x, -om.y, om.x, 0.f };
-    float Om2[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            Om2[3 * i + j] = gsdf_sum3(Om[3 * i] * Om[j], Om[3 * i + 1] * Om[3 + j], Om[3 * i + 2] * Om[6 + j]);
-    float V[9];
-    if (theta < eps) {
-        gsdf_quat_to_R(qe, V);
-    } else {
+    if (!(theta < eps)) {
         const float tsq = theta * theta;
-        const float a = (1.f - trig[3]) / tsq;
-        const float b = (theta - trig[2]) / (tsq * theta);
-        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + a * Om[i] + b * Om2[i];
+        a = (1.f - trig[3]) / tsq;
+        b = (theta - trig[2]) / (tsq * theta);
     }
-    const gsdf_v3 te = gsdf_matvec(V, ups);
-    const float ax = qe[0], ay = qe[1], az = qe[2], aw = qe[3];
-    const float bx = pose7[3], by = pose7[4], bz = pose7[5], bw = pose7[6];
     float qn[4];
-    qn[3] = aw * bw - ax * bx - ay * by - az * bz;
-    qn[0] = aw * bx + ax * bw + ay * bz - az * by;
-    qn[1] = aw * by + ay * bw + az * bx - ax * bz;
-    qn[2] = aw * bz + az * bw + ax * by - ay * bx;
+    gsdf_se3_exp_mul_parts(xi, pose7, imag, real, theta < eps, a, b, qn);
     const float len = sqrtf(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
-    for (int i = 0; i < 4; ++i) qn[i] /= len;
-    const gsdf_v3 qv = { ax, ay, az };
-    const gsdf_v3 tt = { pose7[0], pose7[1], pose7[2] };
-    gsdf_v3 uv = gsdf_cross3(qv, tt);
-    uv.x += uv.x; uv.y += uv.y; uv.z += uv.z;
-    const gsdf_v3 c2 = gsdf_cross3(qv, uv);
-    pose7[0] = te.x + (tt.x + aw * uv.x + c2.x);
-    pose7[1] = te.y + (tt.y + aw * uv.y + c2.y);
-    pose7[2] = te.z + (tt.z + aw * uv.z + c2.z);
-    pose7[3] = qn[0]; pose7[4] = qn[1]; pose7[5] = qn[2]; pose7[6] = qn[3];
+    for (int i = 0; i < 4; ++i) pose7[3 + i] = qn[i] / len;
 }
 GSDF_HD void gsdf_se3_exp_mul(const float* xi, float* pose7) {
     float trig[4] = { 0.f, 1.f, 0.f, 1.f };
@@ -173,9 +182,22 @@ GSDF_HD void gsdf_se3_exp_mul(const float* xi, float* pose7) {
     gsdf_se3_exp_mul_trig(xi, pose7, trig);
 }
 
-/* x = H^-1 g by Cholesky (Eigen H.llt().solve(g), RigidPointOptimizer.cpp:86).  H is the full
- * symmetric 6x6, row-major.  A non-positive pivot stops the factorisation like Eigen's
- * llt_inplace; the triangular solves still run (=> inf/NaN for an all-zero H). */
+/* x = H^-1 g by Cholesky (Eigen H.llt().solve(g), RigidPointOptimizer.cpp:86), in the operation order of Eigen 3.4's
+ * published algorithm: unblocked llt_inplace -- pivot x = A(k,k) - (sum of squares, formed first), column
+ * A21 = (A21 - (A20 * A10^T, each dot product formed first)) / x -- and the completely unrolled triangular solves,
+ * rhs(i) = (rhs(i) - (dot product, Eigen's halving scalar redux)) / diagonal.  H is the full symmetric 6x6, row-major.
+ * A non-positive pivot stops the factorisation like Eigen's llt_inplace; the triangular solves still run (=> inf/NaN
+ * for an all-zero H).  This is the EXACT form (correctly rounded divisions and roots): the host side of the ABI and the
+ * rare non-positive-pivot case of the tracker's head use it; the head's common case is trk_llt_solve6_fast. */
+GSDF_HD float gsdf_tree_sum(const float* t, int n) {            /* redux_novec_unroller: [0,n) = [0,n/2) + [n/2,n) */
+    switch (n) {
+    case 1: return t[0];
+    case 2: return t[0] + t[1];
+    case 3: return t[0] + (t[1] + t[2]);
+    case 4: return (t[0] + t[1]) + (t[2] + t[3]);
+    default: return (t[0] + t[1]) + (t[2] + (t[3] + t[4]));
+    }
+}
 GSDF_HD void gsdf_llt_solve6(const float* Hin, const float* g, float* x) {
     float L[36];
 GSDF_UNROLL
@@ -183,32 +205,46 @@ GSDF_UNROLL
 GSDF_UNROLL
     for (int k = 0; k < 6; ++k) {
         float d = L[6 * k + k];
+        if (k > 0) {
+            float sq = L[6 * k] * L[6 * k];
 GSDF_UNROLL
-        for (int j = 0; j < k; ++j) d -= L[6 * k + j] * L[6 * k + j];
+            for (int j = 1; j < k; ++j) sq = sq + L[6 * k + j] * L[6 * k + j];
+            d -= sq;
+        }
         if (d <= 0.f) break;
         d = sqrtf(d);
         L[6 * k + k] = d;
 GSDF_UNROLL
         for (int i = k + 1; i < 6; ++i) {
             float s = L[6 * i + k];
+            if (k > 0) {
+                float c = L[6 * i] * L[6 * k];
 GSDF_UNROLL
-            for (int j = 0; j < k; ++j) s -= L[6 * i + j] * L[6 * k + j];
+                for (int j = 1; j < k; ++j) c = c + L[6 * i + j] * L[6 * k + j];
+                s -= c;
+            }
             L[6 * i + k] = s / d;
         }
     }
-    float y[6];
+    float t[5];
 GSDF_UNROLL
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 6; ++i) {                              /* L y = g, in place in x */
         float s = g[i];
+        if (i > 0) {
 GSDF_UNROLL
-        for (int j = 0; j < i; ++j) s -= L[6 * i + j] * y[j];
-        y[i] = s / L[6 * i + i];
+            for (int j = 0; j < i; ++j) t[j] = L[6 * i + j] * x[j];
+            s -= gsdf_tree_sum(t, i);
+        }
+        x[i] = s / L[6 * i + i];
     }
 GSDF_UNROLL
-    for (int i = 5; i >= 0; --i) {
-        float s = y[i];
+    for (int i = 5; i >= 0; --i) {                             /* L^T x = y */
+        float s = x[i];
+        if (i < 5) {
 GSDF_UNROLL
-        for (int j = i + 1; j < 6; ++j) s -= L[6 * j + i] * x[j];
+            for (int j = i + 1; j < 6; ++j) t[j - i - 1] = L[6 * j + i] * x[j];
+            s -= gsdf_tree_sum(t, 5 - i);
+        }
         x[i] = s / L[6 * i + i];
     }
 }

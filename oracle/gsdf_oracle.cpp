@@ -14,8 +14,19 @@
  *     the order produced by Eigen 3.4's unrolled scalar redux (redux_novec_unroller
  *     splits [0,3) into [0,1) and [1,3));  Eigen itself is absent here.
  *   - box filter = separable double-precision sums, row pass (ascending dx) then
- *     column pass (ascending dy), BORDER_REFLECT_101, result rounded to float
- *     (OpenCV's float boxFilter accumulates in double: sumType CV_64F).
+ *     column pass (ascending dy), BORDER_REFLECT_101, result rounded to float.
+ *     OpenCV's boxFilter accumulates in double (sumType CV_64F) with RUNNING sums (RowSum:
+ *     s += S[i+k] - S[i]; ColumnSum: SUM += Sp, SUM -= Sm down the image).  The cached planes
+ *     of NormalEstimator::cache follow that order (box_sum mode 1: the matrix inverse behind
+ *     them amplifies the sums' last bits); the per-frame filters of ::compute form a FRESH sum
+ *     of their 11 inputs per output (mode 0), which is NOT OpenCV's order but gives the same
+ *     floats (the two differ by ~1e-16 relative before the rounding to float; counted in
+ *     tests/test_oracle_known_answers.py).
+ *   - H.llt().solve(g): Eigen's unblocked llt_inplace + unrolled triangular solves in
+ *     their published operation order (see llt_solve6); the packetisation of Eigen's
+ *     reductions under the reference's flags is not knowable here.
+ * "Bit-exact occupancy" everywhere in this repository therefore means bit-exact against
+ * THIS reading of the absent libraries' arithmetic.
  */
 #include "gsdf_oracle.h"
 #include "../include/gsdf_mc_tables.h"   /* constant data: the classic marching-cubes case tables */
@@ -95,11 +106,51 @@ static inline int reflect101(int i, int n) {                 /* cv::BORDER_REFLE
     return i;
 }
 
-/* unnormalised box sum, double accumulation, separable (row then column) */
+/* unnormalised box sum, double accumulation, separable (row then column).
+ * mode 0: every output is a fresh sum of its 11 (win) inputs, ascending offset.
+ * mode 1: the summation order of OpenCV 4's generic FilterEngine
+ *   path for cv::boxFilter(.., normalize=false) on CV_32F / CV_64F (imgproc/src/box_filter.simd.hpp; sumType CV_64F):
+ *   RowSum      s = S[0] + .. + S[k-1];  D[0] = s;  then  s += S[i+k] - S[i];  D[i+1] = s        (running, per row)
+ *   ColumnSum   SUM = rows[0] + .. + rows[k-2];  per output row  s0 = SUM + Sp;  D = s0;  SUM = s0 - Sm   (running,
+ *               down the whole image: the filter object keeps SUM between FilterEngine::proceed calls)
+ *   over the BORDER_REFLECT_101-extended rows / row list.  Whether a reference build takes this path (and not IPP's or an
+ *   OpenCL one) depends on how its OpenCV was built -- not knowable here; the library is absent.
+ * DEFINITION the HIP kernels copy: the one-off cached planes (NormalEstimator::cache) use mode 1 -- Q = M^-1 amplifies the
+ * last bits of the sums by 1e8 and more, the order matters there (10 % of the Q floats, normals up to 1e-2) -- and the
+ * per-frame filters of NormalEstimator::compute use mode 0, which gives the same floats as mode 1 there (a 1e-16 difference
+ * in double only shows in rare double roundings; counted by tests/test_oracle_known_answers.py). */
 template <typename Tin>
-static void box_sum(const Tin* src, double* dst, int W, int H, int win) {
+static void box_sum(const Tin* src, double* dst, int W, int H, int win, int mode = 0) {
     const int r = win / 2;
     std::vector<double> rows((size_t)W * H);
+    if (mode == 1) {
+        std::vector<double> ext((size_t)W + 2 * r), SUM((size_t)W);
+        for (int y = 0; y < H; ++y) {
+            for (int i = 0; i < W + 2 * r; ++i) ext[i] = (double)src[(size_t)y * W + reflect101(i - r, W)];
+            double s = 0.0;
+            for (int i = 0; i < win; ++i) s += ext[i];
+            rows[(size_t)y * W] = s;
+            for (int i = 0; i < W - 1; ++i) {
+                s += ext[i + win] - ext[i];
+                rows[(size_t)y * W + i + 1] = s;
+            }
+        }
+        std::fill(SUM.begin(), SUM.end(), 0.0);
+        for (int j = 0; j < win - 1; ++j) {
+            const double* Sp = &rows[(size_t)reflect101(j - r, H) * W];
+            for (int x = 0; x < W; ++x) SUM[x] += Sp[x];
+        }
+        for (int y = 0; y < H; ++y) {
+            const double* Sp = &rows[(size_t)reflect101(y + r, H) * W];
+            const double* Sm = &rows[(size_t)reflect101(y - r, H) * W];
+            for (int x = 0; x < W; ++x) {
+                const double s0 = SUM[x] + Sp[x];
+                dst[(size_t)y * W + x] = s0;
+                SUM[x] = s0 - Sm[x];
+            }
+        }
+        return;
+    }
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
             double s = 0.0;
@@ -131,6 +182,9 @@ struct gsdfo {
     int W = 0, H = 0, win = 0;
     std::vector<float> x0_, y0_, x0n_, y0n_, ninv_, Q11_, Q12_, Q13_, Q22_, Q23_, Q33_;
     int threads = 4;
+    /* summation order of the box filters (see box_sum): the cached planes follow OpenCV's running sums, the per-frame
+     * filters sum freshly (measured to give the same floats); the other settings exist for measuring the difference */
+    int box_mode_cache = 1, box_mode_frame = 0;
 
     /* Sdf::truncate -- Sdf.h:72-74 */
     float truncate(float sdf) const { return std::max(-T_, std::min(T_, sdf)); }
@@ -169,6 +223,7 @@ gsdfo* gsdfo_create(float voxel_size, float T) {
 void gsdfo_destroy(gsdfo* o) { delete o; }
 void gsdfo_set_zrange(gsdfo* o, float zmin, float zmax) { o->z_min_ = zmin; o->z_max_ = zmax; }
 void gsdfo_set_threads(gsdfo* o, int threads) { o->threads = threads > 0 ? threads : 1; }
+void gsdfo_set_box_mode(gsdfo* o, int cache_mode, int frame_mode) { o->box_mode_cache = cache_mode == 1; o->box_mode_frame = frame_mode == 1; }
 
 /* NormalEstimator::cache -- NormalEstimator.h:81-154 (all in double, then cast to float) */
 int gsdfo_normals_init(gsdfo* o, int W, int H, const float K[9], int win) {
@@ -194,12 +249,12 @@ int gsdfo_normals_init(gsdfo* o, int W, int H, const float K[9], int win) {
             m11[i] = x_sq * ni; m12[i] = xy * ni; m22[i] = y_sq * ni;   /* :109,110,112 */
         }
     std::vector<double> M11(N), M12(N), M13(N), M22(N), M23(N), M33(N);
-    box_sum(m11.data(), M11.data(), W, H, win);              /* :109-114 */
-    box_sum(m12.data(), M12.data(), W, H, win);
-    box_sum(x0n.data(), M13.data(), W, H, win);
-    box_sum(m22.data(), M22.data(), W, H, win);
-    box_sum(y0n.data(), M23.data(), W, H, win);
-    box_sum(ninv.data(), M33.data(), W, H, win);
+    box_sum(m11.data(), M11.data(), W, H, win, o->box_mode_cache);              /* :109-114 */
+    box_sum(m12.data(), M12.data(), W, H, win, o->box_mode_cache);
+    box_sum(x0n.data(), M13.data(), W, H, win, o->box_mode_cache);
+    box_sum(m22.data(), M22.data(), W, H, win, o->box_mode_cache);
+    box_sum(y0n.data(), M23.data(), W, H, win, o->box_mode_cache);
+    box_sum(ninv.data(), M33.data(), W, H, win, o->box_mode_cache);
     o->x0_.resize(N); o->y0_.resize(N); o->x0n_.resize(N); o->y0n_.resize(N); o->ninv_.resize(N);
     o->Q11_.resize(N); o->Q12_.resize(N); o->Q13_.resize(N); o->Q22_.resize(N); o->Q23_.resize(N); o->Q33_.resize(N);
     for (size_t i = 0; i < N; ++i) {
@@ -239,9 +294,9 @@ void gsdfo_normals_compute(const gsdfo* o, const float* depth, float* nx, float*
         p3[i] = o->ninv_[i] * zi;
     }
     std::vector<double> b1(N), b2(N), b3(N);
-    box_sum(p1.data(), b1.data(), W, H, o->win);
-    box_sum(p2.data(), b2.data(), W, H, o->win);
-    box_sum(p3.data(), b3.data(), W, H, o->win);
+    box_sum(p1.data(), b1.data(), W, H, o->win, o->box_mode_frame);
+    box_sum(p2.data(), b2.data(), W, H, o->win, o->box_mode_frame);
+    box_sum(p3.data(), b3.data(), W, H, o->win, o->box_mode_frame);
     for (size_t i = 0; i < N; ++i) {
         const float c1 = (float)b1[i], c2 = (float)b2[i], c3 = (float)b3[i];
         const float x = (c1 * o->Q11_[i] + c2 * o->Q12_[i]) + c3 * o->Q13_[i];   /* :195-197 */
@@ -729,36 +784,72 @@ void gsdfo_se3_exp_mul(const float xi[6], float pose7[7]) {
     pose7[3] = qn[0]; pose7[4] = qn[1]; pose7[5] = qn[2]; pose7[6] = qn[3];
 }
 
-/* 6x6 LLT solve restating Eigen's unblocked llt_inplace<float,Lower> + triangular solves.
- * On a non-positive pivot Eigen stops the factorisation and solve() still runs on what is
- * there (=> inf/NaN for an all-zero H, SURVEY.md gotcha 9). */
+/* 6x6 LLT solve: H.llt().solve(g) (RigidPointOptimizer.cpp:86), restated from Eigen 3.4's PUBLISHED algorithm
+ * (Eigen itself is absent here; file names are Eigen's):
+ *  - factorisation = llt_inplace<float, Lower>::unblocked (Cholesky/LLT.h; the blocked form hands sizes < 32 to it):
+ *      x = A(k,k);  if (k > 0) x -= A10.squaredNorm();      the sum of squares is formed FIRST, then one subtraction
+ *      if (x <= 0) return k;  A(k,k) = x = sqrt(x);
+ *      if (k > 0 && rs > 0) A21.noalias() -= A20 * A10.adjoint();   a gemv: res_i += (-1) * (sum_j A(i,j) * A(k,j)), the dot
+ *                                                                   product formed first from 0, columns ascending
+ *      if (rs > 0) A21 /= x;                                        a division per element
+ *    A10 is a strided row of a column-major matrix (no packet access) => its redux is the sequential scalar one.
+ *  - solves = triangular_solver_unroller (SolveTriangular.h; a 6-vector right-hand side is <= 8 => CompleteUnrolling):
+ *      rhs(i) -= (row segment of the factor . rhs segment).sum();   the dot product first, then one subtraction
+ *      rhs(i) /= diagonal;
+ *    the fixed-size .sum() is Eigen's unrolled scalar redux, which halves the range recursively
+ *    (redux_novec_unroller: [0,n) -> [0,n/2) + [n/2,n)) -- the convention already used for the 3-term sums above.
+ * NOT knowable without the library and the reference's compiler flags: whether the contiguous segments of the upper
+ * solve (columns of L) are summed through SSE packets instead; this statement uses the scalar tree for both solves.
+ * On a non-positive pivot Eigen stops the factorisation and solve() still runs on what is there
+ * (=> inf/NaN for an all-zero H, SURVEY.md gotcha 9). */
+static float tree_sum(const float* t, int n) {           /* redux_novec_unroller<.., Start, Length> */
+    if (n == 1) return t[0];
+    const int half = n / 2;
+    return tree_sum(t, half) + tree_sum(t + half, n - half);
+}
 static void llt_solve6(const float Hin[36], const float g[6], float x[6]) {
     float L[36];
     std::memcpy(L, Hin, sizeof(L));
     for (int k = 0; k < 6; ++k) {
         float d = L[6 * k + k];
-        for (int j = 0; j < k; ++j) d -= L[6 * k + j] * L[6 * k + j];
+        if (k > 0) {
+            float sq = L[6 * k] * L[6 * k];
+            for (int j = 1; j < k; ++j) sq = sq + L[6 * k + j] * L[6 * k + j];
+            d -= sq;
+        }
         if (d <= 0.f) break;
         d = std::sqrt(d);
         L[6 * k + k] = d;
         for (int i = k + 1; i < 6; ++i) {
             float s = L[6 * i + k];
-            for (int j = 0; j < k; ++j) s -= L[6 * i + j] * L[6 * k + j];
+            if (k > 0) {
+                float c = L[6 * i] * L[6 * k];
+                for (int j = 1; j < k; ++j) c = c + L[6 * i + j] * L[6 * k + j];
+                s -= c;
+            }
             L[6 * i + k] = s / d;
         }
     }
-    float y[6];
-    for (int i = 0; i < 6; ++i) {          /* L y = g */
+    float t[5];
+    for (int i = 0; i < 6; ++i) {          /* L y = g, in place in x */
         float s = g[i];
-        for (int j = 0; j < i; ++j) s -= L[6 * i + j] * y[j];
-        y[i] = s / L[6 * i + i];
+        if (i > 0) {
+            for (int j = 0; j < i; ++j) t[j] = L[6 * i + j] * x[j];
+            s -= tree_sum(t, i);
+        }
+        x[i] = s / L[6 * i + i];
     }
     for (int i = 5; i >= 0; --i) {         /* L^T x = y */
-        float s = y[i];
-        for (int j = i + 1; j < 6; ++j) s -= L[6 * j + i] * x[j];
+        float s = x[i];
+        if (i < 5) {
+            for (int j = i + 1; j < 6; ++j) t[j - i - 1] = L[6 * j + i] * x[j];
+            s -= tree_sum(t, 5 - i);
+        }
         x[i] = s / L[6 * i + i];
     }
 }
+
+void gsdfo_llt_solve6(const float H36[36], const float g[6], float x[6]) { llt_solve6(H36, g, x); }
 
 /* RigidPointOptimizer::optimize_sampled(depth, K, sampling=1) -- RigidPointOptimizer.cpp:40-99 */
 int gsdfo_track(gsdfo* o, const float* depth, const float K[9], float pose7[7],

@@ -40,6 +40,10 @@ void   gsdfo_set_zrange(gsdfo* o, float zmin, float zmax);
 /* threads used by the *_omp variants (fusion: parallel for + critical, as
  * MapGradPixelSdfOmp.cpp:82,112; tracker: reduction, RigidPointOptimizerOmp.cpp:68-69) */
 void   gsdfo_set_threads(gsdfo* o, int threads);
+/* box-filter summation order (0 = a fresh double sum per output, 1 = OpenCV's running sums: RowSum / ColumnSum of the
+ * generic FilterEngine path), separately for the cached planes (default 1) and the per-frame filters (default 0, same
+ * floats as 1 there).  For measuring the differences; takes effect at the next gsdfo_normals_init / _compute. */
+void   gsdfo_set_box_mode(gsdfo* o, int cache_mode, int frame_mode);
 
 /* cv::NormalEstimator<float>(W, H, K, Size(win,win)) -> cache()  -- NormalEstimator.h:81-165 */
 int    gsdfo_normals_init(gsdfo* o, int W, int H, const float K[9], int win);
@@ -96,6 +100,7 @@ int    gsdfo_track(gsdfo* o, const float* depth, const float K[9], float pose7[7
 void   gsdfo_quat_to_R(const float q_xyzw[4], float R[9]);       /* Eigen Quaternion::toRotationMatrix */
 void   gsdfo_R_to_quat(const float R[9], float q_xyzw[4]);       /* Eigen Quaternion(Matrix3) */
 void   gsdfo_se3_exp_mul(const float xi[6], float pose7[7]);     /* pose = SE3::exp(xi) * pose */
+void   gsdfo_llt_solve6(const float H36[36], const float g[6], float x[6]);   /* H.llt().solve(g), Eigen's order */
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,8 @@ def lib():
         L.gsdfo_destroy.argtypes = [C.c_void_p]
         L.gsdfo_set_zrange.argtypes = [C.c_void_p, C.c_float, C.c_float]
         L.gsdfo_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.gsdfo_set_box_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.gsdfo_llt_solve6.argtypes = [fp, fp, fp]
         L.gsdfo_normals_init.restype = C.c_int
         L.gsdfo_normals_init.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, C.c_int]
         L.gsdfo_normals_cache.argtypes = [C.c_void_p, fp]
@@ -79,9 +81,12 @@ def _fp(a):
 class Oracle:
     """CPU restatement of MapGradPixelSdf + RigidPointOptimizer + NormalEstimator."""
 
-    def __init__(self, voxel_size, trunc_dist, W, H, K, win=11, zmin=0.5, zmax=3.5, threads=4):
+    def __init__(self, voxel_size, trunc_dist, W, H, K, win=11, zmin=0.5, zmax=3.5, threads=4, box_mode=(1, 0)):
+        """box_mode = (cached planes, per-frame filters): 1 = OpenCV's running box sums, 0 = a fresh sum per output.
+        (1, 0) is the definition; the other settings exist to measure what the summation order changes."""
         self.L = lib()
         self.h = self.L.gsdfo_create(np.float32(voxel_size), np.float32(trunc_dist))
+        self.L.gsdfo_set_box_mode(self.h, int(box_mode[0]), int(box_mode[1]))
         self.W, self.H = int(W), int(H)
         self.K = _f32(K).reshape(9)
         self.L.gsdfo_set_zrange(self.h, np.float32(zmin), np.float32(zmax))
@@ -214,6 +219,15 @@ def R_to_quat(R):
     q = np.empty(4, np.float32)
     lib().gsdfo_R_to_quat(_fp(R), _fp(q))
     return q
+
+
+def llt_solve6(H, g):
+    """H.llt().solve(g) in the oracle's statement of Eigen's operation order (float32)."""
+    H = _f32(H).reshape(36)
+    g = _f32(g).reshape(6)
+    x = np.empty(6, np.float32)
+    lib().gsdfo_llt_solve6(_fp(H), _fp(g), _fp(x))
+    return x
 
 
 def se3_exp_mul(xi, pose7):

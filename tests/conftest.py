@@ -13,6 +13,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU test of a few minutes (skipped with GSDF_SKIP_SLOW=1)")
 
 
 @pytest.fixture(scope="session")

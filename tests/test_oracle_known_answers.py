@@ -405,3 +405,102 @@ def test_oracle_extract_pc_plane_known_answer(O):
     g = np.float32(1.2)
     assert np.allclose(rows[0], [0, 0, 0 - np.float32(0.004) * g, 0, 0, -g], atol=1e-7)
     assert np.allclose(rows[1], [np.float32(0.06), 0 + np.float32(0.008) * g, 0, 0, -g, 0], atol=1e-7)
+
+
+# ---- round 5: the restatements of absent third-party arithmetic, measured ---------------------------------------------------
+
+def test_llt_solve6_solves_and_follows_eigens_order(O):
+    """H.llt().solve(g) (RigidPointOptimizer.cpp:86) as restated from Eigen's unblocked llt_inplace + unrolled triangular solves:
+    (1) it solves -- against numpy's double solve on well-conditioned tracker-like systems; (2) it is the published operation
+    order -- a float32 numpy transcription of that order (pivot = a_kk - (sum of squares formed first), column = (a_ik - dot
+    formed first) / pivot root, rhs_i = (rhs_i - halving-tree dot) / diagonal) reproduces it bit for bit; (3) an all-zero H
+    yields NaN (SURVEY.md gotcha 9)."""
+    f = np.float32
+    rng = np.random.default_rng(5)
+
+    def tree(t):
+        n = len(t)
+        if n == 1:
+            return t[0]
+        h = n // 2
+        return f(tree(t[:h]) + tree(t[h:]))
+
+    def eigen_order(H, g):
+        L = H.astype(f).copy()
+        for k in range(6):
+            d = L[k, k]
+            if k > 0:
+                sq = f(L[k, 0] * L[k, 0])
+                for j in range(1, k):
+                    sq = f(sq + f(L[k, j] * L[k, j]))
+                d = f(d - sq)
+            d = f(np.sqrt(d))
+            L[k, k] = d
+            for i in range(k + 1, 6):
+                s = L[i, k]
+                if k > 0:
+                    c = f(L[i, 0] * L[k, 0])
+                    for j in range(1, k):
+                        c = f(c + f(L[i, j] * L[k, j]))
+                    s = f(s - c)
+                L[i, k] = f(s / d)
+        x = g.astype(f).copy()
+        for i in range(6):
+            s = x[i]
+            if i > 0:
+                s = f(s - tree([f(L[i, j] * x[j]) for j in range(i)]))
+            x[i] = f(s / L[i, i])
+        for i in range(5, -1, -1):
+            s = x[i]
+            if i < 5:
+                s = f(s - tree([f(L[j, i] * x[j]) for j in range(i + 1, 6)]))
+            x[i] = f(s / L[i, i])
+        return x
+
+    for _ in range(100):
+        J = rng.normal(size=(60, 6)) * np.array([1, 1, 1, 3, 3, 3])
+        H = (J.T @ J).astype(f)
+        g = rng.normal(size=6).astype(f)
+        x = O.llt_solve6(H, g)
+        ref = np.linalg.solve(H.astype(np.float64), g.astype(np.float64))
+        assert np.abs(x - ref).max() <= 2e-5 * np.abs(ref).max()
+        assert np.array_equal(x.view(np.uint32), eigen_order(H, g).view(np.uint32))
+    assert np.isnan(O.llt_solve6(np.zeros((6, 6)), np.ones(6))).all()
+
+
+def test_box_filter_summation_order_measured(pkg, O):
+    """NormalEstimator.h:109-114,191-193 call cv::boxFilter, whose generic path keeps RUNNING double sums (RowSum / ColumnSum);
+    OpenCV is absent, so the order is restated (oracle/gsdf_oracle.cpp box_sum) and its effect MEASURED here:
+      * cached planes (NormalEstimator::cache): Q = M^-1 amplifies the sums' last bits -- fresh sums change ~10 % of the Q
+        floats and move normals by up to ~1e-2, enough to flip gates of MapGradPixelSdf.cpp:95,98 on a handful of pixels.  The
+        definition therefore follows OpenCV's running order there (box mode (1, .), the GPU's k_ncache_rows / k_ncache_cols);
+      * per-frame filters (::compute): running and fresh sums differ by ~1e-16 relative before the rounding to float; on these
+        frames not one normal changes a bit, no gate flips, the maps are identical -- the definition (and the GPU's tiled
+        kernel) sums freshly there (box mode (., 0)).
+    "Bit-exact occupancy" in this repository means: against this reading of the absent libraries."""
+    W, H, n = 320, 240, 2
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=0)
+    vs = np.float32(0.02)
+    T = np.float32(5) * vs
+    defn = O.Oracle(vs, T, W, H, seq.K)                         # (1, 0): the definition
+    run = O.Oracle(vs, T, W, H, seq.K, box_mode=(1, 1))         # OpenCV's order everywhere
+    fresh = O.Oracle(vs, T, W, H, seq.K, box_mode=(0, 0))       # fresh sums everywhere (rounds 1-4)
+    c_def, c_run, c_fresh = defn.normals_cache(), run.normals_cache(), fresh.normals_cache()
+    assert np.array_equal(c_def.view(np.uint32), c_run.view(np.uint32))
+    q_diff = int((c_def[5:].view(np.uint32) != c_fresh[5:].view(np.uint32)).sum())
+    assert np.array_equal(c_def[:5].view(np.uint32), c_fresh[:5].view(np.uint32))       # the five direct planes have no sums
+    assert q_diff > 0.01 * c_def[5:].size                       # the order MATTERS for Q (measured: ~10 % of the floats at 640x480)
+    worst = 0.0
+    for i in range(n):
+        d, R, t = seq.frame(i)
+        n_def, n_run, n_fresh = defn.normals(d), run.normals(d), fresh.normals(d)
+        ok = np.isfinite(n_def) & np.isfinite(n_run)
+        assert np.array_equal(n_def[ok].view(np.uint32), n_run[ok].view(np.uint32))     # per frame: not one bit
+        ok = np.isfinite(n_def) & np.isfinite(n_fresh)
+        worst = max(worst, float(np.abs(n_def - n_fresh)[ok].max()))
+        assert defn.update(d, R, t) == run.update(d, R, t)      # N_upd, N_valid: no gate flips
+        fresh.update(d, R, t)
+    k_def, p_def = defn.export()
+    k_run, p_run = run.export()
+    assert np.array_equal(k_def, k_run) and np.array_equal(p_def.view(np.uint32), p_run.view(np.uint32))
+    assert 1e-6 < worst < 5e-2                                  # what fresh sums in the CACHE do to normals (1e-2 at 640x480)
