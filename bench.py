@@ -65,6 +65,9 @@ def parse_args():
                     help="frames PER RANK of the sharded GT-pose flavour (8 ranks x 250 = the 2000 frames of BASELINE configs[3]); 0 = skip")
     ap.add_argument("--raycast-reps", type=int, default=10, help="raycasts of the bench map timed for roofline.raycast (0 = skip)")
     ap.add_argument("--no-staged", action="store_true", help="skip the staging-inclusive flavour (config.staged_fps)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip config.default_window (frames 21..220 of the same stream) and config.c3 (BASELINE configs[2])")
+    ap.add_argument("--extras-timeout", type=float, default=150.0, help="seconds the two extra configurations may take before the line is printed without them")
     ap.add_argument("--only-main", action="store_true", help="fused+tracked windows and the roofline replays only (profiling runs)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--single-device", action="store_true",
@@ -181,6 +184,7 @@ def main():
         args.raycast_reps = 0
         args.cpu_frames = 0
         args.no_staged = True
+        args.no_extras = True
 
     W, H = args.width, args.height
     K, Wm = args.steps, args.warmup
@@ -196,6 +200,16 @@ def main():
         c4_seq, c4_frames = render_frames("spheres", W, H, range(rank * F, (rank + 1) * F), seed=0, n_frames=total,
                                           step_deg=360.0 * 4 / 2000)       # 2000 frames = 4 orbits (tools/run_c4.py)
         c4 = {"seq": c4_seq, "frames": c4_frames, "F": F, "total": total}
+
+    # the two other single-GPU configurations under the driver's clock: N = 1, BASELINE's headline arguments only
+    extras_in = None
+    is_headline = ((W, H) == (640, 480) and abs(float(vs) - 0.01) < 1e-6 and args.trunc == 10.0 and args.hash_capacity_log2 == 22)
+    if world == 1 and not args.no_extras and is_headline:
+        DW_WARM, DW_K = 20, 200                              # bench.py's own default window: frames 21..220
+        dw_seq, dw_frames = render_frames("tum", W, H, range(1 + DW_WARM + DW_K), seed=rank, n_frames=1 + DW_WARM + DW_K)
+        C3_W, C3_H, C3_WARM, C3_K = 1280, 960, 5, 20         # configs[2] on the driver's window
+        c3_seq, c3_frames = render_frames("tum", C3_W, C3_H, range(1 + C3_WARM + C3_K), seed=rank, n_frames=1 + C3_WARM + C3_K)
+        extras_in = {"dw": (dw_seq, dw_frames, DW_WARM, DW_K), "c3": (c3_seq, c3_frames, C3_WARM, C3_K, C3_W, C3_H)}
 
     # torch first: libgsdf binds to the HIP runtime already in the process (gradient-sdf_amd/binding.py)
     import torch
@@ -576,6 +590,7 @@ def main():
             W, H, cm, args.trunc, args.hash_capacity_log2)
 
     printed = threading.Lock()
+    extras = {}
 
     def emit(sharded):
         """Rank 0 prints THE line (once); everything it needs is known before the sharded flavour starts."""
@@ -614,6 +629,9 @@ def main():
                     "staged_runs": [round(total_frames / r, 1) for r in staged_runs] if staged_runs else None,
                     "staged_same_passes_as_resident": staged_same if staged_runs else None,
                     "raycast_us": raycast["avg_launch_us"] if raycast else None,
+                    # the same engine on the other two single-GPU windows / configurations, timed like `value` (never `value`)
+                    "default_window": extras.get("default_window"),
+                    "c3": extras.get("c3"),
                     "sharded": sharded,
                 },
                 "roofline": {
@@ -641,6 +659,24 @@ def main():
             print(json.dumps(out))
             sys.stdout.flush()
 
+    # ---- the other two single-GPU numbers, under the same clock as `value` (and the same kind of watchdog as the sharded flavour) ----
+    if extras_in is not None:
+        def give_up_extras():
+            extras.setdefault("default_window", {"error": "did not finish within %.0f s" % args.extras_timeout})
+            extras.setdefault("c3", {"error": "did not finish within %.0f s" % args.extras_timeout})
+            emit({"error": "skipped: the extra configurations did not finish in time"} if c4 is not None else None)
+            os._exit(0)
+        dog_x = threading.Timer(args.extras_timeout, give_up_extras)
+        dog_x.daemon = True
+        dog_x.start()
+        for name, fn in (("default_window", lambda: default_window_flavour(pkg, args, extras_in["dw"], local_rank, vs, T, W, H)),
+                         ("c3", lambda: c3_flavour(pkg, args, extras_in["c3"], local_rank))):
+            try:
+                extras[name] = fn()
+            except Exception as e:                              # noqa: BLE001 -- the headline line must still be printed
+                extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        dog_x.cancel()
+
     # ---- the flavour that shards: GT-pose fusion of frame shards + ONE all-reduce of the per-voxel sums (configs[3]) ------
     # It is the only part of the run with a data-path collective on a communicator of its own.  The headline numbers are
     # complete before it starts, so a watchdog bounds it: if the exchange does not come back (a fabric or RCCL problem on
@@ -661,6 +697,93 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     emit(sharded)
+
+
+def _tracked_windows(g, dev, frames, Wm, K, repeats):
+    """`repeats` timed windows of K tracked + fused frames behind frame 0 (GT pose) and Wm untimed frames, as in main():
+    returns (seconds per window, the frame log rows of the timed frames of the last window, stats before / after it)."""
+    d0, R0, t0 = frames[0]
+    p0 = np.concatenate([t0, pkg_quat(R0)]).astype(np.float32)
+
+    def start():
+        g.reset()
+        g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
+        g.set_pose(p0)
+        for i in range(1, 1 + Wm):
+            g.track_and_fuse_dev(dev[i])
+    runs, st_w = [], None
+    for rep in range(1 + repeats):                            # one whole window untimed first
+        start()
+        g.sync()
+        st_w = g.stats()
+        t_start = time.perf_counter()
+        for i in range(1 + Wm, 1 + Wm + K):
+            g.track_and_fuse_dev(dev[i])
+        g.sync()
+        if rep:
+            runs.append(time.perf_counter() - t_start)
+    return runs, g.frame_log()[Wm:Wm + K], st_w, g.stats(), p0
+
+
+def pkg_quat(R):
+    import __graft_entry__ as graft
+    return graft.package().synth.R_to_quat_np(R).astype(np.float32)
+
+
+def default_window_flavour(pkg, args, dw, local_rank, vs, T, W, H):
+    """config.default_window: frames 21..220 of the SAME stream as `value` (bench.py's own default --steps 200 --warmup 20), on
+    which a quarter of the frames runs all 25 passes and is not fused ("Non-converging frames")."""
+    seq, frames, Wm, K = dw
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=args.hash_capacity_log2, device=local_rank)
+    dev = [g.upload(f[0]) for f in frames]
+    runs, timed, _, _, _ = _tracked_windows(g, dev, frames, Wm, K, 3)
+    g.close()
+    el = float(np.median(runs))
+    return {"frames": "%d..%d of the stream `value` is timed on (= python bench.py without arguments)" % (1 + Wm, Wm + K),
+            "fps": round(K / el, 1), "runs": [round(K / r, 1) for r in runs], "ms_per_frame": round(el / K * 1e3, 4),
+            "converged_frames": int(timed[:, 7].sum()), "frames_total": K, "mean_tracker_passes": round(float(timed[:, 8].mean()), 2)}
+
+
+def c3_flavour(pkg, args, c3, local_rank):
+    """config.c3: BASELINE configs[2] -- the S-tum stream at 1280x960, 5 mm voxels, trunc 10, capacity 2^25 (1 GiB of voxel
+    records: outside the Infinity Cache) -- on the driver's window (frames 6..25), with k_fuse's roofline figures measured the
+    same way as the headline's (HIP events around the executed launches of a replay of the same frames at the same poses)."""
+    seq, frames, Wm, K, W, H = c3
+    vs = np.float32(0.005)
+    T = np.float32(10.0) * vs
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=25, device=local_rank)
+    dev = [g.upload(f[0]) for f in frames]
+    runs, timed, _, _, p0 = _tracked_windows(g, dev, frames, Wm, K, 3)
+    log = g.frame_log()
+    poses = log[:, :7].copy()
+    g.reset()
+    g.update_dev(dev[0], quat_to_R(p0[3:]), frames[0][2])
+    for i in range(1, 1 + Wm):
+        if log[i - 1, 7] > 0:
+            g.update_dev(dev[i], quat_to_R(poses[i - 1, 3:]), poses[i - 1, :3])
+    g.sync()
+    st_a = g.stats()
+    g.profile(1)
+    n_fuse = 0
+    for i in range(1 + Wm, 1 + Wm + K):
+        if log[i - 1, 7] > 0:
+            g.update_dev(dev[i], quat_to_R(poses[i - 1, 3:]), poses[i - 1, :3])
+            n_fuse += 1
+    g.sync()
+    prof = g.profile_read()
+    g.profile(0)
+    st_b = g.stats()
+    g.close()
+    fuse_ms = prof["fusion"]["ms"] / max(prof["fusion"]["launches"], 1)
+    n_upd = (st_b["n_upd"] - st_a["n_upd"]) / max(n_fuse, 1)
+    alg = 16.0 * W * H + 52.0 * n_upd
+    ach = alg / (fuse_ms * 1e-3) / 1e9 if fuse_ms > 0 else 0.0
+    el = float(np.median(runs))
+    return {"workload": "S-stress: the S-tum stream at 1280x960, 5 mm voxels, trunc 10, capacity 2^25 (BASELINE.json configs[2]), frames %d..%d" % (1 + Wm, Wm + K),
+            "fps": round(K / el, 1), "runs": [round(K / r, 1) for r in runs], "ms_per_frame": round(el / K * 1e3, 4),
+            "converged_frames": int(timed[:, 7].sum()), "frames_total": K, "mean_tracker_passes": round(float(timed[:, 8].mean()), 2),
+            "k_fuse_us": round(fuse_ms * 1e3, 2), "k_fuse_launches": int(prof["fusion"]["launches"]),
+            "algorithmic_bytes_per_launch": round(alg), "achieved_gbs": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
 
 
 def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, W, H, coll_dev):

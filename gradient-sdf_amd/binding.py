@@ -128,6 +128,7 @@ def load(path=None):
         "gsdf_merge_prepare": (C.c_int, [vp, C.c_int]),
         "gsdf_grow": (C.c_int, [vp, C.c_int]),
         "gsdf_set_auto_grow": (C.c_int, [vp, C.c_int]),
+        "gsdf_capacity": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "gsdf_merge_raw": (C.c_int, [vp, i32p, fp, C.c_int64]),
         "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
@@ -179,7 +180,7 @@ ABI_SYMBOLS = [
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
     "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
-    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow", "gsdf_merge_prepare",
+    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow", "gsdf_capacity", "gsdf_merge_prepare",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
     "gsdf_merge_allreduce", "gsdf_merge_allreduce_with", "gsdf_rccl_unique_id", "gsdf_rccl_comm_init", "gsdf_rccl_comm_count",
@@ -415,6 +416,11 @@ class GradSdf:
 
     def grow(self, new_capacity_log2):
         self._chk(self.L.gsdf_grow(self.h, int(new_capacity_log2)))
+
+    def capacity_log2(self):
+        v = C.c_int(0)
+        self._chk(self.L.gsdf_capacity(self.h, C.byref(v)))
+        return v.value
 
     def set_auto_grow(self, max_capacity_log2):
         self._chk(self.L.gsdf_set_auto_grow(self.h, int(max_capacity_log2)))

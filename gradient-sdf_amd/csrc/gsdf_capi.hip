@@ -91,18 +91,76 @@ static int fuse_far_table(const gsdf_ctx* c) {
     return c->progress && c->progress[3] * 16u > (unsigned int)c->fuse_blocks ? 1 : 0;
 }
 
-/* Auto-grow (gsdf_set_auto_grow): called at the top of the frame entries.  The count in progress[4] lags by a few frames -- a
- * hint that only has to arrive before the key array is ~95 % full (where the probe budget runs out): the table is doubled
- * once 45 % of its block entries are in use.  Synchronous when it happens (a few 100 us per doubling, a handful of times
- * per scan). */
+/* Auto-grow (gsdf_set_auto_grow): called at the top of the frame entries (gsdf_update_dev, gsdf_track_and_fuse_dev).
+ *
+ * The table is doubled once 45 % of its block entries are in use (the probe budget runs out near 95 %).  The load is the
+ * count a 64-workgroup kernel leaves in a pinned word; it is enqueued at the top of EVERY entry, tagged with the entry's
+ * number, and read without waiting -- so the number the host sees is some entries old, and the host may run ahead of the
+ * device (an unsynchronised gsdf_update_dev loop).  What keeps the doubling in time:
+ *  - the age of the count is known (the tag), and so is how fast the map grew lately (max over the recent counts, decaying):
+ *    while  count + 2 x (entries not covered) x (blocks per frame)  stays below the 45 % the host does not wait;
+ *  - otherwise, and whenever the count is more than grow_max_lag (8) entries old, the entry waits: for the lag it polls the
+ *    pinned word (the device keeps running, no bubble); for the load it flushes, counts and synchronises -- the EXACT load
+ *    decides the doubling;
+ *  - until two counts have been seen (the first entries of a scan, after a reset or a doubling) every entry is exact: a
+ *    first frame that fills half the table is seen before the second one is queued.
+ * What remains possible: ONE frame that adds more blocks than the table has room for (more than half its entries beyond the
+ * 45 %) still sets the sticky GSDF_STATUS_TABLE_FULL -- its samples are dropped where the probes run out, which no later
+ * doubling can undo.  Size the initial table for at least two frames' blocks (the CLI's 2^22 holds 65 536 blocks, a
+ * 640x480 frame at 1 cm touches ~9 000). */
 static int auto_grow_step(gsdf_ctx* c) {
     if (!c->auto_grow_max || !c->progress) return GSDF_OK;
-    const size_t cap_blocks = c->n_slots / GSDF_BLOCK_VOX;
-    if (c->capacity_log2 < c->auto_grow_max && (size_t)c->progress[4] * 100u > cap_blocks * 45u) {
-        const int rc = gsdf_grow_impl(c, c->capacity_log2 + 1);
-        if (rc) return rc;
+    volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(c->progress + 4);
+    if (c->grow_forget) {                                   /* a reset or a doubling: the counts so far describe another table */
+        c->grow_forget = false;
+        c->grow_seq = 0; c->grow_prev_seq = 0; c->grow_prev_cnt = 0; c->grow_rate = 0; c->grow_counts_seen = 0;
+        HIP_TRY(hipStreamSynchronize(c->stream));           /* no count kernel of the old numbering is in flight any more */
+        *word = 0ull;
     }
-    if (--c->grow_countdown <= 0) { c->grow_countdown = c->grow_check_every; gsdf_enqueue_block_count(c); }
+    const unsigned int k = ++c->grow_seq;
+    const size_t cap_blocks = c->n_slots / GSDF_BLOCK_VOX;
+    auto look = [&](unsigned int& cnt, unsigned int& seen) {
+        const unsigned long long w = *word;
+        cnt = (unsigned int)(w & 0xFFFFFFFFull); seen = (unsigned int)(w >> 32);
+        if (seen > c->grow_prev_seq) {                       /* a newer finished count: update the growth per frame */
+            if (c->grow_counts_seen > 0) {
+                const unsigned int d = cnt > c->grow_prev_cnt ? cnt - c->grow_prev_cnt : 0u, n = seen - c->grow_prev_seq;
+                const unsigned int rate = (d + n - 1) / n;
+                c->grow_rate = std::max(rate, c->grow_rate - c->grow_rate / 16u);
+            }
+            c->grow_prev_seq = seen; c->grow_prev_cnt = cnt; ++c->grow_counts_seen;
+        }
+    };
+    unsigned int cnt = 0, seen = 0;
+    look(cnt, seen);
+    /* the count tagged `seen` was enqueued at the top of entry `seen`: it holds the fusions of the entries before it, except
+     * one that a pipelined gsdf_update_dev still kept back => entries seen - 1 ... k - 1 are not in it */
+    unsigned int uncovered = k - seen + 1;
+    if (c->grow_counts_seen >= 2 && (int)uncovered > c->grow_max_lag + 1) {
+        /* far ahead of the device: wait for it to come within grow_max_lag / 2 entries (it is working; nothing is drained) */
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((int)(k - seen) > c->grow_max_lag / 2) {
+            look(cnt, seen);
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        }
+        uncovered = k - seen + 1;
+    }
+    const bool safe = c->grow_counts_seen >= 2 && (int)uncovered <= c->grow_max_lag + 1 &&
+                      ((size_t)cnt + 2u * (size_t)uncovered * std::max(c->grow_rate, 1u)) * 100u <= cap_blocks * 45u;
+    if (!safe && c->capacity_log2 < c->auto_grow_max) {
+        int rc = gsdf_flush_pending(c);                      /* a fusion kept back by the pipelined path counts too */
+        if (rc) return rc;
+        gsdf_enqueue_block_count(c, k);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        ++c->grow_syncs;
+        look(cnt, seen);
+        if ((size_t)cnt * 100u > cap_blocks * 45u) {
+            rc = gsdf_grow_impl(c, c->capacity_log2 + 1);    /* (sets grow_forget: the next entry starts the bookkeeping afresh) */
+            if (rc) return rc;
+        }
+        return GSDF_OK;
+    }
+    gsdf_enqueue_block_count(c, k);
     return GSDF_OK;
 }
 
@@ -458,7 +516,7 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
         if ((env = getenv("GSDF_LAZY_FUSE"))) c->lazy_fuse = atoi(env);
         if ((env = getenv("GSDF_PERSIST"))) c->persist = atoi(env);
         if ((env = getenv("GSDF_FAR_TABLE"))) c->far_table = atoi(env);       /* experiments: 0 / 1 pin the fusion kernel's table size */
-        if ((env = getenv("GSDF_GROW_CHECK_EVERY")) && atoi(env) >= 1) c->grow_check_every = atoi(env);   /* frames between two block counts of auto-grow */
+        if ((env = getenv("GSDF_GROW_MAX_LAG")) && atoi(env) >= 1) c->grow_max_lag = atoi(env);   /* auto-grow: entries the host may be ahead of the newest count */
     }
     int rc = gsdf_reset(c);
     if (rc != GSDF_OK) { gsdf_destroy(c); return rc; }
@@ -510,7 +568,7 @@ int gsdf_reset(gsdf_ctx* c) {
         HIP_TRY(hipMemsetAsync(c->blk_counters, 0, (size_t)c->fuse_blocks * 4 * sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->merged = false;
-    if (c->progress) c->progress[4] = 0u;                    /* auto-grow's block count (a grown table keeps its size) */
+    c->grow_forget = true;                                   /* auto-grow's block counts describe the old map (a grown table keeps its size) */
     c->occ_dirty = false;                                    /* the table clear zeroed the filters as well */
     return GSDF_OK;
 }
@@ -527,7 +585,13 @@ int gsdf_set_auto_grow(gsdf_ctx* c, int max_capacity_log2) {
     }
     if (max_capacity_log2 && !c->progress) return fail(GSDF_ERR_HIP, "gsdf_set_auto_grow: no pinned progress words on this context");
     c->auto_grow_max = max_capacity_log2;
-    c->grow_countdown = 0;
+    c->grow_forget = true;
+    return GSDF_OK;
+}
+
+int gsdf_capacity(gsdf_ctx* c, int* capacity_log2) {
+    if (!c || !capacity_log2) return fail(GSDF_ERR_INVALID, "null argument");
+    *capacity_log2 = c->capacity_log2;
     return GSDF_OK;
 }
 

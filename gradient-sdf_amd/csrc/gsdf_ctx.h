@@ -16,7 +16,7 @@
 
 #define GSDF_SCRATCH_BYTES (256 * 1024)
 #define GSDF_MX_BUFS 8
-#define GSDF_GROW_CHECK_EVERY_DEFAULT 8   /* frames between two counts of the existing blocks (auto-grow) */
+#define GSDF_GROW_MAX_LAG_DEFAULT 8       /* auto-grow: frame entries the host may be ahead of the newest finished block count */
 #define GSDF_PROF_SLOTS 5     /* gsdf_profile: 0 normals, 1 fusion, 2 tracking launches, 3 raycast, 4 tracker (whole optimize) */
 
 inline thread_local std::string g_gsdf_err;
@@ -24,7 +24,7 @@ inline thread_local std::string g_gsdf_err;
 struct gsdf_ctx;
 int gsdf_flush_pending(gsdf_ctx* c);               /* gsdf_capi.hip: launch the deferred GT-pose fusion, if one waits */
 int gsdf_grow_impl(gsdf_ctx* c, int new_capacity_log2);      /* gsdf_merge.hip: rehash into a larger table */
-void gsdf_enqueue_block_count(gsdf_ctx* c);        /* gsdf_merge.hip: existing blocks -> pinned word progress[4] */
+void gsdf_enqueue_block_count(gsdf_ctx* c, unsigned int tag);   /* gsdf_merge.hip: existing blocks | tag << 32 -> pinned words progress[4..5] */
 
 inline int gsdf_fail(int code, const std::string& msg) {
     g_gsdf_err = msg;
@@ -88,7 +88,13 @@ struct gsdf_ctx {
      * named a limit -- every few fusions the number of existing blocks is counted into a pinned word, and a frame entry that
      * finds the key array more than GSDF_GROW_LOAD full doubles the table first */
     int auto_grow_max = 0;                         /* largest capacity_log2 auto-grow may reach; 0 = off */
-    int grow_countdown = 0, grow_check_every = GSDF_GROW_CHECK_EVERY_DEFAULT;
+    unsigned int grow_seq = 0;                     /* frame entries since auto-grow was switched on / the map was reset or grown */
+    unsigned int grow_prev_seq = 0, grow_prev_cnt = 0;   /* the newest finished count the growth rate was updated from */
+    unsigned int grow_rate = 0;                    /* blocks a frame added lately (max over recent counts, decaying) */
+    int grow_counts_seen = 0;                      /* finished counts seen since grow_seq restarted (the rate needs two) */
+    bool grow_forget = false;                      /* set by gsdf_grow / gsdf_reset: restart the bookkeeping above */
+    int grow_max_lag = GSDF_GROW_MAX_LAG_DEFAULT;
+    long long grow_syncs = 0;                      /* entries that had to wait for an exact count (statistics for the tests) */
     unsigned int* grow_scratch = nullptr;          /* two device words of k_count_blocks */
     bool merged = false;                           /* gsdf_merge_allreduce has run: the map is the sum of all ranks (one-shot) */
     struct mx_buf { void* p = nullptr; size_t bytes = 0; } mx[GSDF_MX_BUFS];   /* scratch of the exchange (gsdf_merge.hip): grows, never shrinks */

@@ -388,8 +388,10 @@ __global__ __launch_bounds__(256) void k_rehash(gsdf_table from, gsdf_table to, 
     pd[0] = ps[0]; pd[1] = ps[1];
     for (int w = 0; w < vw; ++w) vis_to[dst * vw + w] = vis_from[src * vw + w];
 }
-/* occupied entries of the key array -> one pinned host word (auto-grow: the host looks at it without waiting) */
-__global__ __launch_bounds__(256) void k_count_blocks(const unsigned long long* bkeys, size_t n, unsigned int* scratch, unsigned int* host_word) {
+/* occupied entries of the key array -> one pinned 64-bit host word, count | tag << 32 (auto-grow: the host looks at it without
+ * waiting; the tag is the number of the frame entry that enqueued this count, so the host knows how old the number is) */
+__global__ __launch_bounds__(256) void k_count_blocks(const unsigned long long* bkeys, size_t n, unsigned int* scratch,
+                                                      unsigned long long* host_word, unsigned int tag) {
     __shared__ unsigned int part[4];
     unsigned int c = 0u;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += bkeys[i] != GSDF_KEY_EMPTY ? 1u : 0u;
@@ -400,7 +402,8 @@ __global__ __launch_bounds__(256) void k_count_blocks(const unsigned long long* 
         atomicAdd(&scratch[0], part[0] + part[1] + part[2] + part[3]);
         __threadfence();
         if (atomicAdd(&scratch[1], 1u) + 1u == gridDim.x) {               /* the last workgroup publishes and resets */
-            __hip_atomic_store(host_word, __hip_atomic_load(&scratch[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long cnt = __hip_atomic_load(&scratch[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_word, cnt | ((unsigned long long)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&scratch[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&scratch[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -409,12 +412,13 @@ __global__ __launch_bounds__(256) void k_count_blocks(const unsigned long long* 
 
 } // namespace
 
-/* enqueue the count of existing blocks into the pinned word progress[4] (gsdf_capi.hip calls it every few fusions when
- * auto-grow is on) */
-void gsdf_enqueue_block_count(gsdf_ctx* c) {
+/* enqueue the count of existing blocks into the pinned words progress[4..5] (gsdf_capi.hip: at the top of every frame entry
+ * while auto-grow is on), tagged with the entry's number */
+void gsdf_enqueue_block_count(gsdf_ctx* c, unsigned int tag) {
     if (!c->progress_dev || !c->grow_scratch) return;
     const size_t cap = c->n_slots / GSDF_BLOCK_VOX;
-    hipLaunchKernelGGL(k_count_blocks, dim3(64), dim3(256), 0, c->stream, c->tab.bkeys, cap, c->grow_scratch, c->progress_dev + 4);
+    hipLaunchKernelGGL(k_count_blocks, dim3(64), dim3(256), 0, c->stream, c->tab.bkeys, cap, c->grow_scratch,
+                       reinterpret_cast<unsigned long long*>(c->progress_dev + 4), tag);
     (void)hipGetLastError();
 }
 
@@ -439,14 +443,39 @@ int gsdf_grow_impl(gsdf_ctx* c, int new_capacity_log2) {
         return gsdf_fail(GSDF_ERR_HIP, std::string("gsdf_grow: ") + hipGetErrorString(e));      /* the map is untouched */
     }
     nt.block_mask = (uint32_t)(n_new / GSDF_BLOCK_VOX - 1);
+    /* A sticky GSDF_STATUS_TABLE_FULL from an earlier fusion must not stop the map from growing: the rehash into an
+     * empty, larger table reports its own failure through the same bit, so the bit is looked at before and after.  (The old
+     * error stays sticky -- samples WERE dropped -- and gsdf_sync keeps reporting it until gsdf_reset.)  Every failure path
+     * below releases the new table. */
+    gsdf_dev_state s0, s1;
+    auto bail = [&](hipError_t err, const char* what) {
+        (void)hipStreamSynchronize(c->stream);                 /* nothing may still write into the buffers that are freed */
+        release();
+        (void)hipGetLastError();
+        return gsdf_fail(GSDF_ERR_HIP, std::string("gsdf_grow: ") + what + ": " + hipGetErrorString(err));
+    };
+    if ((e = hipMemcpy(&s0, c->st, sizeof(s0), hipMemcpyDeviceToHost)) != hipSuccess) return bail(e, "reading the status");
+    const int full_before = s0.status & GSDF_STATUS_TABLE_FULL;
+    if (full_before) {                                         /* cleared for the rehash, restored below */
+        const int cleared = s0.status & ~GSDF_STATUS_TABLE_FULL;
+        if ((e = hipMemcpy(&c->st->status, &cleared, sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "clearing the status");
+    }
     gsdf_launch_table_clear(c->stream, nt, n_new);
-    if (nvis) HIP_TRY(hipMemsetAsync(nvis, 0, n_new * (size_t)c->vis_words * sizeof(uint32_t), c->stream));
+    if (nvis && (e = hipMemsetAsync(nvis, 0, n_new * (size_t)c->vis_words * sizeof(uint32_t), c->stream)) != hipSuccess) return bail(e, "clearing vis_");
     const size_t nb_old = c->n_slots / GSDF_BLOCK_VOX;
     hipLaunchKernelGGL(k_rehash, dim3((unsigned int)((nb_old + 3) / 4)), dim3(256), 0, c->stream, c->tab, nt, c->vis, nvis, c->vis ? c->vis_words : 0,
                        nb_old, c->st);
-    HIP_TRY(hipGetLastError());
-    int rc = read_status(c);                                   /* synchronises */
-    if (rc) { release(); return rc; }
+    if ((e = hipGetLastError()) != hipSuccess) return bail(e, "launching the rehash");
+    if ((e = hipMemcpyAsync(&s1, c->st, sizeof(s1), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return bail(e, "reading the status");
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "the rehash");
+    if (full_before) {
+        const int restored = s1.status | GSDF_STATUS_TABLE_FULL;
+        (void)hipMemcpy(&c->st->status, &restored, sizeof(int), hipMemcpyHostToDevice);
+    }
+    if (s1.status & GSDF_STATUS_TABLE_FULL) {                  /* cannot happen: the new table is empty and larger */
+        release();
+        return gsdf_fail(GSDF_ERR_TABLE_FULL, "gsdf_grow: the rehash ran out of probes");
+    }
     (void)hipFree(c->tab.vox); (void)hipFree(c->tab.bkeys); (void)hipFree(c->tab.occ);
     if (c->vis) (void)hipFree(c->vis);
     c->tab = nt; c->vis = nvis;
@@ -455,7 +484,7 @@ int gsdf_grow_impl(gsdf_ctx* c, int new_capacity_log2) {
     /* PhotoBA's gate list was sized for the old table: the sweeps fall back to the whole table until the next gsdf_ba_setup */
     if (c->ba_gate_list) { (void)hipFree(c->ba_gate_list); c->ba_gate_list = nullptr; }
     c->ba_gate_fresh = false;
-    if (c->progress) c->progress[4] = 0u;
+    c->grow_forget = true;                                     /* auto-grow: the counts in flight describe the old table */
     return GSDF_OK;
 }
 

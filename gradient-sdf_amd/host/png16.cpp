@@ -119,7 +119,9 @@ bool decode_rows_impl(const std::string& path, Header& hd, size_t& stride, int& 
     if (want_w > 0 && (hd.width != want_w || hd.height != want_h)) return fail(err, "frame size differs from --width/--height");
     bpp = hd.channels * hd.bit_depth / 8;
     /* the header's numbers are untrusted: bound what gets allocated (a corrupt IHDR must not overflow size_t or ask for gigabytes) */
-    if ((unsigned long long)hd.width * (unsigned long long)hd.height * (unsigned long long)bpp > (1ull << 31)) return fail(err, "image too large");
+    /* (factors bounded one by one: the 64-bit product of three 31-bit numbers can wrap back below the limit) */
+    if (hd.width > 65535 || hd.height > 65535 ||
+        (unsigned long long)hd.width * (unsigned long long)hd.height * (unsigned long long)bpp > (1ull << 31)) return fail(err, "image too large");
     stride = (size_t)hd.width * bpp;
     const size_t raw_len = (stride + 1) * (size_t)hd.height;
     if (S.raw.size() < raw_len) S.raw.resize(raw_len);

@@ -72,12 +72,19 @@ void gsdf_destroy(gsdf_ctx* c);
 int gsdf_reset(gsdf_ctx* c);
 /* The reference's tsdf_ grows without bound (a node hash map, MapGradPixelSdf.h:65-68); this table has a capacity.  gsdf_grow
  * moves every block into a table of 2^new_capacity_log2 records (synchronous; the map -- voxels, vis_ bit-vectors, frame counter
- * -- is unchanged, only the room differs; on failure the old table stays).  gsdf_set_auto_grow lets the frame entries
+ * -- is unchanged, only the room differs; on failure the old table stays; a sticky GSDF_ERR_TABLE_FULL from an earlier fusion
+ * does not stop it, but stays reported: that fusion's samples were dropped).  gsdf_set_auto_grow lets the frame entries
  * (gsdf_update_dev / gsdf_update / gsdf_track_and_fuse_dev) do that by themselves: the table is doubled when ~45 % of its block
- * entries are in use (counted on the device every few frames, read without waiting), up to max_capacity_log2; 0 switches it
- * off, which is the default -- then GSDF_ERR_TABLE_FULL reports a map that outgrew its table, as before. */
+ * entries are in use, up to max_capacity_log2; 0 switches it off, which is the default -- then GSDF_ERR_TABLE_FULL reports a map
+ * that outgrew its table, as before.  The load is counted on the device behind every frame and read without waiting; the
+ * library knows how old the count it sees is and how fast the map grew lately, and an entry waits by itself (for the device to
+ * come within 8 frames, or for an exact count) when count + lag x growth comes near the limit -- callers need not
+ * synchronise.  What auto-grow cannot absorb: ONE frame that needs more new blocks than the table has left (more than half
+ * its entries): that frame still ends in GSDF_ERR_TABLE_FULL.  Size the initial table for at least two frames' blocks.
+ * gsdf_capacity reports the present capacity_log2. */
 int gsdf_grow(gsdf_ctx* c, int new_capacity_log2);
 int gsdf_set_auto_grow(gsdf_ctx* c, int max_capacity_log2);
+int gsdf_capacity(gsdf_ctx* c, int* capacity_log2);
 
 /* Sdf::set_zmin / Sdf::set_zmax -- Sdf.h:123-129 (defaults 0.5 / 3.5) */
 int gsdf_set_zrange(gsdf_ctx* c, float zmin, float zmax);
@@ -204,7 +211,13 @@ int gsdf_unpack_blocks_dev(gsdf_ctx* c, const uint64_t* block_keys_dev, int64_t 
  * the ranks' shifted vectors are OR-ed (a second all-reduce, unsigned words): the merged map is what PhotoBA needs (C4 -> C5).
  * ONE-SHOT: after the call every map IS the sum, so a second exchange over more than one rank is refused (GSDF_ERR_INVALID)
  * until gsdf_reset.  Failures are collective: a rank that cannot prepare its part reports that through the first all-gather
- * and every rank returns the error, none is left waiting inside a collective. */
+ * and every rank returns the error, none is left waiting inside a collective -- with ONE exception: the two header buffers
+ * of a few hundred bytes are needed to talk at all, and a rank whose hipMalloc fails for THEM returns before the first
+ * all-gather; its peers then wait in it (treat that as fatal for the job, as an out-of-memory device is).
+ * Memory: the key arrays are gathered WHOLE (8 B per block entry of the table, occupied or not, from every rank) and sorted on
+ * the device: three buffers of nranks x 2^(capacity_log2 - 6) x 8 B plus the sort's scratch -- 3 x 4 MB at 8 ranks and 2^22
+ * records, 3 x 268 MB at 2^28 (auto-grow's CLI limit), 3 x 1 GB at 2^30.  Growing to the largest rank's capacity also happens
+ * inside this call (and inside a timed exchange). */
 int gsdf_merge_allreduce(gsdf_ctx* c, void* nccl_comm, int64_t* n_blocks, int64_t* bytes);
 /* Optional set-up of the exchange outside a timed region (like the communicator): the scratch buffers for `nranks` ranks and one
  * run of the union's sort kernels, whose code is loaded on first use (~10 ms in the first exchange of a process otherwise).
@@ -271,7 +284,9 @@ int gsdf_dev_download(gsdf_ctx* c, void* host_dst, const void* dev_src, int64_t 
 /* Asynchronous frame staging for a host loop that keeps the GPU fed (the Scan3D CLI): page-locked host
  * buffers, an upload that is only ENQUEUED on the context's stream (host_src must stay untouched until a later mark is
  * reached), and marks: gsdf_mark records a point in the stream, gsdf_mark_wait blocks until the stream has passed it,
- * gsdf_mark_reached polls.  Marks complete in the order they were recorded. */
+ * gsdf_mark_reached polls.  Marks complete in the order they were recorded.  A reached mark orders STREAM PROGRESS only (the
+ * kernels and copies queued before it have run: a staging slot may be reused); its event carries no system-scope fence, so it
+ * does NOT make device writes visible to the host -- read results through gsdf_sync or the download / export entries. */
 int gsdf_host_alloc(gsdf_ctx* c, void** host_ptr, int64_t bytes);
 int gsdf_host_free(gsdf_ctx* c, void* host_ptr);
 int gsdf_dev_upload_async(gsdf_ctx* c, void* dev_dst, const void* host_src, int64_t bytes);

@@ -1053,16 +1053,29 @@ def test_grow_keeps_the_map_and_auto_grow_removes_table_full(pkg, O, monkeypatch
             g.update(d, R, t)
     assert e.value.code == pkg.binding.ERR_TABLE_FULL
     g.close()
-    monkeypatch.setenv("GSDF_GROW_CHECK_EVERY", "1")            # (count the blocks before every frame: fourteen frames are a short scan)
+    # 3. auto-grow with its defaults and NO synchronisation between the frames: the host queues the whole scan
+    # without waiting; the library counts the blocks behind every frame, knows how old the count it sees is, and waits by
+    # itself where the estimate (count + lag x growth) comes near the limit
     g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=18)
     g.set_auto_grow(22)
-    # (the first frame alone must fit: growth is decided from what earlier frames left in the table)
     dev = [g.upload(f[0]) for f in fr]
     for dptr, (d, R, t) in zip(dev, fr):
         g.update_dev(dptr, R, t)
-        g.sync()
+    g.sync()
     assert g.count() == n_vox
     _cmp_tables(g, o)
+    assert g.capacity_log2() > 18
+    g.close()
+    # 4. a sticky TABLE_FULL does not stop an explicit gsdf_grow (the error itself stays: samples were dropped)
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=18)
+    with pytest.raises(pkg.GsdfError):
+        for d, R, t in fr:
+            g.update(d, R, t)
+    g.grow(20)
+    assert g.capacity_log2() == 20
+    with pytest.raises(pkg.GsdfError) as e:
+        g.sync()
+    assert e.value.code == pkg.binding.ERR_TABLE_FULL
     g.close()
 
 
