@@ -123,8 +123,11 @@ class Sequence:
     """A seeded synthetic depth stream: frame(i) -> (depth float32 HxW metres, R 3x3 f32, t 3 f32)."""
 
     def __init__(self, kind="spheres", W=640, H=480, n_frames=30, seed=0, noise=True,
-                 step_deg=0.5, unit=None, motion=1.0):
+                 step_deg=0.5, unit=None, motion=1.0, pose_rows=None):
         self.kind, self.W, self.H, self.n, self.seed, self.noise = kind, W, H, n_frames, seed, noise
+        # pose_rows: rows "ts tx ty tz qx qy qz qw" of a TUM-format pose file (e.g. the reference's matlab/poses.txt, kept as
+        # data in tests/golden/ref_poses.txt): the frames are rendered from THOSE camera poses instead of the built-in orbit
+        self.pose_rows = None if pose_rows is None else np.asarray(pose_rows, np.float64).reshape(-1, 8)
         self.motion = float(motion)      # "tum": scale of the trajectory's time (0.5 = half the motion between two frames)
         self.K = intrinsics(W, H)
         self.step_deg = step_deg
@@ -144,6 +147,13 @@ class Sequence:
             raise ValueError(kind)
 
     def pose(self, i):
+        if self.pose_rows is not None:
+            row = self.pose_rows[i]
+            x, y, z, w = row[4:8] / np.linalg.norm(row[4:8])
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                          [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            return R.astype(np.float32), row[1:4].astype(np.float32)
         if self.kind == "spheres":
             # look-at-origin orbit, radius 2 m, height -0.125 .. 0.25 (matlab/poses.txt shape),
             # step_deg per frame (poses.txt is ~4 deg/frame: too coarse for tracking)

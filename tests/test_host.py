@@ -84,6 +84,54 @@ def test_scan3d_gt_pose_fusion_matches_oracle(pkg, O, tmp_path):
 
 
 @pytest.mark.gpu
+def test_scan3d_reference_pose_file(pkg, O, tmp_path):
+    """The one fixture the reference holds for this path: matlab/poses.txt (90 TUM-format rows, the orbit RenderSpheres.m renders
+    C1 from), kept as data in tests/golden/ref_poses.txt.  30 sphere frames are rendered from ITS poses and `Scan3D --pose-file`
+    fuses them in the GT-pose branch with --first 2: main_scan_3d.cpp:242 hands poses[0] to the first processed frame and :252
+    poses[i] to the others (SURVEY gotcha 2), ImageLoader::load_pose builds R from the file's 6-digit quaternion WITHOUT
+    normalising it (ImageLoader.h:246-253) and SE3(Matrix4f) goes through a quaternion once more.  The map must equal the
+    oracle's, fed the same file the same way."""
+    _build()
+    W, H, n, first = 320, 240, 30, 2
+    rows = np.loadtxt(os.path.join(ROOT, "tests", "golden", "ref_poses.txt"))
+    assert rows.shape == (90, 8) and abs(np.linalg.norm(rows[0, 4:8]) - 1.0) < 1e-5 and np.linalg.norm(rows[0, 4:8]) != 1.0
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=0, pose_rows=rows[:n])
+    ds = pkg.synth.write_dataset(seq, str(tmp_path / "ds"), layout="synth", with_poses=False)
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "ref_poses.txt"), ds + "ref_poses.txt")     # the file as the reference ships it
+    res = str(tmp_path / "out") + "/"
+    os.makedirs(res)
+    cmd = [os.path.join(HOST, "Scan3D"), "--input", ds, "--results", res, "--pose-file", "ref_poses.txt", "--first", str(first),
+           "--last", str(n - 1), "--scan-type", "grad-sdf", "--data-type", "synth", "--voxel-size", "0.02", "--trunc", "5",
+           "--width", str(W), "--height", str(H), "--hash-capacity", "20", "--save-sdf"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "90 GT poses are loaded!" in out.stdout and "Current frame counter: %d" % (n - first) in out.stdout
+    vs = np.float32(0.02)
+    o = O.Oracle(vs, np.float32(5) * vs, W, H, seq.K)
+    for i in range(first, n):
+        d = seq.depth_u16(i).astype(np.float32) * np.float32(0.001)
+        row = rows[0] if i == first else rows[i]                              # :242 poses[0] for the first processed frame, :252 poses[i] after it
+        q = np.array([np.float32("%.6f" % v) for v in row[4:8]], np.float32)  # operator>> into float
+        R = O.quat_to_R(O.R_to_quat(O.quat_to_R(q)))                          # load_pose: toRotationMatrix of the raw q; SE3(Matrix4f); rotationMatrix()
+        o.update(d, R, row[1:4].astype(np.float32))
+    keys, pay = o.export()
+    assert len(keys) > 20000
+    info = open(res + "gradient_sdf_grid_info.txt").read().split("\n")
+    dim = [int(v) for v in info[1].split(":")[1].split()]
+    mn = [int(v) for v in info[2].split(":")[1].split()]
+    assert mn == keys.min(0).tolist() and dim == (keys.max(0) - keys.min(0) + 1).tolist()
+    lin = (dim[0] * dim[1] * (keys[:, 2] - mn[2]) + dim[0] * (keys[:, 1] - mn[1]) + keys[:, 0] - mn[0])
+    got = np.loadtxt(res + "gradient_sdf_sdf_d.txt")
+    assert np.array_equal(got[:, 0].astype(np.int64), lin)                    # same voxel set (bit-exact keys), same order
+    assert np.abs(got[:, 1] - pay[:, 0]).max() < 1e-4
+    w = np.loadtxt(res + "gradient_sdf_sdf_weight.txt")[:, 1]
+    assert np.abs(w - pay[:, 4]).max() <= 1e-4 * max(1.0, pay[:, 4].max())
+    pf = np.loadtxt(res + "_poses.txt")                                       # :270: the pose file repeats poses[i] of every processed frame
+    assert pf.shape == (n - first, 8) and np.abs(pf[:, 1:4] - rows[first:n, 1:4]).max() < 1e-5
+
+
+@pytest.mark.gpu
 def test_scan3d_tracked_mode_writes_tum_poses(pkg, O, tmp_path):
     _build()
     W, H, n = 640, 480, 4

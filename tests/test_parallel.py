@@ -4,6 +4,7 @@ for the per-rank fusion, and must reproduce the single-process map.  The GPU pat
 exchange with device tensors over RCCL (gradient-sdf_amd/parallel.py:exchange_and_merge)."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -278,6 +279,81 @@ def test_merge_allreduce_over_rccl_one_rank(pkg):
     finally:
         pkg.binding.rccl_comm_destroy(comm)
     g.close()
+
+
+# ---- the RCCL-typed path with PEERS ------------------------------------------------------------------
+# gsdf_merge_allreduce(ctx, ncclComm_t) had only ever run with nranks = 1: RCCL refuses two ranks on one device and the pool
+# offers one GPU per call.  tests/fake_rccl.c is a test double for the seven nccl* entry points libgsdf resolves with
+# dlsym(RTLD_DEFAULT, ...): N processes sharing device 0, shared-memory rendezvous, device buffers staged on the stream they
+# were given.  With it the code that talks to RCCL -- rccl_transport (ncclAllGather of ncclInt8, ncclAllReduce of ncclFloat32
+# and of ncclUint32 for vis_), the header / token scheme, the agree() points, growth to the largest rank's capacity -- runs
+# with 2 and 8 ranks, uneven shards and vis_ on, against the oracle.  What it does NOT test is RCCL itself or xGMI.
+
+def _build_fake_rccl():
+    src = os.path.join(ROOT, "tests", "fake_rccl.c")
+    out = os.path.join(ROOT, "tests", "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                               src, "-o", out, "-lrt"])
+    return out
+
+
+def test_fake_rccl_builds_and_exports_what_libgsdf_resolves():
+    """(CPU) the test double compiles against <rccl/rccl.h> and exports the seven entry points gsdf_merge.hip:50-73 looks up."""
+    out = _build_fake_rccl()
+    syms = subprocess.run(["nm", "-D", "--defined-only", out], capture_output=True, text=True, check=True).stdout
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommCount", "ncclAllGather", "ncclAllReduce",
+                 "ncclGetErrorString"):
+        assert (" T " + name) in syms, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_merge_allreduce_rccl_path_with_peers(pkg, O, tmp_path, world):
+    """gsdf_merge_allreduce(ctx, comm) called by `world` processes over the RCCL test double: every rank ends with the oracle's
+    key set, sums within float noise, the oracle's vis_ bit-vectors (frame f of rank r = integrated frame lo(r) + f) and
+    Sdf::counter_ = 19; all tables have the largest rank's capacity; a second exchange is refused on every rank."""
+    import rccl_rank as RR
+    fake = _build_fake_rccl()
+    id_file = str(tmp_path / "unique_id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_rank.py"), str(r), str(world), id_file, str(tmp_path), fake],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    seq = pkg.synth.Sequence("spheres", RR.W, RR.H, n_frames=RR.N_FRAMES, seed=RR.SEED, step_deg=RR.STEP_DEG)
+    vs = np.float32(RR.VS)
+    o = O.Oracle(vs, np.float32(RR.TRUNC) * vs, RR.W, RR.H, seq.K)
+    for i in range(RR.N_FRAMES):
+        o.update(*seq.frame(i))
+    keys, pay = o.export()
+    vo = o.export_vis(1)
+    z0 = np.load(tmp_path / "rccl_0.npz")
+    shards = []
+    for r in range(world):
+        z = np.load(tmp_path / ("rccl_%d.npz" % r))
+        shards.append((int(z["lo"]), int(z["hi"])))
+        assert np.array_equal(z["keys"], keys) and int(z["frames"]) == RR.N_FRAMES == o.frame_counter()
+        assert np.array_equal(z["vis"], vo)                                  # the ncclUint32 all-reduce
+        assert np.array_equal(z["pay"].view(np.uint32), z0["pay"].view(np.uint32))   # every rank holds the same sums, bit for bit
+        w = z["pay"][:, 4]
+        assert (np.abs(w - pay[:, 4]) / np.maximum(1.0, pay[:, 4])).max() <= 1e-4
+        assert np.abs(z["pay"][:, 0] / w - pay[:, 0]).max() <= 1e-4
+        assert (np.abs(z["pay"][:, 1:4] - pay[:, 1:4]).max(axis=1) / np.maximum(1.0, pay[:, 4])).max() <= 1e-4
+        assert int(z["own"]) < len(keys)                                     # the shards really differed
+        assert int(z["cap"]) == 19                                           # grown to the largest rank's capacity
+        assert int(z["n_blocks"]) == int(z0["n_blocks"]) > 50
+        assert "one-shot" in str(z["again"])
+    assert shards[0][0] == 0 and shards[-1][1] == RR.N_FRAMES and all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+    # what went through the double: all-gathers (header, key arrays, agreements), ONE float all-reduce, ONE unsigned one (vis_)
+    ag, ar_f32, ar_u32, total = [int(v) for v in z0["stats"]]
+    assert ag >= 2 and ar_f32 == 1 and ar_u32 == 1 and total >= int(z0["nbytes"])
 
 
 # ---- BASELINE configs[3] AS CONFIGURED (640x480, 1 cm voxels, trunc 10, sphere orbit): shards -> ONE exchange -> mesh ------

@@ -187,3 +187,56 @@ def test_gpu_photoba_optimize_matches_oracle(pkg, O):
     assert en_g[-1] < 0.3 * en_g[0]
     assert np.abs(g.ba_poses() - P).max() < 0.5 * np.abs(Pp - P).max()
     g.close()
+
+
+@pytest.mark.gpu
+def test_photometric_optimizer_cpp_facade_executed(pkg, O, tmp_path):
+    """host/PhotometricOptimizer.h (the facade for ps_optimizer/PhotometricOptimizer.h:68-186) EXECUTED from C++ --
+    host/photoba_selftest fuses the frames through MapGradPixelSdf::update (vis_ on), then setImages / setPoses / setKeyframes,
+    getEnergy, solvePose, solveDist, optimize -- against the same steps driven through the C-ABI from here: same energies,
+    same poses (both sides are the GPU engine; sums of a sweep are order-free up to float noise)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    host = os.path.join(ROOT, "gradient-sdf_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    n, W, H, vsf, trunc = 6, 160, 120, 0.02, 5
+    seq, vs, T, frames, imgs, P, Pp = _scene(pkg, O, W=W, H=H, n=n, vs=vsf, trunc=trunc)
+    d = tmp_path
+    np.asarray(seq.K, np.float32).reshape(9).tofile(d / "K.bin")
+    np.stack([f[0] for f in frames]).astype(np.float32).tofile(d / "depth.bin")
+    imgs.astype(np.float32).tofile(d / "images.bin")
+    # the facade takes its fusion poses as Matrix4f -> SE3 (quaternion) -> R, like main_photo_ba.cpp; feed the C-ABI side the same R
+    P.astype(np.float32).tofile(d / "poses_true.bin")
+    Pp.astype(np.float32).tofile(d / "poses_start.bin")
+    out = subprocess.run([os.path.join(host, "photoba_selftest"), str(d), str(W), str(H), str(n), repr(vsf), str(trunc)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "photoba_selftest: OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = {}
+    for ln in out.stdout.splitlines():
+        k, _, rest = ln.partition(" ")
+        lines.setdefault(k, []).append(rest.split())
+    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=20)
+    g.enable_vis(64)
+    for (dep, R, t), Pi in zip(frames, P):
+        Rq = O.quat_to_R(O.R_to_quat(Pi[:3, :3].astype(np.float32)))          # SE3(Matrix4f).rotationMatrix()
+        g.update(dep, Rq, Pi[:3, 3].astype(np.float32))
+    assert int(lines["voxels"][0][0]) == g.count() and int(lines["voxels"][0][2]) == n
+    idx = np.arange(n)
+    g.ba_setup(imgs, Pp, idx)
+    e0 = g.ba_energy()
+    g.ba_solve_pose()
+    e1 = g.ba_energy()
+    p1 = g.ba_poses()
+    g.ba_solve_dist()
+    e2 = g.ba_energy()
+    got = [float(v) for v in lines["steps"][0]]
+    assert got == pytest.approx([e0, e1, e2], rel=1e-5) and e1 < 0.5 * e0
+    pf = np.array([[float(v) for v in row[1:]] for row in lines["pose_after_step"]]).reshape(n, 4, 4)
+    assert np.abs(pf - p1).max() < 1e-6 and np.abs(pf - Pp).max() > 1e-3       # solvePose() moved the poses, and download() brought them back
+    conv, en = g.ba_optimize(4)
+    row = lines["optimize"][0]
+    assert int(row[0]) == int(conv) and [float(v) for v in row[1:]] == pytest.approx(list(en), rel=1e-4)
+    pe = np.array([[float(v) for v in r[1:]] for r in lines["pose_final"]]).reshape(n, 4, 4)
+    assert np.abs(pe - g.ba_poses()).max() < 1e-5
+    g.close()
