@@ -494,6 +494,21 @@ static_assert(FUSE_TH % 4 == 0 && FUSE_TH >= 8 && FUSE_TH <= 32, "tile height");
 #define FUSE_PRIO_FLUSH -1
 #endif
 #define FUSE_SETPRIO(n) do { if ((n) >= 0) __builtin_amdgcn_s_setprio((n) < 0 ? 0 : (n)); } while (0)
+/* The flush's record accesses as LANE PAIRS: a 16-byte sc1 store is a 32-byte fabric write whatever it is next to, but two
+ * adjacent lanes of ONE instruction that write the two halves of a record make one write of it (1.0x, not 2 x 0.75:
+ * profiles/r03_write_calibration.txt); loads likewise.  Lanes 2j and 2j+1 therefore serve each other: instruction 1 moves the
+ * even lane's record (even lane: bytes 0-15, odd lane: bytes 16-31), instruction 2 the odd lane's; the halves change lanes
+ * through DPP quad permutes.  0 = every lane moves its own record with two instructions (rounds 2-4). */
+#ifndef FUSE_PAIRED_IO
+#define FUSE_PAIRED_IO 1
+#endif
+template <int QP>
+__device__ __forceinline__ uint32_t fuse_quad(uint32_t v) {      /* v of the lane quad_perm QP names, all lanes active */
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, QP, 0xf, 0xf, false);
+}
+#define FUSE_QP_EVEN 0xA0                /* quad_perm [0,0,2,2]: the even lane of my pair */
+#define FUSE_QP_ODD 0xF5                 /* quad_perm [1,1,3,3]: the odd lane of my pair */
+#define FUSE_QP_SWAP 0xB1                /* quad_perm [1,0,3,2]: my partner */
 typedef uint32_t gsdf_u32x4 __attribute__((ext_vector_type(4)));
 typedef float gsdf_f2 __attribute__((ext_vector_type(2)));           /* packed f32 arithmetic (v_pk_*_f32): two results per issue slot */
 /* a * b + c with a, b < 2^24 (b uniform): full rate, where the 32-bit v_mul_lo_u32 is quarter rate */
@@ -794,7 +809,6 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
 #endif
     const int nk_all = 2 * g.factor + 1;
     const int colour = (tile_x & 1) + 2 * (tile_y & 1);
-    unsigned int* my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
     /* Wave 0 derives the tile-wide decisions from the per-wave entries and hands them to the others through LDS: ~200 uniform
      * instructions that all eight waves used to execute -- 7 % of the kernel's instruction issue, which is what bounds it. */
     int n_pass = 1;
@@ -827,7 +841,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         if (tid == 0) {
             L.ordered = ordered ? 1u : 0u;                            /* read after the ray walk's barrier */
             /* a tile that writes nothing itself has nothing to hand over: publish at once */
-            if (!ordered) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ordered) __hip_atomic_store(a.tile_flags + (size_t)tile_y * a.ntx + tile_x, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         /* Distinct voxels the tile will touch: the volume its rays sweep (pixels x samples / pixels per voxel face) plus
          * half a voxel around that prism (a side of the tile is `side` voxels wide at depth zf).  Calibrated against
@@ -1071,7 +1085,10 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
      * Block keys are insert-only, so plain (possibly stale) key loads can only show EMPTY and the CAS
      * settles it.  Each lane owns FUSE_LCAP/FUSE_THREADS LDS slots and drives them through the stages
      * together, so the dependent HBM round trips (bucket keys -> payload) of its entries overlap. */
+    unsigned int* const my_flag = a.tile_flags + (size_t)tile_y * a.ntx + tile_x;
+    const unsigned int tag = a.tag;
     if (!GSDF_EXPERIMENT(a.debug, 1)) {
+        const gsdf_table& tab = a.tab;
         constexpr int NE = (FUSE_LCAP + FUSE_THREADS - 1) / FUSE_THREADS;
         constexpr uint32_t NOREC = 0xFFFFFFFFu;
         unsigned long long bkey[NE], k0[NE];
@@ -1085,14 +1102,14 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             const uint32_t lk = (i < FUSE_LCAP && (big || !FUSE_DUAL || i < FUSE_LCAP_SMALL)) ? L.key[i] : FUSE_LKEY_EMPTY;
             const unsigned long long ek = gsdf_key_pack(ox + (int)(lk & 1023u), oy + (int)((lk >> 10) & 1023u), oz + (int)(lk >> 20));
             bkey[e] = gsdf_block_key(ek);
-            home[e] = gsdf_hash(bkey[e]) & a.tab.block_mask;
+            home[e] = gsdf_hash(bkey[e]) & tab.block_mask;
             rec[e] = lk == FUSE_LKEY_EMPTY ? NOREC : gsdf_block_local(ek);
             if (lk != FUSE_LKEY_EMPTY) have |= 1u << e;
             k0[e] = GSDF_KEY_EMPTY;
         }
 #pragma unroll
         for (int e = 0; e < NE; ++e)
-            if ((have >> e) & 1u) k0[e] = a.tab.bkeys[home[e]];                   /* 512 KB of block keys: L2 hits */
+            if ((have >> e) & 1u) k0[e] = tab.bkeys[home[e]];                   /* 512 KB of block keys: L2 hits */
         unsigned long long TF = GSDF_EXPERIMENT(a.debug, 128) ? wall_clock64() : 0ull;
         if (pass == 0) GSDF_TRACE(a, tr, 3);                          /* keys unpacked, home-entry loads issued */
         /* Meanwhile one wave looks after the adjacent tiles of lower colour (lane j watches neighbour j).  Their flags have
@@ -1119,7 +1136,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         {
             /* the blocks of this lane's entries, looked up (and inserted) together: the probe chains overlap */
             int blk[NE];
-            gsdf_block_lookup_n<NE, true>(a.tab, bkey, home, k0, have, blk);
+            gsdf_block_lookup_n<NE, true>(tab, bkey, home, k0, have, blk);
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 if (!((have >> e) & 1u)) continue;
@@ -1130,7 +1147,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         if (pass == 0) GSDF_TRACE(a, tr, 5);                          /* wave 0: its blocks looked up */
         if (watcher) {
             const unsigned long long t0 = wall_clock64();
-            bool ok = !need || first_look == a.tag;
+            bool ok = !need || first_look == tag;
             for (;;) {
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(FUSE_POLL_SLEEP);
@@ -1139,7 +1156,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
                     if (lane == 0) { L.ordered = 0u; atomicAdd(&a.st->fuse_timeouts, 1u); }
                     break;
                 }
-                if (!ok) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.tag;
+                if (!ok) ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag;
             }
         }
         __syncthreads();                                              /* the wait above is over (or timed out) */
@@ -1151,13 +1168,32 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
              * write-through stores cost one fabric write each (3 x 8 B measured 2x slower).  hipcc does not
              * count asm memory operations: the wait statement below names every destination register. */
             gsdf_u32x4 ra[NE], rb[NE];
+            /* (the 2560-entry table with the normals role is at the register limit: its five entries per lane stay unpaired) */
+            constexpr bool PAIRED = FUSE_PAIRED_IO && !(NE > 4 && NEXT_NORMALS);
+            /* ra[e]: the half this lane moves of the EVEN lane's record of entry e (even lane: bytes 0-15, odd lane: 16-31),
+             * rb[e]: its half of the ODD lane's record.  The exchanges run with all lanes active; only the memory instructions
+             * are predicated (a pair moves a record if the lane that owns it has one). */
+            const bool odd = (lane & 1) != 0;
+            uint32_t rec_a[NE], rec_b[NE];                   /* record index of the even / the odd lane's entry e (NOREC = none) */
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { rec_a[e] = fuse_quad<FUSE_QP_EVEN>(rec[e]); rec_b[e] = fuse_quad<FUSE_QP_ODD>(rec[e]); }
+            auto half_of = [&](uint32_t r) { return reinterpret_cast<const char*>(tab.vox + r) + (odd ? 16 : 0); };
+            if constexpr (PAIRED) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                ra[e] = gsdf_u32x4{ 0u, 0u, 0u, 0u }; rb[e] = ra[e];
+                if (rec_a[e] != NOREC) { const char* q = half_of(rec_a[e]); asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ra[e]) : "v"(q) : "memory"); }
+                if (rec_b[e] != NOREC) { const char* q = half_of(rec_b[e]); asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(rb[e]) : "v"(q) : "memory"); }
+            }
+            } else {
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 ra[e] = gsdf_u32x4{ 0u, 0u, 0u, 0u }; rb[e] = ra[e];
                 if (rec[e] == NOREC) continue;
-                const gsdf_payload* pe = a.tab.vox + rec[e];
+                const gsdf_payload* pe = tab.vox + rec[e];
                 asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ra[e]) : "v"(pe) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, off offset:16 sc1" : "=v"(rb[e]) : "v"(pe) : "memory");
+            }
             }
             static_assert(NE >= 2 && NE <= 5, "the wait statement names NE x 2 destination registers");
             if constexpr (NE == 5)
@@ -1172,22 +1208,53 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]), "+v"(ra[1]), "+v"(rb[1]) :: "memory");
             if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 1], T - TF); TF = T; }
             if (pass == 0) GSDF_TRACE(a, tr, 7);                      /* wave 0: records arrived */
+            if constexpr (PAIRED) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int i = tid + FUSE_THREADS * e;
+                const bool mine = rec[e] != NOREC;
+                fuse_sums d = { 0.f, 0.f, 0.f, 0.f, 0.f };
+                if (mine) d = fuse_unpack(L.acc[0][i], L.acc[1][i], L.acc[2][i]);
+                /* this lane's own record as it was: bytes 0-15 are ra (even lane) or the partner's rb (odd lane), the first word
+                 * of bytes 16-31 (gz) the partner's ra.x (even lane) or rb.x (odd lane) */
+                const uint32_t p0 = fuse_quad<FUSE_QP_SWAP>(rb[e].x), p1 = fuse_quad<FUSE_QP_SWAP>(rb[e].y),
+                               p2 = fuse_quad<FUSE_QP_SWAP>(rb[e].z), p3 = fuse_quad<FUSE_QP_SWAP>(rb[e].w), q0 = fuse_quad<FUSE_QP_SWAP>(ra[e].x);
+                const uint32_t o0 = odd ? p0 : ra[e].x, o1 = odd ? p1 : ra[e].y, o2 = odd ? p2 : ra[e].z, o3 = odd ? p3 : ra[e].w;
+                const uint32_t o4 = odd ? rb[e].x : q0;
+                gsdf_u32x4 oa;
+                oa.x = __float_as_uint(__uint_as_float(o0) + d.w);
+                oa.y = __float_as_uint(__uint_as_float(o1) + d.s);
+                oa.z = __float_as_uint(__uint_as_float(o2) + d.gx);
+                oa.w = __float_as_uint(__uint_as_float(o3) + d.gy);
+                const uint32_t ogz = __float_as_uint(__uint_as_float(o4) + d.gz);
+                /* what this lane stores: of the even lane's record (sa) and of the odd lane's record (sb) */
+                const uint32_t e_gz = fuse_quad<FUSE_QP_SWAP>(ogz);
+                gsdf_u32x4 sa, sb;
+                sa.x = odd ? e_gz : oa.x; sa.y = odd ? tag : oa.y; sa.z = odd ? 0u : oa.z; sa.w = odd ? 0u : oa.w;
+                const uint32_t x0 = fuse_quad<FUSE_QP_SWAP>(oa.x), x1 = fuse_quad<FUSE_QP_SWAP>(oa.y), x2 = fuse_quad<FUSE_QP_SWAP>(oa.z), x3 = fuse_quad<FUSE_QP_SWAP>(oa.w);
+                sb.x = odd ? ogz : x0; sb.y = odd ? tag : x1; sb.z = odd ? 0u : x2; sb.w = odd ? 0u : x3;
+                if (rec_a[e] != NOREC) { const char* q = half_of(rec_a[e]); asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(q), "v"(sa) : "memory"); }
+                if (rec_b[e] != NOREC) { const char* q = half_of(rec_b[e]); asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(q), "v"(sb) : "memory"); }
+                if (mine) vis_mark(a, tab.vox + rec[e], frame_cur);
+            }
+            } else {
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 if (rec[e] == NOREC) continue;
                 const int i = tid + FUSE_THREADS * e;
                 const fuse_sums d = fuse_unpack(L.acc[0][i], L.acc[1][i], L.acc[2][i]);
-                gsdf_payload* pe = a.tab.vox + rec[e];
+                gsdf_payload* pe = tab.vox + rec[e];
                 gsdf_u32x4 oa, ob;
                 oa.x = __float_as_uint(__uint_as_float(ra[e].x) + d.w);
                 oa.y = __float_as_uint(__uint_as_float(ra[e].y) + d.s);
                 oa.z = __float_as_uint(__uint_as_float(ra[e].z) + d.gx);
                 oa.w = __float_as_uint(__uint_as_float(ra[e].w) + d.gy);
                 ob.x = __float_as_uint(__uint_as_float(rb[e].x) + d.gz);
-                ob.y = a.tag; ob.z = 0u; ob.w = 0u;
+                ob.y = tag; ob.z = 0u; ob.w = 0u;
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(pe), "v"(oa) : "memory");
                 asm volatile("global_store_dwordx4 %0, %1, off offset:16 sc1\n\ts_nop 1" :: "v"(pe), "v"(ob) : "memory");
                 vis_mark(a, pe, frame_cur);
+            }
             }
             /* hand the voxels on: every storing wave drains its stores, then ONE lane publishes the flag.  (Tiles of
              * the highest colour drain too although nobody waits for their flag: the deferred contributions are
@@ -1196,7 +1263,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             if (pass == 0) GSDF_TRACE(a, tr, 8);                      /* wave 0: stores issued */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T = wall_clock64(); atomicAdd(&a.st->dbg[8 + 4 * colour + 3], T - TF); TF = T; }
             if (pass == 0) GSDF_TRACE(a, tr, 9);                      /* all stores drained, flag published */
         } else {
@@ -1206,7 +1273,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             for (int e = 0; e < NE; ++e) {
                 if (rec[e] == NOREC) continue;
                 L.key[tid + FUSE_THREADS * e] = FUSE_LKEY_DEFER | rec[e];
-                vis_mark(a, a.tab.vox + rec[e], frame_cur);
+                vis_mark(a, tab.vox + rec[e], frame_cur);
                 ++my_defer;
             }
             if (my_defer) atomicAdd(&L.n_defer, my_defer);
@@ -1223,7 +1290,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
                     if (o >= a.deferred_cap) { atomicOr(&a.st->status, GSDF_STATUS_TABLE_FULL); continue; }
                     const fuse_sums u = fuse_unpack(L.acc[0][i], L.acc[1][i], L.acc[2][i]);
                     gsdf_deferred d;
-                    d.p = a.tab.vox + (key & ~FUSE_LKEY_DEFER);
+                    d.p = tab.vox + (key & ~FUSE_LKEY_DEFER);
                     d.w = u.w; d.s = u.s;
                     d.gx = u.gx; d.gy = u.gy; d.gz = u.gz;
                     d.pad = 0u;
@@ -1231,10 +1298,10 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
                 }
             }
             /* a timed-out tile still has to release the tiles that wait for it (it wrote nothing itself) */
-            if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && pass + 1 == n_pass) __hip_atomic_store(my_flag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else if (tid == 0) {
-        __hip_atomic_store(my_flag, a.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(my_flag, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (GSDF_EXPERIMENT(a.debug, 128) && tid == 0) { const unsigned long long T3 = wall_clock64(); atomicAdd(&a.st->dbg[3], T3 - T1); T1 = T3; }
     if (pass + 1 < n_pass) {                                          /* next band: start from an empty table */
