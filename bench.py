@@ -65,6 +65,8 @@ def parse_args():
                     help="frames PER RANK of the sharded GT-pose flavour (8 ranks x 250 = the 2000 frames of BASELINE configs[3]); 0 = skip")
     ap.add_argument("--raycast-reps", type=int, default=10, help="raycasts of the bench map timed for roofline.raycast (0 = skip)")
     ap.add_argument("--no-staged", action="store_true", help="skip the staging-inclusive flavour (config.staged_fps)")
+    ap.add_argument("--contexts-per-gpu", type=int, default=2,
+                    help="shard contexts per GPU in the sharded flavour (each on its own stream, merged locally before the exchange)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip config.default_window (frames 21..220 of the same stream) and config.c3 (BASELINE configs[2])")
     ap.add_argument("--extras-timeout", type=float, default=150.0, help="seconds the two extra configurations may take before the line is printed without them")
@@ -630,6 +632,7 @@ def main():
                     "staged_same_passes_as_resident": staged_same if staged_runs else None,
                     "raycast_us": raycast["avg_launch_us"] if raycast else None,
                     # the same engine on the other two single-GPU windows / configurations, timed like `value` (never `value`)
+                    "streams_per_gpu": extras.get("streams_per_gpu"),
                     "default_window": extras.get("default_window"),
                     "c3": extras.get("c3"),
                     "sharded": sharded,
@@ -662,6 +665,7 @@ def main():
     # ---- the other two single-GPU numbers, under the same clock as `value` (and the same kind of watchdog as the sharded flavour) ----
     if extras_in is not None:
         def give_up_extras():
+            extras.setdefault("streams_per_gpu", {"error": "did not finish within %.0f s" % args.extras_timeout})
             extras.setdefault("default_window", {"error": "did not finish within %.0f s" % args.extras_timeout})
             extras.setdefault("c3", {"error": "did not finish within %.0f s" % args.extras_timeout})
             emit({"error": "skipped: the extra configurations did not finish in time"} if c4 is not None else None)
@@ -669,7 +673,8 @@ def main():
         dog_x = threading.Timer(args.extras_timeout, give_up_extras)
         dog_x.daemon = True
         dog_x.start()
-        for name, fn in (("default_window", lambda: default_window_flavour(pkg, args, extras_in["dw"], local_rank, vs, T, W, H)),
+        for name, fn in (("streams_per_gpu", lambda: two_streams_flavour(pkg, args, seq, frames, local_rank, vs, T, W, H, Wm, K)),
+                         ("default_window", lambda: default_window_flavour(pkg, args, extras_in["dw"], local_rank, vs, T, W, H)),
                          ("c3", lambda: c3_flavour(pkg, args, extras_in["c3"], local_rank))):
             try:
                 extras[name] = fn()
@@ -728,6 +733,56 @@ def _tracked_windows(g, dev, frames, Wm, K, repeats):
 def pkg_quat(R):
     import __graft_entry__ as graft
     return graft.package().synth.R_to_quat_np(R).astype(np.float32)
+
+
+def two_streams_flavour(pkg, args, seq, frames, local_rank, vs, T, W, H, Wm, K):
+    """config.streams_per_gpu: TWO independent replica streams of the headline workload in one process, one context (one HIP
+    stream) and one host thread each (tracked mode does not shard -- "N independent streams"; here N = 2 on ONE
+    GPU).  A single dependent stream leaves the chip idle between a third (fusion tail) and nine tenths (tracker passes) of the
+    time; the second stream's launches fill some of it.  Aggregate frames/s of both streams, reported BESIDE `value`, never as it."""
+    import threading
+    ctxs = [pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=args.hash_capacity_log2, device=local_rank) for _ in range(2)]
+    devs = [[g.upload(f[0]) for f in frames] for g in ctxs]
+    d0, R0, t0 = frames[0]
+    p0 = np.concatenate([t0, pkg_quat(R0)]).astype(np.float32)
+
+    def start(g, dev):
+        g.reset()
+        g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
+        g.set_pose(p0)
+        for i in range(1, 1 + Wm):
+            g.track_and_fuse_dev(dev[i])
+        g.sync()
+    runs, logs = [], None
+    for rep in range(4):                                      # the first window is untimed
+        for g, dev in zip(ctxs, devs):
+            start(g, dev)
+        gate = threading.Barrier(3)
+        done = [0.0, 0.0]
+
+        def body(k):
+            g, dev = ctxs[k], devs[k]
+            gate.wait()
+            for i in range(1 + Wm, 1 + Wm + K):
+                g.track_and_fuse_dev(dev[i])
+            g.sync()
+            done[k] = time.perf_counter()
+        th = [threading.Thread(target=body, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        gate.wait()
+        t_start = time.perf_counter()
+        for t in th:
+            t.join()
+        if rep:
+            runs.append(max(done) - t_start)
+    logs = [g.frame_log()[Wm:Wm + K] for g in ctxs]
+    for g in ctxs:
+        g.close()
+    el = float(np.median(runs))
+    return {"streams": 2, "aggregate_fps": round(2 * K / el, 1), "runs": [round(2 * K / r, 1) for r in runs],
+            "frames_per_stream": K, "converged_frames": [int(l[:, 7].sum()) for l in logs],
+            "note": "two independent replica streams (same frames) in one process, one context + one host thread each; aggregate of both"}
 
 
 def default_window_flavour(pkg, args, dw, local_rank, vs, T, W, H):
@@ -851,18 +906,59 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
         dist.all_reduce(t)
         return t.cpu().numpy()
 
+    # ---- one context per GPU first (the form of rounds 1-4): its rate, and its map as the yardstick for the two-context form ----
+    ncx = max(1, min(2, args.contexts_per_gpu))
+    one_fps, ref_map = None, None
+    if ncx > 1:
+        for rnd in range(2):
+            g.reset()
+            barrier()
+            t0 = time.perf_counter()
+            for j, (d, f) in enumerate(zip(dev, frames)):
+                g.update_dev(d, f[1], f[2])
+                if j % 32 == 31:
+                    g.sync()
+            g.sync()
+            one_fps = total / vmax([time.perf_counter() - t0])[0]
+        ref_map = g.export(sorted=True, raw=True)
+        g2 = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=23, device=local_rank)
+        half = (F + 1) // 2                                       # g takes the first frames of the shard, g2 the rest (contiguous)
+        dev2 = [g2.upload(f[0]) for f in frames[half:]]
+
     res = {}
     for rnd in range(2):
         g.reset()
+        if ncx > 1:
+            g2.reset()
         barrier()
         t0 = time.perf_counter()
-        for j, (d, f) in enumerate(zip(dev, frames)):
-            g.update_dev(d, f[1], f[2])
-            if j % 32 == 31:
-                g.sync()
-        g.sync()
+        if ncx > 1:
+            # two shard contexts on this GPU, each on its own stream, enqueued alternately: one fusion's tail (a third of the
+            # workgroup slots idle) runs under the other's launch; then the local sum, then the exchange between the GPUs
+            for j in range(half):
+                g.update_dev(dev[j], frames[j][1], frames[j][2])
+                if half + j < F:
+                    g2.update_dev(dev2[j], frames[half + j][1], frames[half + j][2])
+                if j % 16 == 15:
+                    g.sync(); g2.sync()
+            g.sync(); g2.sync()
+            t_m = time.perf_counter()
+            g.merge_from(g2)
+            t_merge = time.perf_counter() - t_m
+        else:
+            for j, (d, f) in enumerate(zip(dev, frames)):
+                g.update_dev(d, f[1], f[2])
+                if j % 32 == 31:
+                    g.sync()
+            g.sync()
+            t_merge = 0.0
         t_fuse = time.perf_counter() - t0
         own = g.count()
+        same = None
+        if ncx > 1 and rnd == 1:
+            k2, p2 = g.export(sorted=True, raw=True)
+            same = bool(k2.shape == ref_map[0].shape and np.array_equal(k2, ref_map[0]) and
+                        float((np.abs(p2 - ref_map[1]).max(axis=1) / np.maximum(1.0, ref_map[1][:, 4])).max()) <= 1e-5)
         barrier()
         t1 = time.perf_counter()
         if use_rccl:
@@ -871,10 +967,14 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
             nb, nbytes = g.merge_allreduce_with(ag, ar, world)
         g.sync()
         t_exch = time.perf_counter() - t1
-        t_fuse, t_exch, t_both = vmax([t_fuse, t_exch, t_fuse + t_exch])
+        t_fuse, t_exch, t_both, t_merge = vmax([t_fuse, t_exch, t_fuse + t_exch, t_merge])
         res = {"frames_per_rank": F, "frames_total": total, "ranks": world, "rccl_ranks": rccl_ranks, "transport": transport,
+               "contexts_per_gpu": ncx,
                "sharded_fused_fps": round(total / t_fuse, 1), "sharded_fused_fps_incl_exchange": round(total / t_both, 1),
-               "fuse_ms": round(t_fuse * 1e3, 3), "exchange_ms": round(t_exch * 1e3, 3), "exchange_bytes": int(nbytes),
+               "one_context_fused_fps": round(one_fps, 1) if one_fps else None,
+               "same_map_as_one_context": same,
+               "fuse_ms": round(t_fuse * 1e3, 3), "local_merge_ms": round(t_merge * 1e3, 3) if ncx > 1 else None,
+               "exchange_ms": round(t_exch * 1e3, 3), "exchange_bytes": int(nbytes),
                "exchange_blocks": int(nb), "voxels_own_shard": int(own)}
     res["voxels_merged"] = int(g.count())
     res["frames_counter_after_merge"] = int(g.stats()["frames"])
@@ -887,6 +987,8 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
     if comm is not None:
         pkg.binding.rccl_comm_destroy(comm)
     g.close()
+    if ncx > 1:
+        g2.close()
     return res
 
 

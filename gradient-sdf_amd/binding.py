@@ -129,6 +129,7 @@ def load(path=None):
         "gsdf_grow": (C.c_int, [vp, C.c_int]),
         "gsdf_set_auto_grow": (C.c_int, [vp, C.c_int]),
         "gsdf_capacity": (C.c_int, [vp, C.POINTER(C.c_int)]),
+        "gsdf_merge_from": (C.c_int, [vp, vp]),
         "gsdf_merge_raw": (C.c_int, [vp, i32p, fp, C.c_int64]),
         "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
@@ -180,7 +181,7 @@ ABI_SYMBOLS = [
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
     "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
-    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow", "gsdf_capacity", "gsdf_merge_prepare",
+    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow", "gsdf_capacity", "gsdf_merge_from", "gsdf_merge_prepare",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
     "gsdf_merge_allreduce", "gsdf_merge_allreduce_with", "gsdf_rccl_unique_id", "gsdf_rccl_comm_init", "gsdf_rccl_comm_count",
@@ -440,6 +441,10 @@ class GradSdf:
         k = np.ascontiguousarray(keys, np.int32).reshape(-1, 3)
         p = _f32(payload_raw).reshape(-1, 5)
         self._chk(self.L.gsdf_merge_raw(self.h, k.ctypes.data_as(C.POINTER(C.c_int32)), _fp(p), k.shape[0]))
+
+    def merge_from(self, other):
+        """self += other (another context on the same device): gsdf_merge_from."""
+        self._chk(self.L.gsdf_merge_from(self.h, other.h))
 
     def export_raw_dev(self, keys_ptr, payload_ptr, max_n):
         """Unsorted (key, raw sums) compaction into device buffers (e.g. torch tensors' data_ptr())."""

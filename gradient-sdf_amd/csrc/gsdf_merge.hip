@@ -388,6 +388,39 @@ __global__ __launch_bounds__(256) void k_rehash(gsdf_table from, gsdf_table to, 
     pd[0] = ps[0]; pd[1] = ps[1];
     for (int w = 0; w < vw; ++w) vis_to[dst * vw + w] = vis_from[src * vw + w];
 }
+/* gsdf_merge_from: the map of ANOTHER context on the same device added into this one -- one wave per block entry of the source:
+ * lane 0 finds or claims the block in the destination, the 64 lanes add their records (plain read-modify-write: a source block
+ * has one wave, a destination block one source block) and OR the vis_ words in, shifted by the destination's frame count so
+ * that frame f of the source becomes integrated frame (frames of the destination) + f, as in the exchange between ranks. */
+__global__ __launch_bounds__(256) void k_merge_from(gsdf_table from, gsdf_table to, const uint32_t* vis_from, uint32_t* vis_to, int vw,
+                                                    long long bit_offset, size_t n_blocks_from, gsdf_dev_state* st) {
+    const size_t b = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_blocks_from) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bk = from.bkeys[b];
+    if (bk == GSDF_KEY_EMPTY) return;
+    int nb = -1;
+    if (lane == 0) {
+        const uint32_t h = gsdf_hash(bk) & to.block_mask;
+        nb = gsdf_block_find_or_insert(to, bk, h, to.bkeys[h]);
+        if (nb < 0) atomicOr(&st->status, GSDF_STATUS_TABLE_FULL);
+    }
+    nb = __shfl(nb, 0);
+    if (nb < 0) return;
+    const size_t src = b * GSDF_BLOCK_VOX + lane, dst = (size_t)nb * GSDF_BLOCK_VOX + lane;
+    const gsdf_payload s = from.vox[src];
+    if (!(s.w > 0.f)) return;                                  /* the voxel does not exist in the source */
+    gsdf_payload d = to.vox[dst];
+    d.w += s.w; d.s += s.s; d.gx += s.gx; d.gy += s.gy; d.gz += s.gz;
+    to.vox[dst] = d;
+    const int wsh = (int)(bit_offset >> 5), bsh = (int)(bit_offset & 31);
+    for (int w = 0; w < vw; ++w) {
+        const uint32_t v = vis_from[src * vw + w];
+        if (!v) continue;
+        if (w + wsh < vw) vis_to[dst * vw + w + wsh] |= v << bsh;
+        if (bsh && w + wsh + 1 < vw) vis_to[dst * vw + w + wsh + 1] |= v >> (32 - bsh);
+    }
+}
 /* occupied entries of the key array -> one pinned 64-bit host word, count | tag << 32 (auto-grow: the host looks at it without
  * waiting; the tag is the number of the frame entry that enqueued this count, so the host knows how old the number is) */
 __global__ __launch_bounds__(256) void k_count_blocks(const unsigned long long* bkeys, size_t n, unsigned int* scratch,
@@ -527,6 +560,34 @@ int gsdf_rccl_comm_destroy(void* comm) {
     if (!rccl().ok) return gsdf_fail(GSDF_ERR_INVALID, rccl().why);
     RCCL_TRY(rccl().CommDestroy((ncclComm_t)comm));
     return GSDF_OK;
+}
+
+/* Two shard contexts on ONE device ("G logical shards on 1 GPU + local merge"): dst += src.  Both fused frames of the
+ * same job with known poses, each on its own stream; the sums are additive, the frame shards contiguous (dst's frames first). */
+int gsdf_merge_from(gsdf_ctx* dst, gsdf_ctx* src) {
+    if (!dst || !src || dst == src) return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_from: two different contexts are needed");
+    if (dst->device != src->device) return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_from: the contexts live on different devices (use gsdf_merge_allreduce between devices)");
+    if (dst->voxel_size != src->voxel_size || dst->T != src->T) return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_from: voxel size / truncation differ");
+    if ((dst->vis != nullptr) != (src->vis != nullptr) || (dst->vis && dst->vis_words != src->vis_words))
+        return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_from: gsdf_enable_vis must have been called alike on both contexts");
+    HIP_TRY(hipSetDevice(dst->device));
+    if (int rc = gsdf_flush_pending(src)) return rc;
+    if (int rc = gsdf_flush_pending(dst)) return rc;
+    gsdf_dev_state ss, ds;
+    HIP_TRY(hipMemcpyAsync(&ss, src->st, sizeof(ss), hipMemcpyDeviceToHost, src->stream));
+    HIP_TRY(hipStreamSynchronize(src->stream));              /* the source map is complete (and stays untouched) */
+    if (ss.status & GSDF_STATUS_TABLE_FULL) return gsdf_fail(GSDF_ERR_TABLE_FULL, "gsdf_merge_from: the source map reported a full table");
+    HIP_TRY(hipMemcpyAsync(&ds, dst->st, sizeof(ds), hipMemcpyDeviceToHost, dst->stream));
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    const size_t nb_src = src->n_slots / GSDF_BLOCK_VOX;
+    hipLaunchKernelGGL(k_merge_from, dim3((unsigned int)((nb_src + 3) / 4)), dim3(256), 0, dst->stream, src->tab, dst->tab, src->vis, dst->vis,
+                       dst->vis ? dst->vis_words : 0, (long long)ds.frames, nb_src, dst->st);
+    HIP_TRY(hipGetLastError());
+    gsdf_launch_set_frames(dst->stream, dst->st, (long long)(ds.frames + ss.frames));   /* Sdf::counter_ = frames of both shards */
+    dst->occ_dirty = true;
+    dst->ba_gate_fresh = false;
+    dst->grow_forget = true;
+    return read_status(dst);                                  /* synchronises: the source may be reset or destroyed afterwards */
 }
 
 int gsdf_grow(gsdf_ctx* c, int new_capacity_log2) { return gsdf_grow_impl(c, new_capacity_log2); }

@@ -182,6 +182,14 @@ int gsdf_ba_counters(gsdf_ctx* c, int64_t* voxels, int64_t* observations);
 /* additive merge of raw sums into this table (frame-sharded fusion) */
 int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, int64_t n);
 
+/* dst += src for two contexts on the SAME device ("G logical shards on 1 GPU"; the GT-pose branch,
+ * main_scan_3d.cpp:250-254): a GPU can fuse two frame shards at once, each context on its own stream -- a fusion launch leaves
+ * a third of the chip's workgroup slots idle in its tail, which the other context's launch fills -- and adds them up locally
+ * before the exchange between devices.  Voxel sums are added, Sdf::counter_ becomes the frames of both, vis_ bit-vectors of the
+ * source (if enabled, alike on both) are OR-ed in shifted by dst's frame count (dst's frames come first).  Synchronous; src is
+ * left unchanged. */
+int gsdf_merge_from(gsdf_ctx* dst, gsdf_ctx* src);
+
 /* device-buffer variants for the multi-GPU exchange (RCCL works on device memory): unsorted
  * compaction of (key, raw sums) into caller-provided DEVICE buffers / additive merge from them.
  * These are the pack / unpack steps either side of the all-gather. */
