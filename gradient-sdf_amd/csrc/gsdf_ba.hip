@@ -202,11 +202,15 @@ __global__ __launch_bounds__(256) void k_ba_energy(ba_args a, double* block_E) {
 
 /* ---- solveDist ---- */
 /* block_cnt (nullable): [2][gridDim.x] -- the workgroup's voxels with at least one observation and their observations */
-__global__ __launch_bounds__(256) void k_ba_dist(ba_args a, float damping, double* block_cnt) {
-    __shared__ double red[2][4];
+/* 512 lanes per workgroup: the sweep is a latency chain per lane (a keyframe's projection, then its twelve scattered pixel
+ * reads), so it wants every wave the registers allow -- 98 VGPRs = 4 per SIMD = two workgroups of eight waves per CU, where
+ * 256-lane workgroups of the same grid left it at two (1.58 ms for C5's 1.42 M voxels) */
+#define BA_DIST_THREADS 512
+__global__ __launch_bounds__(BA_DIST_THREADS) void k_ba_dist(ba_args a, float damping, double* block_cnt) {
+    __shared__ double red[2][BA_DIST_THREADS / 64];
     unsigned int n_act = 0u, n_obs = 0u;
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x; slot < a.n_slots; slot += stride) {
+    const size_t stride = (size_t)gridDim.x * BA_DIST_THREADS;
+    for (size_t slot = (size_t)blockIdx.x * BA_DIST_THREADS + threadIdx.x; slot < a.n_slots; slot += stride) {
         ba_voxel v;
         if (!ba_load_voxel(a, slot, &v)) continue;
         int Nj = 0;
@@ -248,7 +252,11 @@ __global__ __launch_bounds__(256) void k_ba_dist(ba_args a, float damping, doubl
         for (int off = 32; off > 0; off >>= 1) { cA += __shfl_down(cA, off); cO += __shfl_down(cO, off); }
         if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cA; red[1][threadIdx.x >> 6] = cO; }
         __syncthreads();
-        if (threadIdx.x < 2) block_cnt[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+        if (threadIdx.x < 2) {                                                  /* (small integers: exact in any order) */
+            double t = 0.0;
+            for (int w = 0; w < BA_DIST_THREADS / 64; ++w) t += red[threadIdx.x][w];
+            block_cnt[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = t;
+        }
     }
 }
 
@@ -327,12 +335,16 @@ __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /*
     __syncthreads();
     for (int i = threadIdx.x; i < a.n * BA_NV; i += 256) block_part[(size_t)blockIdx.x * a.n * BA_NV + i] = acc[i];
 }
-__global__ void k_ba_pose_reduce(const float* block_part, int n_blocks, int n_vals, float* out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+/* one WAVE per value: lane l adds the partials of workgroups l, l + 64, ... in that order, the 64 lane sums are then added in a
+ * fixed tree -- a fixed order, so deterministic like the sequential loop it replaces (one lane per value walking all 512
+ * partials: 124 us of dependent strided loads for 1 350 numbers) */
+__global__ __launch_bounds__(256) void k_ba_pose_reduce(const float* block_part, int n_blocks, int n_vals, float* out) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= n_vals) return;
     float s = 0.f;
-    for (int b = 0; b < n_blocks; ++b) s += block_part[(size_t)b * n_vals + j];   /* fixed order */
-    out[j] = s;
+    for (int b = lane; b < n_blocks; b += 64) s += block_part[(size_t)b * n_vals + j];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) out[j] = s;
 }
 
 /* the gate of getEnergy / solvePose as a predicate over slot numbers: the voxel exists and |dist| <= vs (the same s / w division
@@ -360,12 +372,12 @@ void gsdf_launch_ba_energy(hipStream_t s, const gsdf_ba_dev& d, double* block_E)
 }
 void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping, double* block_cnt) {
     ba_args a; std::memcpy(&a, &d, sizeof(a));
-    hipLaunchKernelGGL(k_ba_dist, dim3(BA_BLOCKS), dim3(256), 0, s, a, damping, block_cnt);
+    hipLaunchKernelGGL(k_ba_dist, dim3(BA_BLOCKS), dim3(BA_DIST_THREADS), 0, s, a, damping, block_cnt);
 }
 void gsdf_launch_ba_pose(hipStream_t s, const gsdf_ba_dev& d, float* block_part, float* out) {
     ba_args a; std::memcpy(&a, &d, sizeof(a));
     hipLaunchKernelGGL(k_ba_pose, dim3(BA_BLOCKS), dim3(256), (size_t)a.n * BA_NV * sizeof(float), s, a, block_part);
     const int n_vals = a.n * BA_NV;
-    hipLaunchKernelGGL(k_ba_pose_reduce, dim3((n_vals + 63) / 64), dim3(64), 0, s, block_part, BA_BLOCKS, n_vals, out);
+    hipLaunchKernelGGL(k_ba_pose_reduce, dim3((n_vals + 3) / 4), dim3(256), 0, s, block_part, BA_BLOCKS, n_vals, out);
 }
 int gsdf_ba_blocks(void) { return BA_BLOCKS; }
