@@ -741,7 +741,7 @@ def two_streams_flavour(pkg, args, seq, frames, local_rank, vs, T, W, H, Wm, K):
     GPU).  A single dependent stream leaves the chip idle between a third (fusion tail) and nine tenths (tracker passes) of the
     time; the second stream's launches fill some of it.  Aggregate frames/s of both streams, reported BESIDE `value`, never as it."""
     import threading
-    ctxs = [pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=args.hash_capacity_log2, device=local_rank) for _ in range(2)]
+    ctxs = pkg.GradSdf.shards(2, vs, T, W, H, seq.K, capacity_log2=args.hash_capacity_log2, device=local_rank)   # a hardware queue each
     devs = [[g.upload(f[0]) for f in frames] for g in ctxs]
     d0, R0, t0 = frames[0]
     p0 = np.concatenate([t0, pkg_quat(R0)]).astype(np.float32)
@@ -847,7 +847,12 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
     exists before the timed region -- after which every rank holds the map of all frames; rank 0 extracts the mesh.
     Weak scaling: --c4-frames per rank.  Two rounds, the second one is reported (the first one warms RCCL's channels)."""
     seq, frames, F, total = c4["seq"], c4["frames"], c4["F"], c4["total"]
-    g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=23, device=local_rank)
+    ncx = max(1, min(2, args.contexts_per_gpu))
+    g2 = None
+    if ncx > 1:     # two shard contexts whose streams sit in two hardware queues of their own (gsdf_create_shards)
+        g, g2 = pkg.GradSdf.shards(2, vs, T, W, H, seq.K, capacity_log2=23, device=local_rank)
+    else:
+        g = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=23, device=local_rank)
     dev = [g.upload(f[0]) for f in frames]
 
     def barrier():
@@ -906,19 +911,59 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
         dist.all_reduce(t)
         return t.cpu().numpy()
 
+    # ---- one context per GPU first (the form of rounds 1-4): its rate, and its map as the yardstick for the two-context form ----
+    one_fps, ref_map, dev2, half = None, None, None, F
+    if ncx > 1:
+        for rnd in range(2):
+            g.reset()
+            barrier()
+            t0 = time.perf_counter()
+            for j, (d, f) in enumerate(zip(dev, frames)):
+                g.update_dev(d, f[1], f[2])
+                if j % 32 == 31:
+                    g.sync()
+            g.sync()
+            one_fps = total / vmax([time.perf_counter() - t0])[0]
+        ref_map = g.export(sorted=True, raw=True)
+        half = (F + 1) // 2                                       # g takes the first frames of the shard, g2 the rest (contiguous)
+        dev2 = [g2.upload(f[0]) for f in frames[half:]]
+
     res = {}
     for rnd in range(2):
         g.reset()
+        if g2 is not None:
+            g2.reset()
         barrier()
         t0 = time.perf_counter()
-        for j, (d, f) in enumerate(zip(dev, frames)):
-            g.update_dev(d, f[1], f[2])
-            if j % 32 == 31:
-                g.sync()
-        g.sync()
+        if g2 is not None:
+            # SURVEY.md 8e "G logical shards on 1 GPU": TWO shard contexts on this GPU, each on its own stream, enqueued alternately
+            # -- a fusion launch leaves a third of the chip's workgroup slots idle in its tail, which the other context's launch
+            # fills (measured 1.22-1.28x one context, tools/two_contexts.py) -- then the local sum (gsdf_merge_from, ~0.1 ms),
+            # then the exchange between the GPUs
+            for j in range(half):
+                g.update_dev(dev[j], frames[j][1], frames[j][2])
+                if half + j < F:
+                    g2.update_dev(dev2[j], frames[half + j][1], frames[half + j][2])
+                if j % 32 == 31:
+                    g.sync(); g2.sync()
+            g.sync(); g2.sync()
+            t_m = time.perf_counter()
+            g.merge_from(g2)
+            t_merge = time.perf_counter() - t_m
+        else:
+            for j, (d, f) in enumerate(zip(dev, frames)):
+                g.update_dev(d, f[1], f[2])
+                if j % 32 == 31:
+                    g.sync()
+            g.sync()
+            t_merge = 0.0
         t_fuse = time.perf_counter() - t0
         own = g.count()
-        ref_map = g.export(sorted=True, raw=True) if (rnd == 1 and args.contexts_per_gpu > 1) else None
+        same = None
+        if g2 is not None and rnd == 1:
+            k2, p2 = g.export(sorted=True, raw=True)
+            same = bool(k2.shape == ref_map[0].shape and np.array_equal(k2, ref_map[0]) and
+                        float((np.abs(p2 - ref_map[1]).max(axis=1) / np.maximum(1.0, ref_map[1][:, 4])).max()) <= 1e-5)
         barrier()
         t1 = time.perf_counter()
         if use_rccl:
@@ -927,10 +972,14 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
             nb, nbytes = g.merge_allreduce_with(ag, ar, world)
         g.sync()
         t_exch = time.perf_counter() - t1
-        t_fuse, t_exch, t_both = vmax([t_fuse, t_exch, t_fuse + t_exch])
+        t_fuse, t_exch, t_both, t_merge = vmax([t_fuse, t_exch, t_fuse + t_exch, t_merge])
         res = {"frames_per_rank": F, "frames_total": total, "ranks": world, "rccl_ranks": rccl_ranks, "transport": transport,
+               "contexts_per_gpu": ncx,
                "sharded_fused_fps": round(total / t_fuse, 1), "sharded_fused_fps_incl_exchange": round(total / t_both, 1),
-               "fuse_ms": round(t_fuse * 1e3, 3), "exchange_ms": round(t_exch * 1e3, 3), "exchange_bytes": int(nbytes),
+               "one_context_fused_fps": round(one_fps, 1) if one_fps else None,
+               "same_map_as_one_context": same,
+               "fuse_ms": round(t_fuse * 1e3, 3), "local_merge_ms": round(t_merge * 1e3, 3) if g2 is not None else None,
+               "exchange_ms": round(t_exch * 1e3, 3), "exchange_bytes": int(nbytes),
                "exchange_blocks": int(nb), "voxels_own_shard": int(own)}
     res["voxels_merged"] = int(g.count())
     res["frames_counter_after_merge"] = int(g.stats()["frames"])
@@ -942,38 +991,8 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
     barrier()
     if comm is not None:
         pkg.binding.rccl_comm_destroy(comm)
-    # ---- SURVEY.md 8e "G logical shards on 1 GPU": the same shard on TWO contexts of this GPU, each on its own stream, enqueued
-    # alternately, then added up locally (gsdf_merge_from) -- the step that would sit in front of the exchange.  Measured beside
-    # the one-context form above (never instead of it): a k_fuse launch with its normals riders already fills the chip, so a
-    # second queue mostly time-slices with the first.
-    if args.contexts_per_gpu > 1:
-        try:
-            g2 = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=23, device=local_rank)
-            half = (F + 1) // 2                                   # g takes the first frames of the shard, g2 the rest (contiguous)
-            dev2 = [g2.upload(f[0]) for f in frames[half:]]
-            for rnd in range(2):
-                g.reset(); g2.reset()
-                barrier()
-                t0 = time.perf_counter()
-                for j in range(half):
-                    g.update_dev(dev[j], frames[j][1], frames[j][2])
-                    if half + j < F:
-                        g2.update_dev(dev2[j], frames[half + j][1], frames[half + j][2])
-                    if j % 16 == 15:
-                        g.sync(); g2.sync()
-                g.sync(); g2.sync()
-                t_m = time.perf_counter()
-                g.merge_from(g2)
-                t_merge = time.perf_counter() - t_m
-                t_two, t_merge = vmax([time.perf_counter() - t0, t_merge])
-            k2, p2 = g.export(sorted=True, raw=True)
-            same = bool(ref_map is not None and k2.shape == ref_map[0].shape and np.array_equal(k2, ref_map[0]) and
-                        float((np.abs(p2 - ref_map[1]).max(axis=1) / np.maximum(1.0, ref_map[1][:, 4])).max()) <= 1e-5)
-            res["two_contexts_per_gpu"] = {"fused_fps_incl_local_merge": round(total / t_two, 1), "local_merge_ms": round(t_merge * 1e3, 3),
-                                           "same_map_as_one_context": same, "frames_after_merge": int(g.stats()["frames"])}
-            g2.close()
-        except Exception as e:                                   # noqa: BLE001
-            res["two_contexts_per_gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if g2 is not None:
+        g2.close()
     g.close()
     return res
 

@@ -130,6 +130,7 @@ def load(path=None):
         "gsdf_set_auto_grow": (C.c_int, [vp, C.c_int]),
         "gsdf_capacity": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "gsdf_merge_from": (C.c_int, [vp, vp]),
+        "gsdf_create_shards": (C.c_int, [C.POINTER(vp), C.c_int, C.c_float, C.c_float, C.c_int, C.c_int]),
         "gsdf_merge_raw": (C.c_int, [vp, i32p, fp, C.c_int64]),
         "gsdf_export_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64, i64p]),
         "gsdf_merge_raw_dev": (C.c_int, [vp, vp, vp, C.c_int64]),
@@ -181,7 +182,7 @@ ABI_SYMBOLS = [
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
     "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
-    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow", "gsdf_capacity", "gsdf_merge_from", "gsdf_merge_prepare",
+    "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow", "gsdf_capacity", "gsdf_merge_from", "gsdf_create_shards", "gsdf_merge_prepare",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
     "gsdf_merge_raw_dev", "gsdf_block_keys_dev", "gsdf_pack_blocks_dev", "gsdf_unpack_blocks_dev",
     "gsdf_merge_allreduce", "gsdf_merge_allreduce_with", "gsdf_rccl_unique_id", "gsdf_rccl_comm_init", "gsdf_rccl_comm_count",
@@ -239,16 +240,31 @@ class GradSdf:
     """MapGradPixelSdf + RigidPointOptimizer + NormalEstimator behind the C-ABI (one GPU)."""
 
     def __init__(self, voxel_size, trunc_dist, W, H, K, win=11, capacity_log2=22, device=0,
-                 zmin=0.5, zmax=3.5, lib=None):
+                 zmin=0.5, zmax=3.5, lib=None, _handle=None):
         self.L = load() if lib is None else lib         # lib: load_test_lib() for the path-forcing tests
         self.h = C.c_void_p()
-        self._chk(self.L.gsdf_create(C.byref(self.h), np.float32(voxel_size), np.float32(trunc_dist),
-                                     int(capacity_log2), int(device)))
+        if _handle is not None:                         # (GradSdf.shards: the context exists already)
+            self.h = _handle
+        else:
+            self._chk(self.L.gsdf_create(C.byref(self.h), np.float32(voxel_size), np.float32(trunc_dist),
+                                         int(capacity_log2), int(device)))
         self.W, self.H = int(W), int(H)
         self.K = _f32(K).reshape(9).copy()
         self._chk(self.L.gsdf_set_zrange(self.h, np.float32(zmin), np.float32(zmax)))
         self._chk(self.L.gsdf_normals_init(self.h, self.W, self.H, _fp(self.K), int(win)))
         self._dev = []
+
+    @classmethod
+    def shards(cls, n, voxel_size, trunc_dist, W, H, K, capacity_log2=22, device=0, **kw):
+        """n contexts for n frame shards on one device, each stream in its own hardware queue (gsdf_create_shards); add them up
+        with first.merge_from(other)."""
+        L = load()
+        hs = (C.c_void_p * n)()
+        rc = L.gsdf_create_shards(hs, int(n), np.float32(voxel_size), np.float32(trunc_dist), int(capacity_log2), int(device))
+        if rc != GSDF_OK:
+            raise GsdfError(rc, L.gsdf_last_error().decode())
+        return [cls(voxel_size, trunc_dist, W, H, K, capacity_log2=capacity_log2, device=device, _handle=C.c_void_p(hs[i]), **kw)
+                for i in range(n)]
 
     def _chk(self, rc):
         if rc != GSDF_OK:

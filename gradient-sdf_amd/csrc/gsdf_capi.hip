@@ -454,7 +454,26 @@ const char* gsdf_version(void) { return "gsdf-mi355x 0.2 (gfx950) +experiments";
 const char* gsdf_version(void) { return "gsdf-mi355x 0.2 (gfx950)"; }
 #endif
 
+static int create_impl(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device, bool other_queue);
 int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device) {
+    return create_impl(out, voxel_size, trunc_dist, capacity_log2, device, false);
+}
+/* n contexts for n frame shards on ONE device (gsdf_merge_from adds them up): their streams are created with the device's
+ * HIGHEST stream priority.  The HIP runtime keeps one pool of hardware queues per priority and hands a new stream the
+ * least-used queue of its pool; the normal pool is shared with every other stream of the process (the contexts' copy streams,
+ * PyTorch's, ...), and two streams that land in one queue do not overlap -- measured inside bench.py: two normal-priority
+ * contexts fused 24 500 frames/s where two on separate queues reach 31 600.  Nothing else uses the high-priority pool, so up to
+ * four shard contexts get a queue each, at EQUAL priority. */
+int gsdf_create_shards(gsdf_ctx** out, int n, float voxel_size, float trunc_dist, int capacity_log2, int device) {
+    if (!out || n < 1 || n > 4) return fail(GSDF_ERR_INVALID, "gsdf_create_shards: 1..4 contexts (one hardware queue each)");
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    for (int i = 0; i < n; ++i) {
+        const int rc = create_impl(&out[i], voxel_size, trunc_dist, capacity_log2, device, true);
+        if (rc) { for (int j = 0; j < i; ++j) { gsdf_destroy(out[j]); out[j] = nullptr; } return rc; }
+    }
+    return GSDF_OK;
+}
+static int create_impl(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity_log2, int device, bool other_queue) {
     if (!out) return fail(GSDF_ERR_INVALID, "out == NULL");
     *out = nullptr;
     if (!(voxel_size > 0.f) || !(trunc_dist > 0.f)) return fail(GSDF_ERR_INVALID, "voxel_size and trunc_dist must be > 0");
@@ -477,7 +496,10 @@ int gsdf_create(gsdf_ctx** out, float voxel_size, float trunc_dist, int capacity
     c->capacity_log2 = capacity_log2;
     c->n_slots = (size_t)1 << capacity_log2;
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+    int prio_least = 0, prio_greatest = 0;
+    if (other_queue && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_greatest = 0; }
+    if ((e = (other_queue ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest)
+                          : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking))) != hipSuccess ||
         (e = hipMalloc((void**)&c->tab.vox, c->n_slots * sizeof(gsdf_payload))) != hipSuccess ||
         (e = hipMalloc((void**)&c->tab.bkeys, (c->n_slots / GSDF_BLOCK_VOX) * sizeof(unsigned long long))) != hipSuccess ||
         /* block filter (64 bits per block entry) followed by the cell filter (1 bit per block entry, at least one word) */

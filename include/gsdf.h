@@ -189,6 +189,11 @@ int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, i
  * source (if enabled, alike on both) are OR-ed in shifted by dst's frame count (dst's frames come first).  Synchronous; src is
  * left unchanged. */
 int gsdf_merge_from(gsdf_ctx* dst, gsdf_ctx* src);
+/* n (1..4) contexts for n frame shards on ONE device, like gsdf_create each -- but their streams are guaranteed to sit in n
+ * different hardware queues (created at the device's highest stream priority: the runtime pools its queues per priority, and
+ * nothing else uses that pool), so that their launches overlap.  Streams of the default priority share queues as soon as the
+ * process holds more streams than the runtime has queues (4), and then two contexts fuse no faster than one. */
+int gsdf_create_shards(gsdf_ctx** out, int n, float voxel_size, float trunc_dist, int capacity_log2, int device);
 
 /* device-buffer variants for the multi-GPU exchange (RCCL works on device memory): unsorted
  * compaction of (key, raw sums) into caller-provided DEVICE buffers / additive merge from them.

@@ -290,8 +290,7 @@ def test_merge_from_two_contexts_on_one_gpu(pkg, O):
     seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=5, step_deg=3.0)
     vs = np.float32(0.02)
     T = np.float32(5) * vs
-    a = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=20)
-    b = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=19)          # (another capacity: blocks are re-hashed into dst's table)
+    a, b = pkg.GradSdf.shards(2, vs, T, W, H, seq.K, capacity_log2=20)   # gsdf_create_shards: a hardware queue each
     a.enable_vis(32); b.enable_vis(32)
     fr = [seq.frame(i) for i in range(n)]
     da = [a.upload(f[0]) for f in fr[:6]]
