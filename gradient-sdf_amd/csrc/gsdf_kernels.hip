@@ -1326,7 +1326,14 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         unsigned long long* c = a.blk_counters + 4 * ((size_t)tile_y * a.ntx + tile_x);
         c[0] = nu; c[1] = nv;
         if (nu | nv) { c[2] += nu; c[3] += nv; }                      /* (an empty tile does not wait for its totals to arrive) */
-        if (tile_x == 0 && tile_y == 0) a.st->frames += 1;            /* :120 increase_counter() */
+        if (tile_x == 0 && tile_y == 0) {                             /* :120 increase_counter() */
+            /* read by the launch's LAST workgroup below, which may sit on another XCD: a plain store would wait in this XCD's L2
+             * until the kernel ends (the per-XCD L2s are not coherent for plain accesses) and the snapshot for the next update()
+             * would, rarely, be the OLD counter -- vis_ bits of the next frame one position too low (seen once in 30 runs of the
+             * eight-process exchange test).  An agent-scope atomic, released before this workgroup takes its ticket. */
+            __hip_atomic_fetch_add(&a.st->frames, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
         /* Arrival.  The deferred contributions (near tiles, LDS overflow, timed-out waits: normally a handful) are added
          * by whichever workgroup finishes last, so the common case needs no second launch.  A workgroup that appended to
          * the list releases its entries first (cdna_hip_programming.md G16: stores -> barrier -> one agent-scope release
@@ -1366,7 +1373,7 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         /* Sdf::counter_ as the NEXT update() will see it (this launch's increment included: tile (0, 0) arrived before this
          * workgroup read the ticket).  The normals stage used to take this snapshot; in GT-pose mode it now runs on its own
          * stream beside this kernel and must not touch state the fusion uses. */
-        a.st->frame_cur = a.st->frames;
+        a.st->frame_cur = __hip_atomic_load(&a.st->frames, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.use_dev_pose) fuse_log_row(a);
     }
 }
@@ -1938,6 +1945,9 @@ void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float
         const int per = (chunks + cap - 1) / cap;
         n_blocks = (chunks + per - 1) / per;
     }
+    /* the launch behind the last pass only finishes it (head: reduce, solve, publish): one workgroup does -- workgroup 0 is the
+     * one that publishes; the others would solve the same system and return */
+    if (tp.pass_index >= tp.max_passes && !normals) n_blocks = 1;
     tp.n_track_blocks = n_blocks;
     gsdf_normals_job nj;
     memset(&nj, 0, sizeof(nj));
