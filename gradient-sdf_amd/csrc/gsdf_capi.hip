@@ -94,7 +94,8 @@ static int fuse_far_table(const gsdf_ctx* c) {
 /* Auto-grow (gsdf_set_auto_grow): called at the top of the frame entries (gsdf_update_dev, gsdf_track_and_fuse_dev).
  *
  * The table is doubled once 45 % of its block entries are in use (the probe budget runs out near 95 %).  The load is the
- * count a 64-workgroup kernel leaves in a pinned word; it is enqueued at the top of EVERY entry, tagged with the entry's
+ * count a 64-workgroup kernel leaves in a pinned word; it is enqueued at the top of every entry (every fourth while the
+ * estimate is below 25 %), tagged with the entry's
  * number, and read without waiting -- so the number the host sees is some entries old, and the host may run ahead of the
  * device (an unsynchronised gsdf_update_dev loop).  What keeps the doubling in time:
  *  - the age of the count is known (the tag), and so is how fast the map grew lately (max over the recent counts, decaying):
@@ -113,7 +114,7 @@ static int auto_grow_step(gsdf_ctx* c) {
     volatile unsigned long long* word = reinterpret_cast<volatile unsigned long long*>(c->progress + 4);
     if (c->grow_forget) {                                   /* a reset or a doubling: the counts so far describe another table */
         c->grow_forget = false;
-        c->grow_seq = 0; c->grow_prev_seq = 0; c->grow_prev_cnt = 0; c->grow_rate = 0; c->grow_counts_seen = 0;
+        c->grow_seq = 0; c->grow_prev_seq = 0; c->grow_prev_cnt = 0; c->grow_rate = 0; c->grow_counts_seen = 0; c->grow_last_enq = 0;
         HIP_TRY(hipStreamSynchronize(c->stream));           /* no count kernel of the old numbering is in flight any more */
         *word = 0ull;
     }
@@ -151,6 +152,7 @@ static int auto_grow_step(gsdf_ctx* c) {
         int rc = gsdf_flush_pending(c);                      /* a fusion kept back by the pipelined path counts too */
         if (rc) return rc;
         gsdf_enqueue_block_count(c, k);
+        c->grow_last_enq = k;
         HIP_TRY(hipStreamSynchronize(c->stream));
         ++c->grow_syncs;
         look(cnt, seen);
@@ -160,7 +162,10 @@ static int auto_grow_step(gsdf_ctx* c) {
         }
         return GSDF_OK;
     }
-    gsdf_enqueue_block_count(c, k);
+    /* far below the limit (estimate under 25 % of the entries) a count every fourth entry will do: the 3 us kernel and its
+     * launch boundary are ~4 % of a tracked frame */
+    const bool near = ((size_t)cnt + 2u * (size_t)uncovered * std::max(c->grow_rate, 1u)) * 100u > cap_blocks * 25u;
+    if (near || k - c->grow_last_enq >= 4u) { gsdf_enqueue_block_count(c, k); c->grow_last_enq = k; }
     return GSDF_OK;
 }
 

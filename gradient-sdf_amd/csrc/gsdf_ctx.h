@@ -89,6 +89,7 @@ struct gsdf_ctx {
      * finds the key array more than GSDF_GROW_LOAD full doubles the table first */
     int auto_grow_max = 0;                         /* largest capacity_log2 auto-grow may reach; 0 = off */
     unsigned int grow_seq = 0;                     /* frame entries since auto-grow was switched on / the map was reset or grown */
+    unsigned int grow_last_enq = 0;                /* entry whose count was enqueued last */
     unsigned int grow_prev_seq = 0, grow_prev_cnt = 0;   /* the newest finished count the growth rate was updated from */
     unsigned int grow_rate = 0;                    /* blocks a frame added lately (max over recent counts, decaying) */
     int grow_counts_seen = 0;                      /* finished counts seen since grow_seq restarted (the rate needs two) */
