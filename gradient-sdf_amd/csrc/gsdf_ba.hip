@@ -302,11 +302,22 @@ __global__ __launch_bounds__(BA_DIST_THREADS) void k_ba_dist(ba_args a, float da
 
 /* ---- solvePose: per-workgroup partial (b_i, H_i upper triangle) for every keyframe ---- */
 #define BA_NV 27
+/* BA_POSE_SLICES workgroups (blockIdx.y) share a set of voxels: each takes every BA_POSE_SLICES-th keyframe of the second loop
+ * (the per-keyframe Jacobians and their 27-value wave reduction: 85 % of a wave's instructions).  The gate list holds ~10^5
+ * voxels = ~2000 waves: one wave per SIMD and a chain of ~35 k dependent instructions each (308 us for C5); sliced, the chip
+ * holds four times the waves and each chain is a third as long.  The first loop (the voxel's mean intensity) is repeated by
+ * every slice. */
+#define BA_POSE_SLICES 4
 __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /* [gridDim.x][n][BA_NV] */) {
-    extern __shared__ float acc[];                                             /* [n][BA_NV] */
-    for (int i = threadIdx.x; i < a.n * BA_NV; i += 256) acc[i] = 0.f;
+    const int slice = (int)blockIdx.y;
+    /* one accumulator set per WAVE, [4][n][BA_NV]: lane 63 adds its wave's 27 sums of a keyframe with plain LDS read-modify-
+     * writes.  (They were float atomics on one set shared by the four waves: ds_add_f32 is lane-serial, ~190 cycles per
+     * instruction -- 27 of them per keyframe and wave were two thirds of this kernel.) */
+    extern __shared__ float acc[];
+    for (int i = threadIdx.x; i < 4 * a.n * BA_NV; i += 256) acc[i] = 0.f;
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    float* wacc = acc + (size_t)(threadIdx.x >> 6) * a.n * BA_NV;
     const size_t stride = (size_t)gridDim.x * 256;
     const size_t n_items = a.gate_list ? (size_t)*a.gate_count : a.n_slots;
     const size_t n_iter = (n_items + stride - 1) / stride;
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /*
             }
         const float inv_Nj = Nj ? (float)(1. / (double)(float)Nj) : 0.f;
         mean = gsdf_v3{ inv_Nj * mean.x, inv_Nj * mean.y, inv_Nj * mean.z };
-        for (int i = 0; i < a.n; ++i) {
+        for (int i = slice; i < a.n; i += BA_POSE_SLICES) {
             const bool mine = ok && Nj && ((seen >> (i & 63)) & 1ull);
             if (!__any(mine)) continue;                                        /* wave-uniform skip */
             float val[BA_NV];
@@ -369,12 +380,15 @@ __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /*
             ba_wave_sum_to_lane63(val);
             if (lane == 63) {
 #pragma unroll
-                for (int k = 0; k < BA_NV; ++k) atomicAdd(&acc[i * BA_NV + k], val[k]);   /* 4 waves per workgroup */
+                for (int k = 0; k < BA_NV; ++k) wacc[i * BA_NV + k] += val[k];
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < a.n * BA_NV; i += 256) block_part[(size_t)blockIdx.x * a.n * BA_NV + i] = acc[i];
+    const int nv = a.n * BA_NV;
+    for (int i = threadIdx.x; i < nv; i += 256)
+        if ((i / BA_NV) % BA_POSE_SLICES == slice)                                                   /* this slice's keyframes */
+            block_part[(size_t)blockIdx.x * nv + i] = (acc[i] + acc[nv + i]) + (acc[2 * nv + i] + acc[3 * nv + i]);
 }
 /* one WAVE per value: lane l adds the partials of workgroups l, l + 64, ... in that order, the 64 lane sums are then added in a
  * fixed tree -- a fixed order, so deterministic like the sequential loop it replaces (one lane per value walking all 512
@@ -417,7 +431,7 @@ void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping, dou
 }
 void gsdf_launch_ba_pose(hipStream_t s, const gsdf_ba_dev& d, float* block_part, float* out) {
     ba_args a; std::memcpy(&a, &d, sizeof(a));
-    hipLaunchKernelGGL(k_ba_pose, dim3(BA_BLOCKS), dim3(256), (size_t)a.n * BA_NV * sizeof(float), s, a, block_part);
+    hipLaunchKernelGGL(k_ba_pose, dim3(BA_BLOCKS, BA_POSE_SLICES), dim3(256), (size_t)4 * a.n * BA_NV * sizeof(float), s, a, block_part);
     const int n_vals = a.n * BA_NV;
     hipLaunchKernelGGL(k_ba_pose_reduce, dim3((n_vals + 3) / 4), dim3(256), 0, s, block_part, BA_BLOCKS, n_vals, out);
 }
