@@ -760,12 +760,17 @@ def two_streams_flavour(pkg, args, seq, frames, local_rank, vs, T, W, H, Wm, K):
         gate = threading.Barrier(3)
         done = [0.0, 0.0]
 
+        errs = []
+
         def body(k):
             g, dev = ctxs[k], devs[k]
-            gate.wait()
-            for i in range(1 + Wm, 1 + Wm + K):
-                g.track_and_fuse_dev(dev[i])
-            g.sync()
+            try:
+                gate.wait()
+                for i in range(1 + Wm, 1 + Wm + K):
+                    g.track_and_fuse_dev(dev[i])
+                g.sync()
+            except Exception as e:                              # noqa: BLE001 -- reported by the caller's thread below
+                errs.append(e)
             done[k] = time.perf_counter()
         th = [threading.Thread(target=body, args=(k,)) for k in range(2)]
         for t in th:
@@ -774,6 +779,8 @@ def two_streams_flavour(pkg, args, seq, frames, local_rank, vs, T, W, H, Wm, K):
         t_start = time.perf_counter()
         for t in th:
             t.join()
+        if errs:
+            raise errs[0]
         if rep:
             runs.append(max(done) - t_start)
     logs = [g.frame_log()[Wm:Wm + K] for g in ctxs]
