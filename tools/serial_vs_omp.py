@@ -7,7 +7,7 @@ would be between the reference's own serial and OMP builds" (RigidPointOptimizer
 instead of one sequential sum; MapGradPixelSdfOmp.cpp:112: fusion order left to the scheduler).  This tool MEASURES that: the
 serial oracle against its OMP-structured variant in the same harness (tests/lockstep.py), same streams, same rules.
 
-    python tools/serial_vs_omp.py [bench|c1] [frames]     -> profiles/r05_serial_vs_omp.txt (appended to stdout)
+    python tools/serial_vs_omp.py [bench|c1] [frames] | free    -> profiles/r05_serial_vs_omp.txt (appended to stdout)
 
 CPU only; the bench stretch (48 frames of 640x480) takes a few minutes on 4 cores."""
 import os
@@ -62,7 +62,37 @@ def run(which, n, threads=4):
     return n_conv, n_long, flips
 
 
+def free_running(n=6, threads=4):
+    """The free-running comparison of test_track_and_fuse_stream_matches_oracle_loop (6 sphere frames, 640x480): each build
+    tracks and fuses on its OWN poses and map -- how far do the reference's two builds drift apart per frame?"""
+    pkg, O = graft.package(), graft.oracle_module()
+    W, H = 640, 480
+    seq = pkg.synth.Sequence("spheres", W, H, n_frames=n, seed=0, step_deg=0.5)
+    vs = np.float32(0.01)
+    T = np.float32(10) * vs
+    fr = [seq.frame(i) for i in range(n)]
+    a, b = O.Oracle(vs, T, W, H, seq.K, threads=1), O.Oracle(vs, T, W, H, seq.K, threads=threads)
+    d0, R0, t0 = fr[0]
+    p = np.concatenate([t0, O.R_to_quat(R0)]).astype(np.float32)
+    R0q = O.quat_to_R(p[3:])
+    a.update(d0, R0q, t0)
+    b.update(d0, R0q, t0, omp=True)
+    pa, pb = p.copy(), p.copy()
+    print("free-running spheres stream, %d frames, serial vs OMP-structured oracle, each on its own poses and map:" % n)
+    for i in range(1, n):
+        ca, pa, ua, _, _ = a.track(fr[i][0], pa)
+        cb, pb, ub, _, _ = b.track(fr[i][0], pb, omp=True)
+        if ca:
+            a.update(fr[i][0], O.quat_to_R(pa[3:]), pa[:3])
+        if cb:
+            b.update(fr[i][0], O.quat_to_R(pb[3:]), pb[:3], omp=True)
+        print("  frame %d: serial %s / %d passes, OMP %s / %d passes, max |pose difference| %.2e" % (i, ca, ua, cb, ub, float(np.abs(pa - pb).max())))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "free":
+        free_running()
+        sys.exit(0)
     which = sys.argv[1] if len(sys.argv) > 1 else "bench"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else (48 if which == "bench" else 30)
     run(which, n)
