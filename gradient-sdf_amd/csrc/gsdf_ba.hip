@@ -196,48 +196,33 @@ __device__ __forceinline__ void ba_wave_sum_to_lane63(float (&v)[N]) {
 /* ---- getEnergy ---- */
 /* block_E: [3][gridDim.x] -- the workgroup's energy, its voxels that took part (|dist| <= vs, seen by >= 1 keyframe) and their
  * observations (voxel x keyframe pairs that project into the image): the counts are the units of the sweep's algorithmic bytes */
-/* FOUR lanes per voxel (a quad): lane j takes the keyframes i = j, j + 4, ...; the voxel's mean is the quad's sum (two DPP
- * quad permutes: every lane of the quad ends with the same (s0 + s1) + (s2 + s3)).  The gate list holds ~10^5 voxels -- at one
- * lane per voxel ~2000 waves, each a chain of ~60 dependent gathers (117 us for C5); as quads the chip holds four times the
- * waves and each chain is a quarter as long. */
-template <int QP>
-__device__ __forceinline__ float ba_quad(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), QP, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float ba_quad_sum(float v) {
-    v += ba_quad<0xB1>(v);                                   /* quad_perm [1,0,3,2] */
-    return v + ba_quad<0x4E>(v);                             /* quad_perm [2,3,0,1] */
-}
 __global__ __launch_bounds__(256) void k_ba_energy(ba_args a, double* block_E) {
     __shared__ double red[3][4];
     double E = 0.0;
     unsigned int n_act = 0u, n_obs = 0u;
-    const int j = (int)(threadIdx.x & 3u);
-    const size_t stride = (size_t)gridDim.x * 64;
+    const size_t stride = (size_t)gridDim.x * 256;
     const size_t n_items = a.gate_list ? (size_t)*a.gate_count : a.n_slots;
-    for (size_t item = (size_t)blockIdx.x * 64 + (threadIdx.x >> 2); item < n_items; item += stride) {
+    for (size_t item = (size_t)blockIdx.x * 256 + threadIdx.x; item < n_items; item += stride) {
         const size_t slot = a.gate_list ? (size_t)a.gate_list[item] : item;
         ba_voxel v;
-        if (!ba_load_voxel(a, slot, &v)) continue;                            /* (the same for the four lanes of a quad) */
+        if (!ba_load_voxel(a, slot, &v)) continue;
         if (fabsf(v.dist) > a.vs) continue;                                   /* :285 */
         gsdf_v3 mean = { 0.f, 0.f, 0.f };
-        int mine = 0;
-        for (int i = j; i < a.n; i += 4) {
+        int Nj = 0;
+        for (int i = 0; i < a.n; ++i) {
             if (!ba_visible(a, slot, i)) continue;
             gsdf_v3 p; float m, n;
             if (!ba_project(a, v, i, &p, &m, &n)) continue;
             const ba_img im = { a.W, a.H, a.images + (size_t)i * a.W * a.H * 3 };
             const gsdf_v3 A = ba_interp(n, m, im);
             mean = gsdf_v3{ mean.x + A.x, mean.y + A.y, mean.z + A.z };
-            ++mine;
+            ++Nj;
         }
-        const int Nj = (int)ba_quad_sum((float)mine);                         /* <= 64: exact */
         if (!Nj) continue;
-        mean = gsdf_v3{ ba_quad_sum(mean.x), ba_quad_sum(mean.y), ba_quad_sum(mean.z) };
-        n_act += j == 0 ? 1u : 0u; n_obs += (unsigned int)mine;
+        n_act += 1u; n_obs += (unsigned int)Nj;
         const float inv = (float)(1. / (double)(float)Nj);
         mean = gsdf_v3{ inv * mean.x, inv * mean.y, inv * mean.z };
-        for (int i = j; i < a.n; i += 4) {                                    /* second sweep: same samples */
+        for (int i = 0; i < a.n; ++i) {                                        /* second sweep: same samples */
             if (!ba_visible(a, slot, i)) continue;
             gsdf_v3 p; float m, n;
             if (!ba_project(a, v, i, &p, &m, &n)) continue;
