@@ -307,7 +307,9 @@ __global__ __launch_bounds__(BA_DIST_THREADS) void k_ba_dist(ba_args a, float da
  * voxels = ~2000 waves: one wave per SIMD and a chain of ~35 k dependent instructions each (308 us for C5); sliced, the chip
  * holds four times the waves and each chain is a third as long.  The first loop (the voxel's mean intensity) is repeated by
  * every slice. */
+#ifndef BA_POSE_SLICES
 #define BA_POSE_SLICES 4
+#endif
 __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /* [gridDim.x][n][BA_NV] */) {
     const int slice = (int)blockIdx.y;
     /* one accumulator set per WAVE, [4][n][BA_NV]: lane 63 adds its wave's 27 sums of a keyframe with plain LDS read-modify-

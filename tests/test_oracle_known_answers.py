@@ -504,3 +504,48 @@ def test_box_filter_summation_order_measured(pkg, O):
     k_run, p_run = run.export()
     assert np.array_equal(k_def, k_run) and np.array_equal(p_def.view(np.uint32), p_run.view(np.uint32))
     assert 1e-6 < worst < 5e-2                                  # what fresh sums in the CACHE do to normals (1e-2 at 640x480)
+
+
+def test_host_side_math_header_equals_the_oracle(O, tmp_path):
+    """csrc/gsdf_math.h (compiled for the host here; the same source is the tracker head's exact fallback on the device and the
+    facade's SE3) against the oracle, bit for bit: gsdf_llt_solve6 (Eigen's order), gsdf_se3_exp_mul, quaternion <-> matrix."""
+    import ctypes as C
+    import os
+    import subprocess
+    from conftest import ROOT
+    src = tmp_path / "m.cpp"
+    src.write_text('#include "gsdf_math.h"\nextern "C" {\n'
+                   'void t_llt(const float* H, const float* g, float* x) { gsdf_llt_solve6(H, g, x); }\n'
+                   'void t_exp(const float* xi, float* p) { gsdf_se3_exp_mul(xi, p); }\n'
+                   'void t_q2r(const float* q, float* R) { gsdf_quat_to_R(q, R); }\n'
+                   'void t_r2q(const float* R, float* q) { gsdf_R_to_quat(R, q); }\n}\n')
+    lib = tmp_path / "libm_t.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+                           "-I", os.path.join(ROOT, "gradient-sdf_amd", "csrc"), str(src), "-o", str(lib)])
+    L = C.CDLL(str(lib))
+    fp = C.POINTER(C.c_float)
+    f = np.float32
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        J = rng.normal(size=(40, 6)) * np.array([1, 1, 1, 2, 2, 2])
+        H = np.ascontiguousarray((J.T @ J).astype(f)).reshape(36)
+        g = rng.normal(size=6).astype(f)
+        x = np.empty(6, f)
+        L.t_llt(H.ctypes.data_as(fp), g.ctypes.data_as(fp), x.ctypes.data_as(fp))
+        assert np.array_equal(x.view(np.uint32), O.llt_solve6(H, g).view(np.uint32))
+        xi = (rng.normal(size=6) * np.array([0.01, 0.01, 0.01, 0.02, 0.02, 0.02]) * 10.0 ** rng.integers(-4, 2)).astype(f)
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        p = np.concatenate([rng.normal(size=3), q]).astype(f)
+        p2 = p.copy()
+        L.t_exp(xi.ctypes.data_as(fp), p2.ctypes.data_as(fp))
+        assert np.array_equal(p2.view(np.uint32), O.se3_exp_mul(xi, p).view(np.uint32))
+        R = np.empty(9, f)
+        L.t_q2r(p[3:].copy().ctypes.data_as(fp), R.ctypes.data_as(fp))
+        assert np.array_equal(R.reshape(3, 3).view(np.uint32), O.quat_to_R(p[3:]).view(np.uint32))
+        q2 = np.empty(4, f)
+        L.t_r2q(R.ctypes.data_as(fp), q2.ctypes.data_as(fp))
+        assert np.array_equal(q2.view(np.uint32), O.R_to_quat(R).view(np.uint32))
+    xz = np.empty(6, f)
+    Hz, gz = np.zeros(36, f), np.ones(6, f)
+    L.t_llt(Hz.ctypes.data_as(fp), gz.ctypes.data_as(fp), xz.ctypes.data_as(fp))
+    assert np.isnan(xz).all()
