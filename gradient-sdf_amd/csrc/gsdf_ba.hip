@@ -304,11 +304,11 @@ __global__ __launch_bounds__(BA_DIST_THREADS) void k_ba_dist(ba_args a, float da
 #define BA_NV 27
 /* BA_POSE_SLICES workgroups (blockIdx.y) share a set of voxels: each takes every BA_POSE_SLICES-th keyframe of the second loop
  * (the per-keyframe Jacobians and their 27-value wave reduction: 85 % of a wave's instructions).  The gate list holds ~10^5
- * voxels = ~2000 waves: one wave per SIMD and a chain of ~35 k dependent instructions each (308 us for C5); sliced, the chip
- * holds four times the waves and each chain is a third as long.  The first loop (the voxel's mean intensity) is repeated by
- * every slice. */
+ * voxels = ~2000 waves: one wave per SIMD and a chain of ~35 k dependent instructions each.  The first loop (the voxel's mean
+ * intensity) is repeated by every slice, so more slices soon cost more than they hide: measured on C5 with the per-wave
+ * accumulators below, 1 / 2 / 4 / 8 slices = 237 / 232 / 288 / 384 us (308 us with float atomics and no slices). */
 #ifndef BA_POSE_SLICES
-#define BA_POSE_SLICES 4
+#define BA_POSE_SLICES 2
 #endif
 __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /* [gridDim.x][n][BA_NV] */) {
     const int slice = (int)blockIdx.y;
