@@ -323,6 +323,13 @@ def test_merge_from_two_contexts_on_one_gpu(pkg, O):
     assert np.array_equal(kb0, ob.export()[0]) and b.stats()["frames"] == 4
     with pytest.raises(pkg.GsdfError):
         a.merge_from(a)
+    with pytest.raises(pkg.GsdfError):                             # at most four shard contexts (one hardware queue each)
+        pkg.GradSdf.shards(5, vs, T, W, H, seq.K, capacity_log2=16)
+    c = pkg.GradSdf(np.float32(0.04), np.float32(5) * np.float32(0.04), W, H, seq.K, capacity_log2=16)
+    with pytest.raises(pkg.GsdfError) as e:                        # another voxel size: not the same map
+        a.merge_from(c)
+    assert "voxel size" in str(e.value)
+    c.close()
     a.close(); b.close()
 
 
