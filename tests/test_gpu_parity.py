@@ -1118,3 +1118,26 @@ def test_where_the_gated_fusion_is_queued_is_invisible(pkg, O, monkeypatch):
     assert np.abs(pa - pb).max() <= 1e-5 * max(1.0, float(np.abs(pa).max()))
     conv = la[:, 7] != 0
     assert 0 < conv.sum() < len(conv), "the stretch should hold converged and non-converged frames"
+
+
+def test_tracker_head_takes_the_exact_forms_outside_the_fast_range(pkg, O):
+    """The tracker's head computes llt().solve and SE3::exp in <= 1-ulp forms for the common case (rotation step below 0.1 rad,
+    positive pivots) and in the exact forms otherwise.  A start pose 0.2 rad off makes the first Gauss-Newton step rotate by more
+    than 0.1 rad: the exact SE3::exp path (full-range sinf / cosf); an empty map makes every pivot zero: the exact
+    llt path (Eigen stops at the pivot and solves on what it has: NaN, SURVEY gotcha 9).  One pass each, against the oracle."""
+    seq, g, o = _mk(pkg, O, kind="tum", W=320, H=240, vs=0.02, trunc=5, cap=20, n=3, seed=2)
+    d0, R0, t0 = seq.frame(0)
+    p0 = pose7_from(O, R0, t0)
+    cg, pg, passes = g.track(d0, p0, iters=1)                   # empty map: zero pivots
+    co, po, used, _, _ = o.track(d0, p0, iters=1)
+    assert passes == used == 1 and np.array_equal(pg, po) and not cg and not co
+    R0q = O.quat_to_R(p0[3:])
+    g.update(d0, R0q, t0); o.update(d0, R0q, t0)
+    start = O.se3_exp_mul(np.array([0.01, -0.01, 0.0, 0.0, 0.2, 0.0], np.float32), p0)
+    cg, pg, passes = g.track(d0, start, iters=1)
+    co, po, used, trace, _ = o.track(d0, start, iters=1)
+    xi = trace[0, 29:35]
+    assert float(np.linalg.norm(xi[3:])) > 0.1, xi                # the step really is outside the fast range
+    assert passes == used == 1
+    assert np.abs(pg[:3] - po[:3]).max() < TOL and np.abs(np.abs(pg[3:]) - np.abs(po[3:])).max() < TOL, (pg, po)
+    g.close()
