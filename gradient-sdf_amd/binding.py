@@ -107,6 +107,7 @@ def load(path=None):
         "gsdf_update": (C.c_int, [vp, fp, fp, fp]),
         "gsdf_update_dev": (C.c_int, [vp, vp, fp, fp]),
         "gsdf_track": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "gsdf_track_sampled": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_float, C.c_float, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "gsdf_set_pose": (C.c_int, [vp, fp]),
         "gsdf_get_pose": (C.c_int, [vp, fp]),
         "gsdf_track_and_fuse_dev": (C.c_int, [vp, vp, fp, C.c_int, C.c_float, C.c_float]),
@@ -180,7 +181,7 @@ def load(path=None):
 ABI_SYMBOLS = [
     "gsdf_last_error", "gsdf_version", "gsdf_create", "gsdf_destroy", "gsdf_reset", "gsdf_set_zrange",
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
-    "gsdf_track", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
+    "gsdf_track", "gsdf_track_sampled", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
     "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow", "gsdf_capacity", "gsdf_merge_from", "gsdf_create_shards", "gsdf_merge_prepare",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
@@ -332,12 +333,17 @@ class GradSdf:
         self._chk(self.L.gsdf_update_dev(self.h, depth_dev, _fp(R), _fp(t)))
 
     # -- tracking -----------------------------------------------------------------------------
-    def track(self, depth, pose7, iters=25, conv=1e-3, damping=1.0):
+    def track(self, depth, pose7, iters=25, conv=1e-3, damping=1.0, sampling=None):
+        """RigidPointOptimizer::optimize (sampling None) / ::optimize_sampled(depth, K, sampling)"""
         d = _f32(depth).reshape(self.H, self.W)
         p = _f32(pose7).reshape(7).copy()
         conv_flag, passes = C.c_int(0), C.c_int(0)
-        self._chk(self.L.gsdf_track(self.h, _fp(d), _fp(self.K), _fp(p), int(iters), np.float32(conv),
-                                    np.float32(damping), C.byref(conv_flag), C.byref(passes)))
+        if sampling is None:
+            self._chk(self.L.gsdf_track(self.h, _fp(d), _fp(self.K), _fp(p), int(iters), np.float32(conv),
+                                        np.float32(damping), C.byref(conv_flag), C.byref(passes)))
+        else:
+            self._chk(self.L.gsdf_track_sampled(self.h, _fp(d), _fp(self.K), _fp(p), int(iters), np.float32(conv),
+                                                np.float32(damping), int(sampling), C.byref(conv_flag), C.byref(passes)))
         return bool(conv_flag.value), p, passes.value
 
     def set_pose(self, pose7):

@@ -139,10 +139,16 @@ static int auto_grow_step(gsdf_ctx* c) {
     unsigned int uncovered = k - seen + 1;
     if (c->grow_counts_seen >= 2 && (int)uncovered > c->grow_max_lag + 1) {
         /* far ahead of the device: wait for it to come within grow_max_lag / 2 entries (it is working; nothing is drained) */
+        /* ... but never for a count that was not enqueued: counts are tagged with the entry that queued them (every fourth
+         * entry while the estimate is low), so `seen` cannot pass grow_last_enq (with a small GSDF_GROW_MAX_LAG the
+         * old target k - seen <= lag / 2 was unreachable and the loop spun out its whole timeout on every entry) */
+        const int target = std::max(c->grow_max_lag / 2, (int)(k - c->grow_last_enq));
         const auto t0 = std::chrono::steady_clock::now();
-        while ((int)(k - seen) > c->grow_max_lag / 2) {
+        for (long spin = 0; (int)(k - seen) > target; ++spin) {
             look(cnt, seen);
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+            if (spin < 4096) { __builtin_ia32_pause(); continue; }
+            if ((spin & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+            std::this_thread::yield();
         }
         uncovered = k - seen + 1;
     }
@@ -248,8 +254,19 @@ int follow_progress(gsdf_ctx* c, unsigned int serial, int last) {
     }
 }
 
-int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, float damping, bool fuse_after) {
-    const gsdf_frame_geom g = c->geom();
+int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, float damping, bool fuse_after, int sampling = 1) {
+    gsdf_frame_geom g = c->geom();
+    if (sampling > 1) {
+        /* optimize_sampled(depth, K, sampling) -- RigidPointOptimizer.cpp:62: the pixels (x, y) = (i * s, j * s).  They are
+         * compacted into their own image (so that the pass kernel's coalesced pixel -> lane mapping serves them unchanged) and the
+         * passes run on the grid of sampled pixels; k_track_pass<true> turns a grid index back into the pixel coordinate. */
+        if (fuse_after) return fail(GSDF_ERR_INVALID, "the frame loop tracks every pixel (RigidPointOptimizer.h:69-72)");
+        const int Ws = (c->W + sampling - 1) / sampling, Hs = (c->H + sampling - 1) / sampling;
+        if (!c->depth_sampled) HIP_TRY(hipMalloc((void**)&c->depth_sampled, (size_t)((c->W + 1) / 2) * ((c->H + 1) / 2) * sizeof(float)));
+        gsdf_launch_subsample(c->stream, depth_dev, c->W, c->H, sampling, c->depth_sampled);
+        depth_dev = c->depth_sampled;
+        g.W = Ws; g.H = Hs;
+    }
     gsdf_pose_arg unused;
     std::memset(&unused, 0, sizeof(unused));
     if (iters <= 0) {
@@ -278,7 +295,8 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     tp.progress = adaptive ? c->progress_dev : nullptr;
     tp.debug = c->debug >> 16;
     tp.n_track_blocks = c->track_blocks;
-    if (c->persist && c->track_rows && c->track_blocks <= 2 * GSDF_TRACK_MAXBLK) {
+    tp.sampling = sampling;
+    if (sampling == 1 && c->persist && c->track_rows && c->track_blocks <= 2 * GSDF_TRACK_MAXBLK) {
         /* the whole optimize() as one launch; the frame's fusion, gated on the device by done && converged, right behind it */
         tp.pass_index = 0;
         tp.rot = 0;
@@ -543,7 +561,9 @@ static int create_impl(gsdf_ctx** out, float voxel_size, float trunc_dist, int c
         if ((env = getenv("GSDF_LAZY_FUSE"))) c->lazy_fuse = atoi(env);
         if ((env = getenv("GSDF_PERSIST"))) c->persist = atoi(env);
         if ((env = getenv("GSDF_FAR_TABLE"))) c->far_table = atoi(env);       /* experiments: 0 / 1 pin the fusion kernel's table size */
-        if ((env = getenv("GSDF_GROW_MAX_LAG")) && atoi(env) >= 1) c->grow_max_lag = atoi(env);   /* auto-grow: entries the host may be ahead of the newest count */
+        /* auto-grow: entries the host may be ahead of the newest count.  Counts are queued every fourth entry while the load
+         * is low, so a lag below 8 could never be "safe" between two of them: smaller values are raised to 8 */
+        if ((env = getenv("GSDF_GROW_MAX_LAG")) && atoi(env) >= 1) c->grow_max_lag = std::max(8, atoi(env));
     }
     int rc = gsdf_reset(c);
     if (rc != GSDF_OK) { gsdf_destroy(c); return rc; }
@@ -564,7 +584,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     for (hipEvent_t e : c->mark_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->upload_pool) (void)hipEventDestroy(e);
     for (auto& m : c->marks) (void)hipEventDestroy(m.second);
-    void* ptrs[] = { c->tile_stats, c->grow_scratch, c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
+    void* ptrs[] = { c->depth_sampled, c->tile_stats, c->grow_scratch, c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
                      c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb, c->ba_gate_list, c->ba_gate_tmp, c->counter2 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -636,12 +656,12 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
         return fail(GSDF_ERR_INVALID, "W,H > 0 and odd window <= 15 required");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    void* old[] = { c->tile_stats, c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log, c->deferred,
+    void* old[] = { c->depth_sampled, c->tile_stats, c->planes, c->depth_stage, c->normals, c->partials, c->blk_counters, c->frame_log, c->deferred,
                     c->deferred_count, c->tile_flags, c->tile_order, c->fuse_ticket, c->track_rows, c->track_abort };
     for (void* p : old) if (p) (void)hipFree(p);
     c->track_rows = nullptr; c->track_abort = nullptr;
     c->tile_flags = nullptr; c->tile_order = nullptr; c->tile_stats = nullptr;
-    c->planes = c->depth_stage = c->normals = nullptr; c->partials = nullptr;
+    c->planes = c->depth_stage = c->normals = nullptr; c->partials = nullptr; c->depth_sampled = nullptr;
     c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr; c->fuse_ticket = nullptr;
     c->W = W; c->H = H; c->win = win;
     std::memcpy(c->K, K, 9 * sizeof(float));
@@ -798,16 +818,24 @@ int gsdf_get_pose(gsdf_ctx* c, float pose7[7]) {
 
 int gsdf_track(gsdf_ctx* c, const float* depth_host, const float K[9], float pose7[7], int num_iterations,
                float conv_threshold, float damping, int* converged, int* passes) {
+    return gsdf_track_sampled(c, depth_host, K, pose7, num_iterations, conv_threshold, damping, 1, converged, passes);
+}
+
+int gsdf_track_sampled(gsdf_ctx* c, const float* depth_host, const float K[9], float pose7[7], int num_iterations,
+                       float conv_threshold, float damping, int sampling, int* converged, int* passes) {
     GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     if (!depth_host || !K || !pose7) return fail(GSDF_ERR_INVALID, "null argument");
+    /* size_t sampling of the reference: 0 never ends its loops (y += 0); a stride beyond the image is the single pixel (0, 0) */
+    if (sampling < 1) return fail(GSDF_ERR_INVALID, "sampling must be >= 1");
+    if (sampling > std::max(c->W, c->H)) sampling = std::max(c->W, c->H);
     if (std::memcmp(K, c->K, 9 * sizeof(float)) != 0)
         return fail(GSDF_ERR_INVALID, "K differs from the intrinsics given to gsdf_normals_init");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->depth_stage, depth_host, (size_t)c->W * c->H * sizeof(float), hipMemcpyHostToDevice, c->stream));
     gsdf_launch_set_pose(c->stream, c->st, nullptr, pose7);
-    rc = enqueue_track(c, c->depth_stage, num_iterations, conv_threshold, damping, false);
+    rc = enqueue_track(c, c->depth_stage, num_iterations, conv_threshold, damping, false, sampling);
     if (rc) return rc;
     gsdf_dev_state s;
     rc = read_state(c, &s);

@@ -82,6 +82,7 @@ struct gsdf_ctx {
     unsigned long long* rc_counts = nullptr;       /* raycaster: per-workgroup rows of (samples, records, fast / slow iterations of wave 0) */
     size_t rc_rows = 0;
     long long rc_iters[2] = { 0, 0 };              /* loop iterations of the workgroups' wave 0 as of the last gsdf_raycast_counters */
+    float* depth_sampled = nullptr;                /* the compacted pixels of gsdf_track_sampled (sampling > 1), lazily allocated */
     void* scratch = nullptr;                       /* device scratch of gsdf_query / gsdf_get_voxels for small batches (GSDF_SCRATCH_BYTES) */
     bool occ_dirty = false;                        /* blocks may have been inserted since the raycaster's filters (gsdf_table::occ) were built */
     /* the reference's map grows without bound (MapGradPixelSdf.h:65-68); here: gsdf_grow, or by itself when gsdf_set_auto_grow

@@ -120,6 +120,8 @@ struct gsdf_track_params {
     int debug;                    /* experiment switches (gsdf_debug_flags >> 8); 0 in production */
     unsigned int rot;             /* tracker launches issued on this context so far, mod 3: selects the sum buffers */
     int n_track_blocks;           /* workgroups of the pass itself (set by the launcher); further ones compute normals tiles */
+    int sampling;                 /* optimize_sampled's stride (RigidPointOptimizer.h:65); > 1: the geometry is the sampled grid, the
+                                     depth image its compaction (gsdf_launch_subsample), no normals riders */
 };
 /* NormalEstimator::compute of the frame being tracked, run by extra workgroups of its first pass (Scan3D loop) */
 struct gsdf_normals_job {
@@ -130,6 +132,7 @@ struct gsdf_normals_job {
     int r, ntx;                   /* window radius; tiles per image row (set by the launcher) */
     int tile_first, tile_count;   /* the tiles this launch computes: [tile_first, tile_first + tile_count); count 0 = all the rest */
 };
+void gsdf_launch_subsample(hipStream_t s, const float* depth, int W, int H, int sampling, float* out /* ceil(W/s) * ceil(H/s) */);
 int  gsdf_normals_tiles(int W, int H);       /* normals tiles of a frame (workgroups of k_normals / of the normals role) */
 void gsdf_launch_track_none(hipStream_t s, gsdf_dev_state* st);
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,

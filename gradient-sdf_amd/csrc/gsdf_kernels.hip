@@ -1657,7 +1657,8 @@ __device__ __forceinline__ void trk_solve_update(const float* tot, float damping
 template <int PPT>
 __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_table& tab, const float* __restrict__ depth,
                                            const float* z_first, const float pose[7], int pix0, int pix_stride, int batch_stride,
-                                           float (&acc)[GSDF_TRACK_NSUM], unsigned long long* wave_stamp = nullptr) {
+                                           float (&acc)[GSDF_TRACK_NSUM], unsigned long long* wave_stamp = nullptr,
+                                           const int xy_scale = 1) {
     /* wave_stamp (test build, tools/track_waves.py): one word per wave = gather ticks | ticks until the block lookups are done |
      * pixels that passed the z gate | pixels with a voxel, 16 bits each (first batch of pixels) */
     const unsigned long long ws_t0 = wave_stamp ? wall_clock64() : 0ull;
@@ -1689,7 +1690,10 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             ok[j] = ok[j] && !(z[j] <= g.zmin || z[j] >= g.zmax);         /* :64-65 */
-            const int y = (int)py, x = (int)px;
+            /* optimize_sampled's `y += sampling`, `x += sampling` (RigidPointOptimizer.cpp:62): g.W x g.H is then the grid of
+             * sampled pixels, `depth` their compacted image, and the pixel coordinate the grid index times the stride
+             * (xy_scale is the literal 1 in the unsampled instantiation: folded away) */
+            const int y = (int)py * xy_scale, x = (int)px * xy_scale;
             px += step_x; py += step_y;
             if (px >= uW) { px -= uW; ++py; }
             const float x0 = ((float)x - g.cx) * fx_inv;                  /* :67-68 */
@@ -1741,7 +1745,7 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
             const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ pb[j].x, pb[j].y, pc2[j].x });
             const gsdf_v3 gr = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };
             const gsdf_v3 d = { g.vs * (float)vx[j] - p[j].x, g.vs * (float)vy[j] - p[j].y, g.vs * (float)vz[j] - p[j].z };
-            const float phi = pa[j].y / w0 + gsdf_dot3(gr, d);
+            const float phi = gsdf_tsdf_phi(pa[j].y / w0, gn, d);         /* :114 (double literal, see gsdf_math.h) */
             const gsdf_v3 pxg = gsdf_cross3(p[j], gr);                    /* :78 */
             const float J[6] = { gr.x, gr.y, gr.z, pxg.x, pxg.y, pxg.z };
             acc[0] += phi * phi;                                          /* :76 */
@@ -1766,6 +1770,10 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
 }
 
 static_assert(GSDF_TRACK_BLOCK == NRM_THREADS, "the normals tiles of the first pass run in tracker-sized workgroups");
+/* SAMPLED: optimize_sampled(depth, K, sampling > 1) -- the public stride argument of RigidPointOptimizer.h:65.  g.W x g.H is
+ * the grid of sampled pixels (ceil(W / s) x ceil(H / s)), `depth` its compacted image (k_subsample), tp.sampling the stride.
+ * A second instantiation so that the sampling-1 kernel of the frame loop stays instruction for instruction what it was. */
+template <bool SAMPLED>
 __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_geom g, const float* __restrict__ depth,
                                                                  gsdf_table tab, gsdf_dev_state* st,
                                                                  double* rows, gsdf_track_params tp, gsdf_normals_job nj) {
@@ -1909,8 +1917,9 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
     float acc[GSDF_TRACK_NSUM];
 #pragma unroll
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
-    if (trk_heavy) trk_gather<TRK_PPT>(g, tab, depth, z_pre, pose, trk_pix0, 64, trk_batch, acc, trk_tr ? trk_tr + 8 + wave : nullptr);
-    else trk_gather<TRK_PPT - 1>(g, tab, depth, z_pre, pose, trk_pix0, 64, trk_batch, acc, trk_tr ? trk_tr + 8 + wave : nullptr);
+    const int xy_scale = SAMPLED ? tp.sampling : 1;
+    if (trk_heavy) trk_gather<TRK_PPT>(g, tab, depth, z_pre, pose, trk_pix0, 64, trk_batch, acc, trk_tr ? trk_tr + 8 + wave : nullptr, xy_scale);
+    else trk_gather<TRK_PPT - 1>(g, tab, depth, z_pre, pose, trk_pix0, 64, trk_batch, acc, trk_tr ? trk_tr + 8 + wave : nullptr, xy_scale);
     if (trk_tr && threadIdx.x == 0) trk_tr[2] = wall_clock64();                         /* wave 0: gather done */
     /* every wave reduces its sums as soon as its own gather is done (wsum is used here only): ONE barrier per pass tail */
     wave_sum_to_lane63(acc);
@@ -1960,7 +1969,22 @@ void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float
         extra = std::max(0, nj.tile_count > 0 ? std::min(nj.tile_count, rest) : rest);
         dyn = extra ? sizeof(nrm_lds) : 0;
     }
-    hipLaunchKernelGGL(k_track_pass, dim3(n_blocks + extra), dim3(GSDF_TRACK_BLOCK), dyn, s, g, depth, tab, st, partials, tp, nj);
+    if (tp.sampling > 1)
+        hipLaunchKernelGGL(k_track_pass<true>, dim3(n_blocks + extra), dim3(GSDF_TRACK_BLOCK), dyn, s, g, depth, tab, st, partials, tp, nj);
+    else
+        hipLaunchKernelGGL(k_track_pass<false>, dim3(n_blocks + extra), dim3(GSDF_TRACK_BLOCK), dyn, s, g, depth, tab, st, partials, tp, nj);
+}
+
+/* the sampled pixels of optimize_sampled (RigidPointOptimizer.cpp:62: y = 0, s, 2s, ... < H; x likewise), compacted row-major */
+__global__ __launch_bounds__(256) void k_subsample(const float* __restrict__ depth, int W, int s, int Ws, int Ns, float* __restrict__ out) {
+    const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (q >= Ns) return;
+    const int qy = q / Ws, qx = q - qy * Ws;
+    out[q] = depth[(size_t)(qy * s) * W + (size_t)qx * s];
+}
+void gsdf_launch_subsample(hipStream_t st, const float* depth, int W, int H, int s, float* out) {
+    const int Ws = (W + s - 1) / s, Hs = (H + s - 1) / s, Ns = Ws * Hs;
+    hipLaunchKernelGGL(k_subsample, dim3((Ns + 255) / 256), dim3(256), 0, st, depth, W, s, Ws, Ns, out);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -2290,7 +2314,7 @@ __global__ __launch_bounds__(256) void k_query(gsdf_table tab, float vs, float i
                 const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ sl->gx, sl->gy, sl->gz });
                 og = gsdf_v3{ 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };
                 const gsdf_v3 d = { vs * (float)vx - p.x, vs * (float)vy - p.y, vs * (float)vz - p.z };
-                od = sl->s / sl->w + gsdf_dot3(og, d);
+                od = gsdf_tsdf_phi(sl->s / sl->w, gn, d);                                  /* :114 */
             }
         }
         w[i] = ow; dist[i] = od;
@@ -2382,9 +2406,8 @@ __device__ __forceinline__ void rc_step(rc_ray_state& st, const gsdf_v3& p, int 
     }
     if (w0 > 0.f) {
         const gsdf_v3 gn = gsdf_normalized3(gsdf_v3{ gx, gy, gz });
-        const gsdf_v3 g = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };
         const gsdf_v3 c = { vs * (float)vx - p.x, vs * (float)vy - p.y, vs * (float)vz - p.z };
-        const float phi = sd / w0 + gsdf_dot3(g, c);
+        const float phi = gsdf_tsdf_phi(sd / w0, gn, c);                                   /* MapGradPixelSdf.h:114 */
         if (st.prev_ok && st.phi_prev < 0.f && phi >= 0.f) {   /* the stored SDF is negative in front of the surface */
             st.out_z = st.s_prev + (s - st.s_prev) * (st.phi_prev / (st.phi_prev - phi));
             st.out_n = gsdf_v3{ gsdf_sum3(R[0] * gn.x, R[3] * gn.y, R[6] * gn.z), gsdf_sum3(R[1] * gn.x, R[4] * gn.y, R[7] * gn.z),

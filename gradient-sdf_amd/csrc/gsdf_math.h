@@ -54,6 +54,17 @@ GSDF_HD gsdf_v3 gsdf_normalized3(gsdf_v3 n) {
     return n;
 }
 
+/* The return expression of MapGradPixelSdf::tsdf -- MapGradPixelSdf.h:114:
+ *     return v.dist + 1.2*v.grad.normalized().dot(vox2float(idx) - point);
+ * The member calls bind before `*`: the dot product is taken in float with the UNIT gradient, the result meets the
+ * double literal 1.2 (a float * double product, no Eigen expression involved, so nothing demotes the literal -- unlike
+ * `1.2*v.grad.normalized()` of :113, where Eigen's scalar-times-matrix operator converts it to float), v.dist is added in
+ * double and the function's float return type rounds once.  unit = grad.normalized(), d = vox2float(idx) - point.
+ * Two double operations, each rounded (no fma: -ffp-contract=off). */
+GSDF_HD float gsdf_tsdf_phi(float dist, gsdf_v3 unit, gsdf_v3 d) {
+    return (float)((double)dist + 1.2 * (double)gsdf_dot3(unit, d));
+}
+
 /* Sdf::weight -- sdf_tracker/Sdf.h:76-85 */
 GSDF_HD float gsdf_weight(float sdf, float T, float inv_T) {
     const float ramp = 1.f - sdf * inv_T;

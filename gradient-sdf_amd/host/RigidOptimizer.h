@@ -34,8 +34,10 @@ public:
     RigidPointOptimizer(Sdf* tSDF) : RigidOptimizer(tSDF) {}
     RigidPointOptimizer(int num_iterations, float conv_threshold, float damping, Sdf* tSDF)
         : RigidOptimizer(num_iterations, conv_threshold, damping, tSDF) {}
-    /* optimize() -> optimize_sampled(depth, K, 1) -- RigidPointOptimizer.h:69-72, .cpp:40-99 */
-    bool optimize(const DepthImage& depth, const Mat3f K) override;
+    /* optimize_sampled(depth, K, sampling) -- RigidPointOptimizer.h:65, .cpp:40-99 (sampling = pixel stride, .cpp:62) */
+    bool optimize_sampled(const DepthImage& depth, const Mat3f K, size_t sampling);
+    /* optimize() -> optimize_sampled(depth, K, 1) -- RigidPointOptimizer.h:69-72 */
+    bool optimize(const DepthImage& depth, const Mat3f K) override { return optimize_sampled(depth, K, 1); }
     int last_passes() const { return last_passes_; }
 };
 

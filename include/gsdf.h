@@ -123,6 +123,15 @@ int gsdf_track(gsdf_ctx* c, const float* depth_host, const float K[9], float pos
                int num_iterations, float conv_threshold, float damping,
                int* converged, int* passes);
 
+/* RigidPointOptimizer::optimize_sampled(depth, K, sampling) -- RigidPointOptimizer.h:65, the public member optimize() forwards to
+ * with sampling 1 (.h:69-72).  sampling >= 1 is the pixel stride of RigidPointOptimizer.cpp:62 (`y += sampling`, `x += sampling`:
+ * the pixels (i * sampling, j * sampling)); a stride beyond the image leaves pixel (0, 0), as there; sampling < 1 (the
+ * reference's size_t 0 never leaves its loop) is GSDF_ERR_INVALID.  gsdf_track == gsdf_track_sampled(..., 1, ...).  The frame
+ * loop entry below has no such argument because the reference's loop calls optimize() (main_scan_3d.cpp:258). */
+int gsdf_track_sampled(gsdf_ctx* c, const float* depth_host, const float K[9], float pose7[7],
+                       int num_iterations, float conv_threshold, float damping, int sampling,
+                       int* converged, int* passes);
+
 /* The Scan3D loop body without host round trips -- main_scan_3d.cpp:255-266:
  *   conv = pOpt->optimize(depth, K);  if (conv) tSDF->update(color, depth, K, pOpt->pose(), NEst);
  * The pose persists on the device between frames (RigidOptimizer::pose_, RigidOptimizer.h:64);

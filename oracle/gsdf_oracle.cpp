@@ -598,11 +598,15 @@ static inline float oracle_weights(const gsdfo* o, V3 p, const SdfVoxel** vout, 
 /* MapGradPixelSdf::tsdf -- MapGradPixelSdf.h:109-115 */
 static inline float oracle_tsdf(const gsdfo* o, const SdfVoxel& v, Key idx, V3 p, V3* grad) {
     const V3 gn = normalized3(V3{ v.grad[0], v.grad[1], v.grad[2] });
-    const V3 g = { 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };       /* 1.2 is promoted to float by Eigen */
-    if (grad) *grad = g;
+    /* :113 `1.2*v.grad.normalized()`: scalar * Eigen expression -- Eigen's operator converts the double literal to the
+     * expression's scalar type (float) before the product */
+    if (grad) *grad = V3{ 1.2f * gn.x, 1.2f * gn.y, 1.2f * gn.z };
     const V3 c = o->vox2float(idx);
     const V3 d = { c.x - p.x, c.y - p.y, c.z - p.z };
-    return v.dist + dot3(g, d);
+    /* :114 `v.dist + 1.2*v.grad.normalized().dot(c - point)`: the member calls bind before `*`, so .dot() is taken in
+     * float with the UNIT gradient and returns a float; 1.2 * float and v.dist + (...) are plain C++ double arithmetic,
+     * and the float return type rounds once.  (Built with -ffp-contract=off: two double roundings, no fma.) */
+    return (float)((double)v.dist + 1.2 * (double)dot3(gn, d));
 }
 
 void gsdfo_query(const gsdfo* o, const float* pts, int64_t n, float* dist, float* grad, float* w) {
@@ -851,10 +855,12 @@ static void llt_solve6(const float Hin[36], const float g[6], float x[6]) {
 
 void gsdfo_llt_solve6(const float H36[36], const float g[6], float x[6]) { llt_solve6(H36, g, x); }
 
-/* RigidPointOptimizer::optimize_sampled(depth, K, sampling=1) -- RigidPointOptimizer.cpp:40-99 */
+/* RigidPointOptimizer::optimize_sampled(depth, K, sampling) -- RigidPointOptimizer.cpp:40-99; sampling = the public stride
+ * argument of RigidPointOptimizer.h:65 (`y += sampling`, `x += sampling`, .cpp:62; optimize() passes 1, .h:71) */
 int gsdfo_track(gsdfo* o, const float* depth, const float K[9], float pose7[7],
-                int num_iterations, float conv_threshold, float damping,
+                int num_iterations, float conv_threshold, float damping, int sampling,
                 int omp, int* iters_used, float* trace, int64_t* hits) {
+    if (sampling < 1) return -1;                                      /* size_t 0: the reference's loops would never end */
     const float z_min = o->z_min_, z_max = o->z_max_;
     const int w = o->W, h = o->H;
     const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
@@ -903,8 +909,8 @@ int gsdfo_track(gsdfo* o, const float* depth, const float K[9], float pose7[7],
                 float E_ = 0.f, g_[6] = { 0 }, H_[36] = { 0 };
                 size_t c_ = 0;
 #pragma omp for schedule(static)
-                for (int y = 0; y < h; ++y)
-                    for (int x = 0; x < w; ++x) pixel(x, y, E_, g_, H_, c_);
+                for (int y = 0; y < h; y += sampling)                 /* Omp.cpp:70: the parallel for is over the strided y */
+                    for (int x = 0; x < w; x += sampling) pixel(x, y, E_, g_, H_, c_);
                 Es[tid] = E_; cs[tid] = c_;
                 std::memcpy(&gs[6 * tid], g_, sizeof(g_));
                 std::memcpy(&Hs[36 * tid], H_, sizeof(H_));
@@ -915,10 +921,10 @@ int gsdfo_track(gsdfo* o, const float* depth, const float K[9], float pose7[7],
                 for (int i = 0; i < 36; ++i) Hm[i] += Hs[36 * tdx + i];
             }
 #else
-            for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) pixel(x, y, E, g, Hm, counter);
+            for (int y = 0; y < h; y += sampling) for (int x = 0; x < w; x += sampling) pixel(x, y, E, g, Hm, counter);
 #endif
         } else {
-            for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) pixel(x, y, E, g, Hm, counter);   /* :62 */
+            for (int y = 0; y < h; y += sampling) for (int x = 0; x < w; x += sampling) pixel(x, y, E, g, Hm, counter);   /* :62 */
         }
 
         float xi[6];

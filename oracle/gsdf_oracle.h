@@ -88,12 +88,12 @@ void   gsdfo_query(const gsdfo* o, const float* pts, int64_t n, float* dist, flo
 void   gsdfo_raycast(const gsdfo* o, const float K[9], const float R[9], const float t[3], int W, int H,
                      float zmin, float zmax, float* depth, float* normals);
 
-/* RigidPointOptimizer::optimize_sampled(depth, K, 1) -- RigidPointOptimizer.cpp:40-99.
+/* RigidPointOptimizer::optimize_sampled(depth, K, sampling) -- RigidPointOptimizer.cpp:40-99 (sampling >= 1: pixel stride, :62).
  * pose7 in/out.  trace (optional, may be NULL): per executed iteration 36 floats =
  * E, g[6], H upper-tri[21] row-major, count, xi[6], |xi|^2.  hits (optional) = N_hit per iteration.
  * Returns 1 if converged (RigidPointOptimizer.cpp:88-91), else 0. omp=1: threaded reduction. */
 int    gsdfo_track(gsdfo* o, const float* depth, const float K[9], float pose7[7],
-                   int num_iterations, float conv_threshold, float damping,
+                   int num_iterations, float conv_threshold, float damping, int sampling,
                    int omp, int* iters_used, float* trace, int64_t* hits);
 
 /* SE3 helpers restating Eigen / Sophus (used by tests and the facade parity tests) */

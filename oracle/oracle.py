@@ -61,7 +61,7 @@ def lib():
         L.gsdfo_extract_mesh.argtypes = [C.c_void_p, C.c_float, fp, C.c_int64]
         L.gsdfo_raycast.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]
         L.gsdfo_track.restype = C.c_int
-        L.gsdfo_track.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_float, C.c_float, C.c_int,
+        L.gsdfo_track.argtypes = [C.c_void_p, fp, fp, fp, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
                                   C.POINTER(C.c_int), fp, C.POINTER(C.c_int64)]
         L.gsdfo_quat_to_R.argtypes = [fp, fp]
         L.gsdfo_R_to_quat.argtypes = [fp, fp]
@@ -193,15 +193,15 @@ class Oracle:
             self.L.gsdfo_extract_mesh(self.h, np.float32(iso), _fp(tris), n)
         return tris
 
-    def track(self, depth, pose7, iters=25, conv=1e-3, damping=1.0, omp=False):
-        """Returns (converged, pose7, iters_used, trace[iters_used,36], hits[iters_used])."""
+    def track(self, depth, pose7, iters=25, conv=1e-3, damping=1.0, omp=False, sampling=1):
+        """optimize_sampled(depth, K, sampling).  Returns (converged, pose7, iters_used, trace[iters_used,36], hits[iters_used])."""
         d = _f32(depth).reshape(self.H, self.W)
         p = _f32(pose7).reshape(7).copy()
         used = C.c_int(0)
         trace = np.zeros((iters, 36), np.float32)
         hits = np.zeros(iters, np.int64)
         conv_flag = self.L.gsdfo_track(self.h, _fp(d), _fp(self.K), _fp(p), int(iters), np.float32(conv),
-                                       np.float32(damping), int(bool(omp)), C.byref(used), _fp(trace),
+                                       np.float32(damping), int(sampling), int(bool(omp)), C.byref(used), _fp(trace),
                                        hits.ctypes.data_as(C.POINTER(C.c_int64)))
         u = used.value
         return bool(conv_flag), p, u, trace[:u], hits[:u]

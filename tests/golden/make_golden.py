@@ -30,6 +30,7 @@ LARGE = {
     "tum_640x480": ("tum", 640, 480, 0.01, 10, 3, 0, 0.5),
 }
 SAMPLE = 4096
+SAMPLINGS = (2, 3, 4)
 
 CASES = {
     # name: (kind, W, H, voxel size, trunc voxels, frames, seed, step_deg)
@@ -91,8 +92,13 @@ def main():
         conv, pose, used, trace, hits = o.track(depth[n - 1], p0)
         _, pose1, _, _, _ = o.track(depth[n - 1], p0, iters=1)
         _, pose3, _, _, _ = o.track(depth[n - 1], p0, iters=3)
+        # optimize_sampled(depth, K, sampling) -- RigidPointOptimizer.h:65: strides 2, 3, 4 (rows: pose7, converged, passes)
+        sampled = []
+        for s_ in SAMPLINGS:
+            c_, p_, u_, _, h_ = o.track(depth[n - 1], p0, sampling=s_)
+            sampled.append(np.concatenate([p_, [float(c_), float(u_), float(h_[0])]]))
         np.savez_compressed(
-            os.path.join(HERE, name + ".npz"), large=True, kind=kind, W=W, H=H, voxel_size=vs, trunc_dist=T, unit=np.float32(seq.unit),
+            os.path.join(HERE, name + ".npz"), large=True, track_samplings=np.array(SAMPLINGS), track_sampled=np.array(sampled, np.float32), kind=kind, W=W, H=H, voxel_size=vs, trunc_dist=T, unit=np.float32(seq.unit),
             K=seq.K, depth_u16=d16, R=Rs, t=ts, probes=probes, normals_at_probes=nrm, counts=np.array(counts, np.int64),
             n_voxels=len(keys), keys_sha256=digest(keys), payload_sha256=digest(pay), payload_colsum=pay.astype(np.float64).sum(axis=0),
             voxel_sample_index=vsel, voxel_sample_keys=keys[vsel], voxel_sample_payload=pay[vsel],

@@ -75,6 +75,9 @@ def test_oracle_reproduces_full_size_golden(O, path):
     conv, pose, used, trace, hits = o.track(depth[n - 1], z["track_start"])
     assert conv == bool(z["track_converged"]) and used == int(z["track_passes"]) and np.array_equal(pose, z["track_pose"])
     assert np.array_equal(trace, z["track_trace"], equal_nan=True)
+    for s_, row in zip(z["track_samplings"], z["track_sampled"]):          # optimize_sampled's stride argument
+        c_, p_, u_, _, h_ = o.track(depth[n - 1], z["track_start"], sampling=int(s_))
+        assert np.array_equal(p_, row[:7]) and c_ == bool(row[7]) and u_ == int(row[8]) and int(h_[0]) == int(row[9])
 
 
 @pytest.mark.gpu
@@ -117,6 +120,13 @@ def test_hip_path_matches_full_size_golden(pkg, path):
     conv, pose, passes = g.track(depth[n - 1], z["track_start"])
     assert conv == bool(z["track_converged"]) and passes == int(z["track_passes"])
     assert np.abs(pose - z["track_pose"]).max() <= TOL
+    # optimize_sampled(depth, K, sampling) -- RigidPointOptimizer.h:65 / gsdf_track_sampled: pass counts equal, pose <= 1e-4
+    for s_, row in zip(z["track_samplings"], z["track_sampled"]):
+        conv, pose, passes = g.track(depth[n - 1], z["track_start"], sampling=int(s_))
+        assert conv == bool(row[7]) and passes == int(row[8]), (int(s_), conv, passes, row[7:9])
+        assert np.abs(pose - row[:7]).max() <= TOL, (int(s_), np.abs(pose - row[:7]).max())
+    conv, pose, passes = g.track(depth[n - 1], z["track_start"], sampling=1)        # the same entry at stride 1 == gsdf_track
+    assert conv == bool(z["track_converged"]) and passes == int(z["track_passes"]) and np.abs(pose - z["track_pose"]).max() <= TOL
     g.close()
 
 

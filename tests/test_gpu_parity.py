@@ -192,6 +192,34 @@ def test_tracker_matches_oracle(pkg, O):
     g.close()
 
 
+@pytest.mark.parametrize("sampling", [2, 3, 4, 7, 100000])
+def test_tracker_sampled_matches_oracle(pkg, O, sampling):
+    """gsdf_track_sampled == RigidPointOptimizer::optimize_sampled(depth, K, sampling) (RigidPointOptimizer.h:65, .cpp:62):
+    640x480 (not a multiple of 7: ragged last column / row of samples), pass counts equal, pose <= 1e-4, first-pass hit count exact"""
+    seq, g, o = _mk(pkg, O, kind="tum", W=640, H=480, vs=0.01, trunc=10, cap=21, n=3, seed=0)
+    d0, R0, t0 = seq.frame(0)
+    g.update(d0, R0, t0)
+    o.update(d0, R0, t0)
+    d1, R1, t1 = seq.frame(1)
+    p0 = pose7_from(O, R0, t0)
+    n0 = g.stats()["n_hit"]
+    cg, pg, passes = g.track(d1, p0, sampling=sampling, iters=1)
+    co, po, used, trace, hits = o.track(d1, p0, sampling=sampling, iters=1)
+    assert g.stats()["n_hit"] - n0 == int(hits[0])            # the same pixels: same voxels hit from the same pose
+    assert np.abs(pg - po).max() <= TOL
+    cg, pg, passes = g.track(d1, p0, sampling=sampling)
+    co, po, used, trace, hits = o.track(d1, p0, sampling=sampling)
+    assert cg == co and passes == used, (cg, co, passes, used)
+    assert np.abs(pg - po).max() <= TOL
+    # and the unsampled entry afterwards is untouched by the sampled one's geometry
+    cg, pg, passes = g.track(d1, p0)
+    co, po, used, _, _ = o.track(d1, p0)
+    assert cg == co and passes == used and np.abs(pg - po).max() <= TOL
+    with pytest.raises(RuntimeError):
+        g.track(d1, p0, sampling=0)
+    g.close()
+
+
 def test_tracker_no_overlap_returns_false(pkg, O):
     seq, g, o = _mk(pkg, O)
     d0, R0, t0 = seq.frame(0)

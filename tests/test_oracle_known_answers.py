@@ -549,3 +549,79 @@ def test_host_side_math_header_equals_the_oracle(O, tmp_path):
     Hz, gz = np.zeros(36, f), np.ones(6, f)
     L.t_llt(Hz.ctypes.data_as(fp), gz.ctypes.data_as(fp), xz.ctypes.data_as(fp))
     assert np.isnan(xz).all()
+
+
+def test_tsdf_return_expression_is_the_references_mixed_precision_one(O, pkg):
+    """MapGradPixelSdf.h:113-114 on 10^6 random voxels, vectorised float64 numpy transcription against the oracle, bit for bit:
+
+        (*grad_ptr) = 1.2*v.grad.normalized();                                  // Eigen scalar * expression: 1.2 -> 1.2f
+        return v.dist + 1.2*v.grad.normalized().dot(vox2float(idx) - point);    // float dot, then PLAIN C++ double * and +
+
+    The float-only reading `dist + dot(1.2f * unit, d)` (rounds 1-5 of this repository) differs in the last bit of phi on
+    about a tenth of the voxels -- the test measures that too, so the distinction it guards stays visible."""
+    rng = np.random.default_rng(2024)
+    n = 1_000_000
+    # distinct voxel keys on a 128^3 lattice
+    lin = rng.choice(128 ** 3, size=n, replace=False)
+    keys = np.stack([lin % 128 - 64, (lin // 128) % 128 - 64, lin // (128 * 128) - 64], axis=1).astype(np.int32)
+    pay = np.empty((n, 5), np.float32)
+    pay[:, 0] = rng.uniform(-0.1, 0.1, n)                        # dist
+    pay[:, 1:4] = rng.normal(0, 3, (n, 3))                       # grad (un-normalised sum of weighted normals)
+    pay[:, 4] = rng.uniform(0.5, 40, n)                          # weight
+    pay[:7, 1:4] = 0                                             # normalized() of a zero vector: unchanged (Eigen: only if |g|^2 > 0)
+    W, H = 32, 24
+    o = O.Oracle(VS, T10, W, H, pkg.synth.intrinsics(W, H))
+    o.set_map(keys, pay)
+    f32 = np.float32
+    centre = (VS * keys.astype(np.float32)).astype(np.float32)   # vox2float: vs * float(idx)
+    pts = (centre + rng.uniform(-0.0049, 0.0049, (n, 3)).astype(np.float32)).astype(np.float32)
+    # only points whose voxel is the intended one (float2vox(point) == idx)
+    back = np.where(f32(100.0) * pts >= 0, np.floor(f32(100.0) * pts + f32(0.5)), -np.floor(-(f32(100.0) * pts) + f32(0.5))).astype(np.int32)
+    own = (back == keys).all(axis=1)
+    assert own.mean() > 0.95
+    dist, grad, w = o.query(pts)
+    assert np.array_equal(w[own], pay[own, 4])
+
+    g = pay[:, 1:4]
+    sq = (g[:, 0] * g[:, 0] + (g[:, 1] * g[:, 1] + g[:, 2] * g[:, 2])).astype(np.float32)      # squaredNorm: x0 + (x1 + x2)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        unit = np.where(sq[:, None] > 0, g / np.sqrt(sq)[:, None], g).astype(np.float32)
+    d = (centre - pts).astype(np.float32)
+    dot = (unit[:, 0] * d[:, 0] + (unit[:, 1] * d[:, 1] + unit[:, 2] * d[:, 2])).astype(np.float32)
+    phi = (pay[:, 0].astype(np.float64) + np.float64(1.2) * dot.astype(np.float64)).astype(np.float32)   # :114
+    gout = (f32(1.2) * unit).astype(np.float32)                                                          # :113
+    assert np.array_equal(dist[own].view(np.uint32), phi[own].view(np.uint32))
+    assert np.array_equal(grad[own].view(np.uint32), gout[own].view(np.uint32))
+
+    # the float-only reading is a different function: same value to 1e-8, another last bit on ~10 % of the voxels
+    phi_f = (pay[:, 0] + (gout[:, 0] * d[:, 0] + (gout[:, 1] * d[:, 1] + gout[:, 2] * d[:, 2]))).astype(np.float32)
+    frac = float((phi_f[own].view(np.uint32) != phi[own].view(np.uint32)).mean())
+    assert 0.02 < frac < 0.3, frac
+    assert np.abs(phi_f[own] - phi[own]).max() < 1e-7
+
+
+@pytest.mark.parametrize("sampling", [2, 3, 5, 1000])
+def test_optimize_sampled_visits_the_strided_pixels_only(O, pkg, sampling):
+    """RigidPointOptimizer::optimize_sampled(depth, K, sampling) -- RigidPointOptimizer.cpp:62 `for (y = 0; y < h; y += sampling)
+    for (x = 0; x < w; x += sampling)`: the same pixels, in the same order, as the full loop over an image whose other pixels are
+    invalid (z = 0 fails the z_min gate of :64-65) -- so the two runs must agree bit for bit, pass for pass."""
+    W, H = 96, 72
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=2, seed=4)
+    vs = np.float32(0.04)
+    o = O.Oracle(vs, np.float32(5) * vs, W, H, seq.K)
+    d0, R0, t0 = seq.frame(0)
+    o.update(d0, R0, t0)
+    d1, _, _ = seq.frame(1)
+    p0 = pose7_from(O, R0, t0)
+    masked = np.zeros_like(d1)
+    masked[::sampling, ::sampling] = d1[::sampling, ::sampling]
+    ca, pa, ua, tra, ha = o.track(d1, p0, iters=6, sampling=sampling)
+    cb, pb, ub, trb, hb = o.track(masked, p0, iters=6, sampling=1)
+    assert ca == cb and ua == ub and np.array_equal(pa, pb) and np.array_equal(tra, trb, equal_nan=True) and np.array_equal(ha, hb)
+    n_sampled = len(range(0, H, sampling)) * len(range(0, W, sampling))
+    assert 0 < ha[0] <= n_sampled
+    if sampling == 1000:
+        assert n_sampled == 1                       # a stride beyond the image leaves pixel (0, 0)
+    # the OMP-structured variant strides the same loop (RigidPointOptimizerOmp.cpp:70)
+    cc, pc, uc, _, hc = o.track(d1, p0, iters=6, sampling=sampling, omp=True)
+    assert np.array_equal(hc[:1], ha[:1]) and np.abs(pc - pa).max() < 1e-4

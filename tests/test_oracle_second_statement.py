@@ -167,6 +167,13 @@ def normalized(v):
     return list(v)
 
 
+def tsdf_return(dist, unit, c):
+    """MapGradPixelSdf.h:114 `return v.dist + 1.2*v.grad.normalized().dot(vox2float(idx) - point);` -- the float dot
+    product with the UNIT gradient, times the double literal, plus dist in double, rounded once by the float return"""
+    dot = sum3(unit[0] * c[0], unit[1] * c[1], unit[2] * c[2])                             # float, x0 + (x1 + x2)
+    return f32(np.float64(dist) + np.float64(1.2) * np.float64(dot))
+
+
 def first_pass(st, depth, K, R, t):
     """RigidPointOptimizer::optimize_sampled, the sums of its first iteration -- RigidPointOptimizer.cpp:51-84 -- with
     MapGradPixelSdf::weights / tsdf (MapGradPixelSdf.h:109-125) on the second statement's own voxel dict"""
@@ -187,9 +194,9 @@ def first_pass(st, depth, K, R, t):
             if v is None or not (v[2] > 0):                                                # weights(): :117-125
                 continue
             gn = normalized(v[1])
-            gc = [f32(f32(1.2) * gn[i]) for i in range(3)]                                 # 1.2 * normalized(): Eigen promotes the literal to float
+            gc = [f32(f32(1.2) * gn[i]) for i in range(3)]                                 # :113 scalar * Eigen expression: the literal becomes a float
             c = [f32(f32(st.vs * f32(idx[i])) - p[i]) for i in range(3)]
-            phi = f32(v[0] + sum3(gc[0] * c[0], gc[1] * c[1], gc[2] * c[2]))               # :113-114
+            phi = tsdf_return(v[0], gn, c)                                                 # :114
             E = f32(E + f32(phi * phi))
             pxg = [f32(f32(p[1] * gc[2]) - f32(p[2] * gc[1])), f32(f32(p[2] * gc[0]) - f32(p[0] * gc[2])), f32(f32(p[0] * gc[1]) - f32(p[1] * gc[0]))]
             J = gc + pxg
