@@ -75,6 +75,11 @@ def parse_args():
     ap.add_argument("--single-device", action="store_true",
                     help="dry run of the N>1 code path on a 1-GPU box: every rank uses device 0, the exchange goes through "
                          "gsdf_merge_allreduce_with over torch.distributed (RCCL refuses two ranks on one device)")
+    ap.add_argument("--rccl-double", default="", metavar="LIBFAKE_RCCL_SO",
+                    help="TEST INFRASTRUCTURE: run the whole --gpus N line on ONE GPU with the RCCL test double (tests/libfake_rccl.so) "
+                         "standing in for RCCL: every rank is started with LD_PRELOAD=<this> and HIP_VISIBLE_DEVICES=0, torch.distributed "
+                         "uses gloo, and the sharded flavour goes through gsdf_rccl_comm_init / gsdf_merge_allreduce exactly as with the "
+                         "real library.  The line is labelled `transport: rccl test double`; it is never a scaling number.")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (CPU test of --gpus N): the ranks rendezvous over gloo, barrier, max-reduce, rank 0 prints a stub line")
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="seconds the sharded flavour may take before the line is printed without it")
@@ -100,6 +105,9 @@ def spawn_ranks(args):
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+        if args.rccl_double:                                    # every rank on device 0, the double in front of any real RCCL
+            env["LD_PRELOAD"] = os.path.abspath(args.rccl_double) + ((":" + env["LD_PRELOAD"]) if env.get("LD_PRELOAD") else "")
+            env["HIP_VISIBLE_DEVICES"] = "0"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     deadline = time.time() + args.rank_timeout
     worst = 0
@@ -167,6 +175,14 @@ def main():
         sys.exit(2)
     if args.single_device:
         local_rank = 0
+    if args.rccl_double:
+        # the ranks share device 0; torch's own collectives (barrier, max over ranks, the unique-id broadcast) go over gloo -- the
+        # preloaded double would otherwise stand in for torch's RCCL as well, and it only has the seven entries libgsdf resolves
+        local_rank = 0
+        args.dist_backend = "gloo"
+        if world > 1 and os.path.abspath(args.rccl_double) not in os.environ.get("LD_PRELOAD", ""):
+            print("bench.py: --rccl-double needs LD_PRELOAD=%s in every rank (bench.py sets it when it starts the ranks itself)" % args.rccl_double, file=sys.stderr)
+            sys.exit(2)
     if args.dry_run:
         import torch
         import torch.distributed as dist
@@ -443,6 +459,7 @@ def main():
         g.track_and_fuse_dev(dev[i])
     g.sync()
     prof_t = g.profile_read()
+    trk_each = np.sort(g.profile_launches(2))[::-1]           # every tracker launch by itself, longest first
     g.profile(0)
     st_d = g.stats()
     log_t = g.frame_log()[Wm:Wm + K]
@@ -450,6 +467,12 @@ def main():
     trk_bytes = 4.0 * W * H * trk_passes + 32.0 * float(st_d["n_hit"] - st_c["n_hit"])
     trk_ms = prof_t["track_pass"]["ms"]
     trk_achieved = trk_bytes / (trk_ms * 1e-3) / 1e9 if trk_ms > 0 else 0.0
+    # Per EXECUTED pass: of the launches the host issues (batches of 5, then 8) only `passes` gather; the launch
+    # behind a frame's last pass is head-only (reduce, solve, publish) and those behind the end of optimize() return at once.
+    # The launches that ran a pass are the `passes` longest ones; their median duration is the per-pass figure.
+    n_exec = int(min(trk_passes, len(trk_each)))
+    trk_pass_us = float(np.median(trk_each[:n_exec])) * 1e3 if n_exec else 0.0
+    trk_per_pass = (trk_bytes / max(trk_passes, 1.0)) / (trk_pass_us * 1e-6) / 1e9 if trk_pass_us > 0 else 0.0
 
     # ---- the raycaster's roofline entry: render the bench map (all 1 + W + K frames tracked and fused) from the last pose ---
     # bytes per render = 8 per sample the definition evaluates (one block-key probe) + 32 per voxel record read + 16 per pixel
@@ -617,7 +640,8 @@ def main():
                     "workload": workload,
                     "width": W, "height": H, "voxel_size_m": float(vs), "trunc_voxels": args.trunc,
                     "hash_capacity_log2": args.hash_capacity_log2, "tracker": "25 iters, conv 1e-3, damping 1",
-                    "parallelism": "replicas x%d (tracked path does not shard)" % world,
+                    "parallelism": "replicas x%d (tracked path does not shard)" % world + (
+                        " -- ALL RANKS ON ONE GPU (--rccl-double: launch-path test, value is not an N-GPU number)" if args.rccl_double else ""),
                     "value_is": "median of %d timed windows" % len(runs),
                     "value_runs": [round(total_frames / r, 1) for r in runs],
                 "burn_in_windows": len(burn), "burn_in_runs": [round(total_frames / r, 1) for r in burn],
@@ -643,10 +667,14 @@ def main():
                     "algorithmic_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(fuse_ms * 1e3, 2),
                     "launches": prof["fusion"]["launches"],
                     "l2_atomics_per_launch": l2_atomics,       # the C2 table is cache resident, so report atomics too
-                    "tracker": {"kernel": "k_track_pass", "achieved": round(trk_achieved, 1), "frac": round(trk_achieved / HBM_PEAK_GBS, 4),
+                    # `frac` / `achieved`: per EXECUTED pass = (bytes of all passes / passes) / median duration of the launches that
+                    # ran one; `per_launch`: the same bytes over the time of ALL tracker launches, head-only and empty ones included
+                    "tracker": {"kernel": "k_track_pass", "achieved": round(trk_per_pass, 1), "frac": round(trk_per_pass / HBM_PEAK_GBS, 4),
                                 "algorithmic_bytes": round(trk_bytes), "passes": int(trk_passes),
-                                "launches": prof_t["track_pass"]["launches"],
-                                "avg_launch_us": round(trk_ms * 1e3 / max(prof_t["track_pass"]["launches"], 1), 2)},
+                                "pass_launch_us_median": round(trk_pass_us, 2),
+                                "per_launch": {"achieved": round(trk_achieved, 1), "frac": round(trk_achieved / HBM_PEAK_GBS, 4),
+                                               "launches": prof_t["track_pass"]["launches"],
+                                               "avg_launch_us": round(trk_ms * 1e3 / max(prof_t["track_pass"]["launches"], 1), 2)}},
                     "raycast": raycast,
                 },
                 "cpu_baseline": cpu,
@@ -876,7 +904,7 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
 
     # ---- transport, outside the timed region ----
     comm, transport, rccl_ranks = None, None, None
-    use_rccl = not args.single_device and (world == 1 or args.dist_backend == "nccl")
+    use_rccl = not args.single_device and (world == 1 or args.dist_backend == "nccl" or bool(args.rccl_double))
     if use_rccl:
         ok = 1.0
         try:
@@ -884,16 +912,22 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
             if rank == 0:
                 idt = torch.frombuffer(bytearray(pkg.binding.rccl_unique_id()), dtype=torch.uint8).clone()
             if world > 1:
-                idt = idt.cuda()
+                idt = idt.to(coll_dev)
                 dist.broadcast(idt, src=0)
-            comm = pkg.binding.rccl_comm_init(world, bytes(idt.cpu().numpy().tobytes()), rank, local_rank)
+            uid = bytes(idt.cpu().numpy().tobytes())
+            if args.rccl_double and not uid.startswith(b"/gsdf_fake_rccl_"):
+                raise RuntimeError("--rccl-double: libgsdf resolved another RCCL than the test double")
+            comm = pkg.binding.rccl_comm_init(world, uid, rank, local_rank)
             rccl_ranks = pkg.binding.rccl_comm_count(comm)
         except Exception as e:                                   # noqa: BLE001
             print("bench.py rank %d: RCCL communicator: %s" % (rank, e), file=sys.stderr)
             ok = 0.0
         # every rank takes the same route
         ok = -vmax([-ok])[0] if world > 1 else ok
-        if ok > 0:
+        if ok > 0 and args.rccl_double:
+            transport = ("rccl test double (tests/fake_rccl.c preloaded: %d processes share ONE GPU, shared-memory rendezvous; the code path of "
+                         "gsdf_rccl_comm_init / gsdf_merge_allreduce is the production one, the transport is not RCCL / xGMI -- NOT a scaling number)" % world)
+        elif ok > 0:
             transport = "rccl (gsdf_merge_allreduce: pack -> ncclAllReduce -> unpack on the context's stream)"
         else:
             if comm is not None:
@@ -935,6 +969,7 @@ def sharded_flavour(pkg, args, c4, rank, world, local_rank, torch, dist, vs, T, 
         half = (F + 1) // 2                                       # g takes the first frames of the shard, g2 the rest (contiguous)
         dev2 = [g2.upload(f[0]) for f in frames[half:]]
 
+    g.merge_prepare(world)            # like the communicator: the exchange's scratch and first-use code loads, outside the timed region
     res = {}
     for rnd in range(2):
         g.reset()

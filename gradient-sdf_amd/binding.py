@@ -149,6 +149,7 @@ def load(path=None):
         "gsdf_raycast_dev": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),
         "gsdf_raycast_counters": (C.c_int, [vp, i64p, i64p, C.c_int]),
         "gsdf_profile_read_n": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), i64p]),
+        "gsdf_profile_read_launches": (C.c_int, [vp, C.c_int, fp, C.c_int64, i64p]),
         "gsdf_raycast": (C.c_int, [vp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]),
         "gsdf_extract_mesh": (C.c_int, [vp, C.c_float, C.POINTER(C.c_int8), fp, C.c_int64, C.POINTER(C.c_int64)]),
         "gsdf_dev_alloc": (C.c_int, [vp, C.POINTER(vp), C.c_int64]),
@@ -192,7 +193,7 @@ ABI_SYMBOLS = [
     "gsdf_dev_alloc", "gsdf_dev_free", "gsdf_dev_upload", "gsdf_dev_download", "gsdf_timer_start", "gsdf_timer_stop_ms",
     "gsdf_host_alloc", "gsdf_host_free", "gsdf_dev_upload_async", "gsdf_mark", "gsdf_mark_wait", "gsdf_mark_reached",
     "gsdf_dev_upload_ahead", "gsdf_upload_wait",
-    "gsdf_profile", "gsdf_profile_read", "gsdf_profile_read_n",
+    "gsdf_profile", "gsdf_profile_read", "gsdf_profile_read_n", "gsdf_profile_read_launches",
 ]
 
 
@@ -244,6 +245,7 @@ class GradSdf:
                  zmin=0.5, zmax=3.5, lib=None, _handle=None):
         self.L = load() if lib is None else lib         # lib: load_test_lib() for the path-forcing tests
         self.h = C.c_void_p()
+        self._dev = []                                  # before anything can raise: close() / __del__ walk it
         if _handle is not None:                         # (GradSdf.shards: the context exists already)
             self.h = _handle
         else:
@@ -253,19 +255,29 @@ class GradSdf:
         self.K = _f32(K).reshape(9).copy()
         self._chk(self.L.gsdf_set_zrange(self.h, np.float32(zmin), np.float32(zmax)))
         self._chk(self.L.gsdf_normals_init(self.h, self.W, self.H, _fp(self.K), int(win)))
-        self._dev = []
 
     @classmethod
     def shards(cls, n, voxel_size, trunc_dist, W, H, K, capacity_log2=22, device=0, **kw):
         """n contexts for n frame shards on one device, each stream in its own hardware queue (gsdf_create_shards); add them up
         with first.merge_from(other)."""
-        L = load()
+        L = kw.get("lib") or load()
         hs = (C.c_void_p * n)()
         rc = L.gsdf_create_shards(hs, int(n), np.float32(voxel_size), np.float32(trunc_dist), int(capacity_log2), int(device))
         if rc != GSDF_OK:
             raise GsdfError(rc, L.gsdf_last_error().decode())
-        return [cls(voxel_size, trunc_dist, W, H, K, capacity_log2=capacity_log2, device=device, _handle=C.c_void_p(hs[i]), **kw)
-                for i in range(n)]
+        out = []
+        try:
+            for i in range(n):
+                out.append(cls(voxel_size, trunc_dist, W, H, K, capacity_log2=capacity_log2, device=device, _handle=C.c_void_p(hs[i]), **kw))
+        except Exception:
+            # a constructor failed (set_zrange / normals_init): the handles not wrapped yet belong to nobody -- destroy them
+            # (handle len(out) belongs to the half-built wrapper, whose __del__ closes it)
+            for j in range(len(out) + 1, n):
+                L.gsdf_destroy(C.c_void_p(hs[j]))
+            for g in out:
+                g.close()
+            raise
+        return out
 
     def _chk(self, rc):
         if rc != GSDF_OK:
@@ -607,6 +619,15 @@ class GradSdf:
         self._chk(self.L.gsdf_profile_read(self.h, ms, n))
         names = ("normals", "fusion", "track_pass")
         return {names[i]: {"ms": ms[i], "launches": n[i]} for i in range(3)}
+
+    def profile_launches(self, slot):
+        """durations (ms) of every launch of one slot since profile(1): 0 normals, 1 fusion, 2 tracker launches, 3 raycast"""
+        n = C.c_int64(0)
+        self._chk(self.L.gsdf_profile_read_launches(self.h, int(slot), None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.float32)
+        if n.value:
+            self._chk(self.L.gsdf_profile_read_launches(self.h, int(slot), _fp(out), n.value, C.byref(n)))
+        return out
 
     def profile_read_all(self):
         """All slots (gsdf_profile_read_n): normals, fusion, track_pass, raycast, track_opt."""

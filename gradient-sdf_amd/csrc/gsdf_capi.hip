@@ -56,7 +56,10 @@ void prof_collect(gsdf_ctx* c) {
     for (int k = 0; k < GSDF_PROF_SLOTS; ++k) {
         for (auto& pr : c->prof_events[k]) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { c->prof_ms[k] += ms; c->prof_n[k] += 1; }
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                c->prof_ms[k] += ms; c->prof_n[k] += 1;
+                if (c->prof_each[k].size() < (size_t)1 << 20) c->prof_each[k].push_back(ms);
+            }
             c->event_pool.push_back(pr.first);
             c->event_pool.push_back(pr.second);
         }
@@ -520,7 +523,15 @@ static int create_impl(gsdf_ctx** out, float voxel_size, float trunc_dist, int c
     c->n_slots = (size_t)1 << capacity_log2;
     hipError_t e;
     int prio_least = 0, prio_greatest = 0;
-    if (other_queue && hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { (void)hipGetLastError(); prio_greatest = 0; }
+    if (other_queue) {
+        /* the separate-queue guarantee of gsdf_create_shards rests on a priority pool of its own: without one it is
+         * not claimed -- an error, not a silent default-priority stream */
+        if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess || prio_greatest == prio_least) {
+            (void)hipGetLastError();
+            delete c;
+            return fail(GSDF_ERR_HIP, "gsdf_create_shards: the device offers no stream priority range, so separate hardware queues cannot be guaranteed (use gsdf_create)");
+        }
+    }
     if ((e = (other_queue ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest)
                           : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking))) != hipSuccess ||
         (e = hipMalloc((void**)&c->tab.vox, c->n_slots * sizeof(gsdf_payload))) != hipSuccess ||
@@ -1656,7 +1667,17 @@ int gsdf_profile(gsdf_ctx* c, int enable) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     prof_collect(c);
     c->profiling = enable != 0;
-    if (enable) for (int k = 0; k < GSDF_PROF_SLOTS; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; }
+    if (enable) for (int k = 0; k < GSDF_PROF_SLOTS; ++k) { c->prof_ms[k] = 0; c->prof_n[k] = 0; c->prof_each[k].clear(); }
+    return GSDF_OK;
+}
+int gsdf_profile_read_launches(gsdf_ctx* c, int slot, float* ms, int64_t max_n, int64_t* n) {
+    if (!c || !n || slot < 0 || slot >= GSDF_PROF_SLOTS || max_n < 0 || (max_n > 0 && !ms)) return fail(GSDF_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    const std::vector<float>& v = c->prof_each[slot];
+    *n = (int64_t)v.size();
+    for (int64_t i = 0; i < std::min<int64_t>(max_n, *n); ++i) ms[i] = v[i];
     return GSDF_OK;
 }
 int gsdf_profile_read(gsdf_ctx* c, double ms[3], int64_t launches[3]) {

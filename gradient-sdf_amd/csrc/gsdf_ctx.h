@@ -144,6 +144,7 @@ struct gsdf_ctx {
     std::deque<std::pair<long long, hipEvent_t>> uploads;
     long long upload_serial = 0;
     double prof_ms[GSDF_PROF_SLOTS] = { 0 };
+    std::vector<float> prof_each[GSDF_PROF_SLOTS];  /* every launch's duration since the last gsdf_profile(c, 1) (gsdf_profile_read_launches) */
     long long prof_n[GSDF_PROF_SLOTS] = { 0 };
 
     gsdf_frame_geom geom() const {

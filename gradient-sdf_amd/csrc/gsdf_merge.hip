@@ -447,6 +447,14 @@ __global__ __launch_bounds__(256) void k_count_blocks(const unsigned long long* 
 
 /* enqueue the count of existing blocks into the pinned words progress[4..5] (gsdf_capi.hip: at the top of every frame entry
  * while auto-grow is on), tagged with the entry's number */
+/* the same count into a device word (zeroed by the caller) */
+__global__ __launch_bounds__(256) void k_count_blocks_dev(const unsigned long long* bkeys, size_t n, unsigned long long* out) {
+    unsigned int c = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += bkeys[i] != GSDF_KEY_EMPTY ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
 void gsdf_enqueue_block_count(gsdf_ctx* c, unsigned int tag) {
     if (!c->progress_dev || !c->grow_scratch) return;
     const size_t cap = c->n_slots / GSDF_BLOCK_VOX;
@@ -573,21 +581,48 @@ int gsdf_merge_from(gsdf_ctx* dst, gsdf_ctx* src) {
     HIP_TRY(hipSetDevice(dst->device));
     if (int rc = gsdf_flush_pending(src)) return rc;
     if (int rc = gsdf_flush_pending(dst)) return rc;
+    /* the blocks both maps hold, counted behind everything queued on their streams and read with the state words */
     gsdf_dev_state ss, ds;
+    unsigned long long n_src = 0, n_dst = 0;
+    const size_t nb_src = src->n_slots / GSDF_BLOCK_VOX;
+    HIP_TRY(hipMemsetAsync(src->counter, 0, sizeof(unsigned long long), src->stream));
+    hipLaunchKernelGGL(k_count_blocks_dev, dim3(64), dim3(256), 0, src->stream, src->tab.bkeys, nb_src, src->counter);
+    HIP_TRY(hipMemcpyAsync(&n_src, src->counter, sizeof(n_src), hipMemcpyDeviceToHost, src->stream));
     HIP_TRY(hipMemcpyAsync(&ss, src->st, sizeof(ss), hipMemcpyDeviceToHost, src->stream));
     HIP_TRY(hipStreamSynchronize(src->stream));              /* the source map is complete (and stays untouched) */
     if (ss.status & GSDF_STATUS_TABLE_FULL) return gsdf_fail(GSDF_ERR_TABLE_FULL, "gsdf_merge_from: the source map reported a full table");
+    HIP_TRY(hipMemsetAsync(dst->counter, 0, sizeof(unsigned long long), dst->stream));
+    hipLaunchKernelGGL(k_count_blocks_dev, dim3(64), dim3(256), 0, dst->stream, dst->tab.bkeys, dst->n_slots / GSDF_BLOCK_VOX, dst->counter);
+    HIP_TRY(hipMemcpyAsync(&n_dst, dst->counter, sizeof(n_dst), hipMemcpyDeviceToHost, dst->stream));
     HIP_TRY(hipMemcpyAsync(&ds, dst->st, sizeof(ds), hipMemcpyDeviceToHost, dst->stream));
     HIP_TRY(hipStreamSynchronize(dst->stream));
-    const size_t nb_src = src->n_slots / GSDF_BLOCK_VOX;
+    /* Room in dst: the union holds at most n_dst + n_src blocks.  Beyond the 45 % at which the frame entries double
+     * the table, dst is doubled here too when gsdf_set_auto_grow allows it; where it does not and the worst case would pass
+     * 90 % of the entries (the probe budget runs out near 95 %), the call fails BEFORE dst is touched. */
+    {
+        const size_t worst = (size_t)n_dst + (size_t)n_src;
+        int need = dst->capacity_log2;
+        while (need < 30 && worst * 100u > (((size_t)1 << need) / GSDF_BLOCK_VOX) * 45u) ++need;
+        if (need > dst->capacity_log2 && dst->auto_grow_max > dst->capacity_log2) {
+            if (int rc = gsdf_grow_impl(dst, std::min(need, dst->auto_grow_max))) return rc;
+        }
+        if (worst * 100u > (dst->n_slots / GSDF_BLOCK_VOX) * 90u)
+            return gsdf_fail(GSDF_ERR_TABLE_FULL, "gsdf_merge_from: dst cannot hold the blocks of both maps (" + std::to_string(n_dst) + " + " +
+                             std::to_string(n_src) + " of " + std::to_string(dst->n_slots / GSDF_BLOCK_VOX) + " entries); dst is unchanged -- gsdf_grow it or allow it with gsdf_set_auto_grow");
+    }
     hipLaunchKernelGGL(k_merge_from, dim3((unsigned int)((nb_src + 3) / 4)), dim3(256), 0, dst->stream, src->tab, dst->tab, src->vis, dst->vis,
                        dst->vis ? dst->vis_words : 0, (long long)ds.frames, nb_src, dst->st);
     HIP_TRY(hipGetLastError());
-    gsdf_launch_set_frames(dst->stream, dst->st, (long long)(ds.frames + ss.frames));   /* Sdf::counter_ = frames of both shards */
     dst->occ_dirty = true;
     dst->ba_gate_fresh = false;
     dst->grow_forget = true;
-    return read_status(dst);                                  /* synchronises: the source may be reset or destroyed afterwards */
+    /* synchronises: the source may be reset or destroyed afterwards.  Sdf::counter_ only advances when every block found its
+     * entry: behind a GSDF_ERR_TABLE_FULL here (possible between 45 % and 90 % only in theory: a probe chain that runs out early)
+     * dst holds PART of src and is to be reset. */
+    if (int rc = read_status(dst)) return rc;
+    gsdf_launch_set_frames(dst->stream, dst->st, (long long)(ds.frames + ss.frames));   /* Sdf::counter_ = frames of both shards */
+    HIP_TRY(hipStreamSynchronize(dst->stream));
+    return GSDF_OK;
 }
 
 int gsdf_grow(gsdf_ctx* c, int new_capacity_log2) { return gsdf_grow_impl(c, new_capacity_log2); }

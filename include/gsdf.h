@@ -196,12 +196,19 @@ int gsdf_merge_raw(gsdf_ctx* c, const int32_t* keys, const float* payload_raw, i
  * a third of the chip's workgroup slots idle in its tail, which the other context's launch fills -- and adds them up locally
  * before the exchange between devices.  Voxel sums are added, Sdf::counter_ becomes the frames of both, vis_ bit-vectors of the
  * source (if enabled, alike on both) are OR-ed in shifted by dst's frame count (dst's frames come first).  Synchronous; src is
- * left unchanged. */
+ * left unchanged.  Room: the union holds at most blocks(dst) + blocks(src); if that passes 45 % of dst's block entries dst is
+ * doubled first when gsdf_set_auto_grow allows it, and if it would pass 90 % of them (no growth allowed, or not enough) the call
+ * returns GSDF_ERR_TABLE_FULL with dst UNCHANGED.  Should the kernel itself still report a full table, dst holds part of src,
+ * Sdf::counter_ is not advanced and dst is to be reset (gsdf_reset). */
 int gsdf_merge_from(gsdf_ctx* dst, gsdf_ctx* src);
 /* n (1..4) contexts for n frame shards on ONE device, like gsdf_create each -- but their streams are guaranteed to sit in n
  * different hardware queues (created at the device's highest stream priority: the runtime pools its queues per priority, and
  * nothing else uses that pool), so that their launches overlap.  Streams of the default priority share queues as soon as the
- * process holds more streams than the runtime has queues (4), and then two contexts fuse no faster than one. */
+ * process holds more streams than the runtime has queues (4), and then two contexts fuse no faster than one.
+ * Side effects, stated: the shard streams run at the HIGHEST priority, so their launches are scheduled ahead of default-priority
+ * work on the same GPU (other gsdf contexts, PyTorch) -- meant for a process whose GPU work at that moment IS the shard fusion;
+ * and the guarantee holds only while nothing else in the process creates highest-priority streams.  A device without a stream
+ * priority range makes the call fail (GSDF_ERR_HIP) instead of handing out default-priority streams. */
 int gsdf_create_shards(gsdf_ctx** out, int n, float voxel_size, float trunc_dist, int capacity_log2, int device);
 
 /* device-buffer variants for the multi-GPU exchange (RCCL works on device memory): unsorted
@@ -331,6 +338,10 @@ int gsdf_profile(gsdf_ctx* c, int enable);
 int gsdf_profile_read(gsdf_ctx* c, double ms[3], int64_t launches[3]);
 /* the first n <= 5 slots: 0 normals, 1 fusion, 2 tracking pass launches, 3 raycast, 4 reserved */
 int gsdf_profile_read_n(gsdf_ctx* c, int n, double* ms, int64_t* launches);
+/* every launch of one slot by itself, in launch order (ms each; at most 2^20 kept): *n = launches recorded since the last
+ * gsdf_profile(c, 1), the first min(max_n, *n) durations in ms[].  Lets a caller tell the tracker launches that ran a pass from
+ * the head-only ones and those that found optimize() already ended (bench.py: roofline.tracker per executed pass). */
+int gsdf_profile_read_launches(gsdf_ctx* c, int slot, float* ms, int64_t max_n, int64_t* n);
 
 #ifdef __cplusplus
 }

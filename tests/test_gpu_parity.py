@@ -11,6 +11,9 @@ from test_oracle_serial_vs_omp import SERIAL_VS_OMP_FLIPS
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+# frames of the free-running 64-frame bench stream that agree with the oracle EXACTLY (flag, pass count) before the first one that
+# differs; measured on MI355X in round 6 (see the MEASURED line the test prints with -rP)
+N_STRICT_FLOOR = 8
 
 
 def _mk(pkg, O, kind="spheres", W=160, H=120, vs=0.02, trunc=5, cap=18, seed=1, n=4, lib=None, **kw):
@@ -575,8 +578,11 @@ def test_tracked_bench_stream_matches_oracle_frame_by_frame(pkg, O):
     conv_o = np.array(conv_o)
     conv_g = log[:, 7] > 0
     # every deterministic frame in front of the first sensitive one agreed exactly (the assertion inside the loop), so:
+    print("MEASURED n_strict %d first_sensitive %s strict_not_conv %d flags_equal %.3f conv_g %d conv_o %d" % (
+        n_strict, first_sensitive, strict_not_conv, (conv_g == conv_o).mean(), conv_g.sum(), conv_o.sum()))
     assert first_sensitive is not None and n_strict >= first_sensitive - 1, (n_strict, first_sensitive)
-    assert n_strict >= 8 and strict_not_conv >= 1         # ... among them frames that run all 25 passes and are not fused
+    # ... and an absolute floor near the measured value (the relative bound alone would follow a regression down)
+    assert n_strict >= N_STRICT_FLOOR and strict_not_conv >= 1         # ... among them frames that run all 25 passes and are not fused
     assert not bool(log[0, 7]) and int(log[0, 8]) == 25   # frame 1: one fused frame in the map, 25 passes, not fused
     # the whole stream in the aggregate
     # the yardstick: the reference's own serial and OMP builds, each free-running on this stream, give the same flag on 61 of 63
@@ -1168,4 +1174,31 @@ def test_tracker_head_takes_the_exact_forms_outside_the_fast_range(pkg, O):
     assert float(np.linalg.norm(xi[3:])) > 0.1, xi                # the step really is outside the fast range
     assert passes == used == 1
     assert np.abs(pg[:3] - po[:3]).max() < TOL and np.abs(np.abs(pg[3:]) - np.abs(po[3:])).max() < TOL, (pg, po)
+    g.close()
+
+
+def test_tracker_fast_head_stays_within_ulps_of_the_exact_head(pkg, O):
+    """the head's common case (rcp / rsq + one Newton step, FMA dots, polynomial sin / cos) is a <= 1-ulp form per
+    operation, not the oracle's exact one.  Test build, tracker debug bit 4 = every head takes the exact forms: from the same
+    start pose and map the two heads must give the same pass count and poses within a few ulps of the pose, pass by pass --
+    so that later drift in the fast forms is caught here and not as a mysterious flip in a stream test."""
+    L = pkg.binding.load_test_lib()
+    seq, g, o = _mk(pkg, O, kind="tum", W=640, H=480, vs=0.01, trunc=10, cap=21, n=3, seed=0, lib=L)
+    d0, R0, t0 = seq.frame(0)
+    g.update(d0, R0, t0)
+    d1, _, _ = seq.frame(1)
+    p0 = pose7_from(O, R0, t0)
+    worst = 0.0
+    for iters in (1, 2, 3, 4, 25):
+        g.debug_flags(0)
+        cf, pf, nf = g.track(d1, p0, iters=iters)
+        g.debug_flags(4 << 16)
+        ce, pe, ne = g.track(d1, p0, iters=iters)
+        assert (cf, nf) == (ce, ne), (iters, cf, nf, ce, ne)
+        ulp = np.spacing(np.maximum(np.abs(pe), np.float32(1.0)).astype(np.float32))
+        worst = max(worst, float((np.abs(pf - pe) / ulp).max()))
+    print("MEASURED fast-vs-exact head: worst %.1f ulp(max(1, |pose|))" % worst)
+    # each pass adds a few 1-ulp operations on top of sums that agree to ~1e-7 relative; the Gauss-Newton map is contracting here
+    assert worst <= 16.0, worst
+    g.debug_flags(0)
     g.close()

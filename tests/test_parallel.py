@@ -333,6 +333,43 @@ def test_merge_from_two_contexts_on_one_gpu(pkg, O):
     a.close(); b.close()
 
 
+@pytest.mark.gpu
+def test_merge_from_checks_the_room_in_dst_before_touching_it(pkg, O):
+    """a dst too small for both maps used to come back half merged with the frame counter advanced.  Now the blocks
+    of both maps are counted first: without leave to grow the call fails with GSDF_ERR_TABLE_FULL and dst is bit for bit what
+    it was; with gsdf_set_auto_grow dst is doubled as far as needed and the merge equals the oracle's map of all frames."""
+    W, H, n = 320, 240, 6
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=3)
+    vs = np.float32(0.01); T = np.float32(10) * vs
+    fr = [seq.frame(i) for i in range(n)]
+    src = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=20)
+    for d, R, t in fr[1:]:
+        src.update(d, R, t)
+    dst = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=18)          # 4096 block entries
+    dst.update(*fr[0])
+    k0, p0 = dst.export(sorted=True, raw=True)
+    blocks_dst = len(np.unique(k0 >> 2, axis=0))
+    ks, _ = src.export(sorted=True, raw=True)
+    blocks_src = len(np.unique(ks >> 2, axis=0))
+    assert (blocks_dst + blocks_src) * 100 > 4096 * 90, (blocks_dst, blocks_src)      # the case under test: no room
+    with pytest.raises(pkg.GsdfError) as e:
+        dst.merge_from(src)
+    assert e.value.code == pkg.binding.ERR_TABLE_FULL and "unchanged" in str(e.value)
+    k1, p1 = dst.export(sorted=True, raw=True)
+    assert np.array_equal(k0, k1) and np.array_equal(p0, p1) and dst.stats()["frames"] == 1 and dst.capacity_log2() == 18
+    dst.set_auto_grow(22)
+    dst.merge_from(src)
+    assert dst.capacity_log2() >= 20 and dst.stats()["frames"] == n
+    o = O.Oracle(vs, T, W, H, seq.K)
+    for d, R, t in fr:
+        o.update(d, R, t)
+    keys, pay = o.export()
+    ka, pa = dst.export(sorted=True, raw=True)
+    assert np.array_equal(ka, keys)
+    assert np.abs(pa[:, 0] / pa[:, 4] - pay[:, 0]).max() <= 1e-4
+    src.close(); dst.close()
+
+
 # ---- the RCCL-typed path with PEERS (VERDICT r4 #2 / #6) ------------------------------------------------------------------
 # gsdf_merge_allreduce(ctx, ncclComm_t) had only ever run with nranks = 1: RCCL refuses two ranks on one device and the pool
 # offers one GPU per call.  tests/fake_rccl.c is a test double for the seven nccl* entry points libgsdf resolves with
@@ -468,7 +505,7 @@ def _tri_cells(tris, vs):
 
 
 @pytest.mark.gpu
-def test_c4_as_configured_shards_exchange_mesh(pkg, tmp_path):
+def test_c4_as_configured_shards_exchange_mesh(pkg, O, tmp_path):
     """BASELINE configs[3] at its frame size and voxel size: four ranks x 32 frames of the sphere orbit (640x480, 1 cm, trunc 10,
     ground-truth poses) -> gsdf_merge_allreduce_with -> every rank holds the map ONE context gets from all 128 frames: key set
     bit-exact, sums within float re-association (1e-5 relative; the shards add 32 frames each and then the four sums, the single
@@ -504,6 +541,21 @@ def test_c4_as_configured_shards_exchange_mesh(pkg, tmp_path):
     scale = np.maximum(1.0, np.abs(pay[:, 4:5]))
     assert (np.abs(a["pay"] - pay) / scale).max() <= 1e-5
     assert np.array_equal(a["vis"], vis)
+    # ... and the ORACLE on the same 128 full-size frames (the full-size exchange is held to the oracle, not only
+    # to another GPU context): key set bit-exact, distance <= 1e-4, weight / gradient sums <= 1e-4 relative to the weight
+    # (the rule of test_gpu_parity._cmp_tables), vis_ bit-vectors and the frame counter equal.  ~1 min on one core.
+    o = O.Oracle(vs, np.float32(10) * vs, C4_W, C4_H, seq.K)
+    for i in range(n):
+        d, R, t = seq.frame(i)
+        o.update(d, R, t)
+    ko, po = o.export()
+    assert np.array_equal(a["keys"], ko) and o.frame_counter() == n
+    w = a["pay"][:, 4]
+    osc = np.maximum(1.0, po[:, 4])
+    assert np.abs(a["pay"][:, 0] / w - po[:, 0]).max() <= 1e-4
+    assert (np.abs(w - po[:, 4]) / osc).max() <= 1e-4
+    assert (np.abs(a["pay"][:, 1:4] - po[:, 1:4]).max(axis=1) / osc).max() <= 1e-4
+    assert np.array_equal(a["vis"], o.export_vis((n + 31) // 32))
     # the meshes
     ta, tb = a["tris"], tris
     assert len(tb) > 20000 and abs(len(ta) - len(tb)) <= 1e-3 * len(tb)
@@ -594,3 +646,24 @@ def test_bench_two_ranks_on_one_gpu(pkg):
     assert sh["voxels_merged"] > sh["voxels_own_shard"] and sh["mesh_faces"] > 1000
     assert out["roofline"]["raycast"]["avg_launch_us"] > 0 and out["roofline"]["raycast"]["hit_fraction"] > 0.5
     assert out["cpu_baseline"] is None                               # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_bench_gpus_8_end_to_end_over_the_rccl_double():
+    """`python bench.py --gpus 8` had never run end to end anywhere.  On ONE GPU over the RCCL test double
+    (TEST INFRASTRUCTURE: LD_PRELOAD=tests/libfake_rccl.so and HIP_VISIBLE_DEVICES=0 in every rank, torch.distributed over gloo):
+    bench.py starts its 8 ranks, they rendezvous, run the tracked replica windows with the max-over-ranks timing, exchange the
+    unique id, gsdf_rccl_comm_init x 8, gsdf_merge_prepare, fuse their shards on two contexts each, gsdf_merge_allreduce with 8
+    peers, mesh on rank 0, ONE JSON line from rank 0 -- labelled as the double so that it can never pass for a scaling number."""
+    fake = _build_fake_rccl()
+    out = _run_bench(["--gpus", "8", "--steps", "10", "--warmup", "3", "--repeats", "2", "--c4-frames", "16", "--rccl-double", fake,
+                      "--raycast-reps", "0", "--no-staged", "--rank-timeout", "800"], timeout=900)
+    assert out["n_gpus"] == 8 and out["steps"] == 10 and out["value"] > 0 and out["scaling"] == "weak"
+    assert "ONE GPU" in out["config"]["parallelism"]
+    sh = out["config"]["sharded"]
+    assert sh is not None and sh["ranks"] == 8 and sh["rccl_ranks"] == 8 and sh["contexts_per_gpu"] == 2
+    assert sh["transport"].startswith("rccl test double")
+    assert sh["same_map_as_one_context"] is True
+    assert sh["frames_total"] == 8 * 16 and sh["frames_counter_after_merge"] == 8 * 16
+    assert sh["voxels_merged"] > sh["voxels_own_shard"] and sh["exchange_blocks"] > 1000 and sh["mesh_faces"] > 1000
+    assert out["cpu_baseline"] is None or out["n_gpus"] == 8          # the CPU baseline is an N = 1 item
