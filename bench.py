@@ -80,6 +80,7 @@ def parse_args():
                          "standing in for RCCL: every rank is started with LD_PRELOAD=<this> and HIP_VISIBLE_DEVICES=0, torch.distributed "
                          "uses gloo, and the sharded flavour goes through gsdf_rccl_comm_init / gsdf_merge_allreduce exactly as with the "
                          "real library.  The line is labelled `transport: rccl test double`; it is never a scaling number.")
+    ap.add_argument("--no-next-hint", action="store_true", help="do not name the next frame ahead (gsdf_hint_next_depth_dev): A/B of that entry")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (CPU test of --gpus N): the ranks rendezvous over gloo, barrier, max-reduce, rank 0 prints a stub line")
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="seconds the sharded flavour may take before the line is printed without it")
@@ -155,6 +156,19 @@ def render_frames(kind, W, H, indices, seed, **kw):
     return seq, [seq.frame(i) for i in indices]
 
 
+NEXT_HINT = True            # --no-next-hint: A/B of gsdf_hint_next_depth_dev
+
+
+def track_fuse(g, dev, i, last):
+    """One step: gsdf_track_and_fuse_dev of frame i.  The frames are resident, so the next one is known: it is named first
+    (gsdf_hint_next_depth_dev) and its normals are computed in the tail of this frame's fusion launch instead of beside the
+    next frame's tracker passes -- time only, same poses and map (tests/test_gpu_parity.py::test_next_depth_hint_is_invisible_except_in_time).
+    `last`: the last frame index of the loop (no hint beyond it)."""
+    if NEXT_HINT and i < last:
+        g.hint_next_depth(dev[i + 1])
+    g.track_and_fuse_dev(dev[i])
+
+
 def quat_to_R(q):
     x, y, z, w = [np.float32(v) for v in q]
     tx, ty, tz = 2 * x, 2 * y, 2 * z
@@ -197,6 +211,8 @@ def main():
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "max_over_ranks": float(t.item()), "local_rank": local_rank}))
         return
+    global NEXT_HINT
+    NEXT_HINT = not args.no_next_hint
     if args.only_main:
         args.c4_frames = 0
         args.raycast_reps = 0
@@ -273,7 +289,7 @@ def main():
         g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
         g.set_pose(p0)
         for i in range(1, 1 + Wm):
-            g.track_and_fuse_dev(dev[i])
+            track_fuse(g, dev, i, Wm + K)
 
     # ---- burn-in: whole windows, untimed ------------------------------------------------------------------------------
     # Python's cyclic garbage collector is switched off for the windows: a generation-2 collection -- ~40 ms with the frame
@@ -290,7 +306,7 @@ def main():
         sync_all()
         t_b = time.perf_counter()
         for i in range(1 + Wm, 1 + Wm + K):
-            g.track_and_fuse_dev(dev[i])
+            track_fuse(g, dev, i, Wm + K)
         sync_all()
         burn.append(max_over_ranks([time.perf_counter() - t_b])[0])
         if len(burn) >= 2 and burn[-1] <= 1.5 * min(burn):
@@ -306,7 +322,7 @@ def main():
         sync_all()
         t_start = time.perf_counter()
         for i in range(1 + Wm, 1 + Wm + K):
-            g.track_and_fuse_dev(dev[i])
+            track_fuse(g, dev, i, Wm + K)
         sync_all()
         runs.append(max_over_ranks([time.perf_counter() - t_start])[0])
     elapsed = float(np.median(runs))          # (the collector stays off: the flavours measured below are timed too)
@@ -640,6 +656,7 @@ def main():
                     "workload": workload,
                     "width": W, "height": H, "voxel_size_m": float(vs), "trunc_voxels": args.trunc,
                     "hash_capacity_log2": args.hash_capacity_log2, "tracker": "25 iters, conv 1e-3, damping 1",
+                    "next_depth_hint": bool(NEXT_HINT),   # gsdf_hint_next_depth_dev in the resident loops (see track_fuse)
                     "parallelism": "replicas x%d (tracked path does not shard)" % world + (
                         " -- ALL RANKS ON ONE GPU (--rccl-double: launch-path test, value is not an N-GPU number)" if args.rccl_double else ""),
                     "value_is": "median of %d timed windows" % len(runs),
@@ -743,7 +760,7 @@ def _tracked_windows(g, dev, frames, Wm, K, repeats):
         g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
         g.set_pose(p0)
         for i in range(1, 1 + Wm):
-            g.track_and_fuse_dev(dev[i])
+            track_fuse(g, dev, i, Wm + K)
     runs, st_w = [], None
     for rep in range(1 + repeats):                            # one whole window untimed first
         start()
@@ -751,7 +768,7 @@ def _tracked_windows(g, dev, frames, Wm, K, repeats):
         st_w = g.stats()
         t_start = time.perf_counter()
         for i in range(1 + Wm, 1 + Wm + K):
-            g.track_and_fuse_dev(dev[i])
+            track_fuse(g, dev, i, Wm + K)
         g.sync()
         if rep:
             runs.append(time.perf_counter() - t_start)
@@ -779,7 +796,7 @@ def two_streams_flavour(pkg, args, seq, frames, local_rank, vs, T, W, H, Wm, K):
         g.update_dev(dev[0], quat_to_R(p0[3:]), t0)
         g.set_pose(p0)
         for i in range(1, 1 + Wm):
-            g.track_and_fuse_dev(dev[i])
+            track_fuse(g, dev, i, Wm + K)
         g.sync()
     runs, logs = [], None
     for rep in range(4):                                      # the first window is untimed
@@ -795,7 +812,7 @@ def two_streams_flavour(pkg, args, seq, frames, local_rank, vs, T, W, H, Wm, K):
             try:
                 gate.wait()
                 for i in range(1 + Wm, 1 + Wm + K):
-                    g.track_and_fuse_dev(dev[i])
+                    track_fuse(g, dev, i, Wm + K)
                 g.sync()
             except Exception as e:                              # noqa: BLE001 -- reported by the caller's thread below
                 errs.append(e)

@@ -216,16 +216,29 @@ int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsd
 }
 
 /* normals (unless the frame's were computed beside its first tracker pass: normals_done) + fusion, in stream order */
-int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done) {
+int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done, int set,
+                 const float* next_depth) {
     const size_t N = (size_t)c->W * c->H;
-    float* nrm = c->normals + (size_t)2 * 3 * N;       /* tracked frames: set 2, filled beside the first tracker pass */
+    /* tracked frames: set 2, filled beside the first tracker passes -- or the set the PREVIOUS frame's fusion filled in its
+     * tail (gsdf_hint_next_depth_dev) */
+    float* nrm = c->normals + (size_t)set * 3 * N;
     if (!normals_done) {
         nrm = c->normals + (size_t)c->nrm_parity * 3 * N;
         c->nrm_parity ^= 1;
+        c->nrm_ready_depth = nullptr;                  /* (sets 0 / 1 are also where a hinted frame's normals wait) */
         prof_scope ps(c, 0);
         gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr, stats_of(c, nrm));
+        next_depth = nullptr;
     }
-    return launch_fuse(c, depth_dev, nrm, pose, use_dev_pose, nullptr, nullptr);
+    float* next_nrm = nullptr;
+    if (next_depth) {
+        /* gsdf_hint_next_depth_dev: this launch's last workgroups compute NormalEstimator::compute of the NEXT frame (they do
+         * not look at the gate), into whichever of sets 0 / 1 this fusion does not read */
+        const int next_set = set == 0 ? 1 : 0;
+        next_nrm = c->normals + (size_t)next_set * 3 * N;
+        c->nrm_ready_depth = next_depth; c->nrm_ready_set = next_set;
+    }
+    return launch_fuse(c, depth_dev, nrm, pose, use_dev_pose, next_depth, next_nrm);
 }
 
 /* RigidPointOptimizer::optimize_sampled as a chain of per-pass launches.  The convergence test, the pose update
@@ -239,7 +252,8 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
  * done, passes) and only issues a further batch if the optimisation has not ended by the last head of the
  * previous one.  Correctness never depends on what the host sees: a late or lost observation only costs empty
  * launches. */
-int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done);
+int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done, int set = 2,
+                 const float* next_depth = nullptr);
 
 /* 1 = optimize() ended, 0 = the head of launch `last` ran and it has not ended, -1 = gave up waiting */
 int follow_progress(gsdf_ctx* c, unsigned int serial, int last) {
@@ -272,13 +286,23 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     }
     gsdf_pose_arg unused;
     std::memset(&unused, 0, sizeof(unused));
+    /* gsdf_hint_next_depth_dev: (1) this frame's normals may already lie in set 0 / 1 -- the previous frame's fusion computed them
+     * in its tail -- and then no normals tiles ride in this frame's tracker launches; (2) this frame's fusion (the first one
+     * queued) computes the hinted NEXT frame's.  Not in event-timed replays (gsdf_profile): there the fusion launch is the plain
+     * one, so that what bench.py quotes as k_fuse's duration is the fusion work alone. */
+    const bool pre = fuse_after && !c->profiling && c->nrm_ready_depth == depth_dev && c->nrm_ready_set >= 0 && iters > 0;
+    const int fuse_set = pre ? c->nrm_ready_set : 2;
+    const float* hint = fuse_after && !c->profiling && iters > 0 ? c->hint_next : nullptr;
+    c->nrm_ready_depth = nullptr;        /* consumed (or not ours) */
+    c->hint_next = nullptr;
+    if (hint == depth_dev) hint = nullptr;
     if (iters <= 0) {
         gsdf_launch_track_none(c->stream, c->st);
         return fuse_after ? enqueue_fuse(c, depth_dev, unused, 1, false) : GSDF_OK;
     }
     if (iters > 0x7FFF) return fail(GSDF_ERR_INVALID, "num_iterations must be <= 32767");
     gsdf_normals_job nj;
-    if (fuse_after) {                    /* the frame's normals ride along with its first pass */
+    if (fuse_after && !pre) {            /* the frame's normals ride along with its first passes */
         const size_t N = (size_t)c->W * c->H;
         nj.nc = c->ncache();
         nj.nx = c->normals + 6 * N; nj.ny = c->normals + 7 * N; nj.nz = c->normals + 8 * N;          /* set 2 */
@@ -307,10 +331,10 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
         {
             prof_scope ps(c, 2);
             gsdf_launch_track_all(c->stream, g, depth_dev, c->tab, c->st, c->track_rows, c->track_abort, c->track_blocks, tp,
-                                  fuse_after ? &nj : nullptr);
+                                  fuse_after && !pre ? &nj : nullptr);
         }
         if (fuse_after) {
-            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true);               /* main_scan_3d.cpp:261-265 */
+            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint);   /* main_scan_3d.cpp:261-265 */
             if (rc) return rc;
         }
         hipError_t e = hipGetLastError();
@@ -331,7 +355,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
              * tiles; launch 0 has no head and ends early, so it takes the smallest one.  Tile 0 (it resets the frame's deferred list)
              * stays in launch 0. */
             const gsdf_normals_job* job = nullptr;
-            if (fuse_after && k <= 2) {
+            if (fuse_after && !pre && k <= 2) {
                 const int tiles = gsdf_normals_tiles(c->W, c->H);
                 const bool three = iters >= 2 && batch >= 3;
                 const int b1 = std::max(1, tiles * c->nrm_split / 100);
@@ -348,8 +372,9 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
          * once the progress word says that optimize() has ended (the frame that converges late pays the host's look). */
         bool fuse_queued = false;
         if (fuse_after && (batch_no == 0 || last == iters || !c->lazy_fuse)) {
-            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true);           /* main_scan_3d.cpp:261-265 */
+            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint);   /* main_scan_3d.cpp:261-265 */
             if (rc) return rc;
+            hint = nullptr;                                  /* the first fusion launch of the frame carries the next frame's normals */
             fuse_queued = true;
         }
         ++batch_no;
@@ -364,8 +389,9 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
         }
         if (ended) {
             if (fuse_after && !fuse_queued) {
-                const int rc = enqueue_fuse(c, depth_dev, unused, 1, true);
+                const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint);
                 if (rc) return rc;
+                hint = nullptr;
             }
             break;
         }
@@ -398,6 +424,14 @@ int gsdf_flush_pending(gsdf_ctx* c) {
  * upload(buf) -> update_dev(buf) -> upload(buf) -> update_dev(buf) on ONE staging buffer is correct by stream order only if
  * the waiting fusion is launched before the second copy is queued.  Copies elsewhere leave the pipelining alone. */
 static int flush_if_overlaps(gsdf_ctx* c, const void* dst, int64_t bytes) {
+    if (c && (c->nrm_ready_depth || c->hint_next)) {
+        /* a copy into a frame whose normals were computed ahead (gsdf_hint_next_depth_dev), or that is hinted: those belong to the
+         * old contents -- forget them, the frame's own tracker launches compute its normals then */
+        const uintptr_t a0 = (uintptr_t)dst, a1 = a0 + (uintptr_t)std::max<int64_t>(bytes, 0);
+        const size_t fb = (size_t)c->W * c->H * sizeof(float);
+        for (const float** q : { &c->nrm_ready_depth, &c->hint_next })
+            if (*q) { const uintptr_t b0 = (uintptr_t)*q; if (a0 < b0 + fb && b0 < a1) *q = nullptr; }
+    }
     if (!c || !c->pending.valid) return GSDF_OK;
     const uintptr_t a0 = (uintptr_t)dst, a1 = a0 + (uintptr_t)std::max<int64_t>(bytes, 0);
     const uintptr_t b0 = (uintptr_t)c->pending.depth, b1 = b0 + (size_t)c->W * c->H * sizeof(float);
@@ -611,6 +645,7 @@ int gsdf_reset(gsdf_ctx* c) {
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     c->pending.valid = false;                              /* a fusion that was never launched is dropped with the map */
+    c->hint_next = nullptr; c->nrm_ready_depth = nullptr;  /* (gsdf_hint_next_depth_dev: a new scan starts without them) */
     if (c->deferred_count) HIP_TRY(hipMemsetAsync(c->deferred_count, 0, sizeof(unsigned int), c->stream));
     gsdf_launch_table_clear(c->stream, c->tab, c->n_slots);
     if (c->vis) HIP_TRY(hipMemsetAsync(c->vis, 0, c->n_slots * (size_t)c->vis_words * sizeof(uint32_t), c->stream));
@@ -673,6 +708,7 @@ int gsdf_normals_init(gsdf_ctx* c, int W, int H, const float K[9], int win) {
     c->track_rows = nullptr; c->track_abort = nullptr;
     c->tile_flags = nullptr; c->tile_order = nullptr; c->tile_stats = nullptr;
     c->planes = c->depth_stage = c->normals = nullptr; c->partials = nullptr; c->depth_sampled = nullptr;
+    c->hint_next = nullptr; c->nrm_ready_depth = nullptr;
     c->blk_counters = nullptr; c->frame_log = nullptr; c->deferred = nullptr; c->deferred_count = nullptr; c->fuse_ticket = nullptr;
     c->W = W; c->H = H; c->win = win;
     std::memcpy(c->K, K, 9 * sizeof(float));
@@ -781,6 +817,7 @@ int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const
     const size_t N = (size_t)c->W * c->H;
     const int set = c->nrm_parity;
     c->nrm_parity ^= 1;
+    c->nrm_ready_depth = nullptr;                          /* sets 0 / 1 are this path's: a hinted tracked frame's normals are gone */
     float* nrm = c->normals + (size_t)set * 3 * N;
     if (!c->pending.valid) {
         gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr, stats_of(c, nrm));
@@ -855,6 +892,12 @@ int gsdf_track_sampled(gsdf_ctx* c, const float* depth_host, const float K[9], f
     if (converged) *converged = s.converged;
     if (passes) *passes = s.passes;
     return status_to_code(s.status);
+}
+
+int gsdf_hint_next_depth_dev(gsdf_ctx* c, const float* next_depth_dev) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    c->hint_next = next_depth_dev;                       /* nullptr withdraws it; no device work, no flush */
+    return GSDF_OK;
 }
 
 int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9], int num_iterations,
@@ -1620,6 +1663,11 @@ int gsdf_dev_upload_ahead(gsdf_ctx* c, void* dev_dst, const void* host_src, int6
             return fail(GSDF_ERR_INVALID, "gsdf_dev_upload_ahead into the depth image of a fusion that has not run yet (record a gsdf_mark "
                                           "behind its gsdf_update_dev and wait for it first)");
     }
+    for (const float** q : { &c->nrm_ready_depth, &c->hint_next })      /* new contents: normals computed ahead are the old frame's */
+        if (*q) {
+            const uintptr_t a0 = (uintptr_t)dev_dst, b0 = (uintptr_t)*q;
+            if (a0 < b0 + (size_t)c->W * c->H * sizeof(float) && b0 < a0 + (uintptr_t)bytes) *q = nullptr;
+        }
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->copy_stream));
     hipEvent_t e = nullptr;                                      /* (a pool of their own: these keep the default fences) */

@@ -82,6 +82,11 @@ struct gsdf_ctx {
     unsigned long long* rc_counts = nullptr;       /* raycaster: per-workgroup rows of (samples, records, fast / slow iterations of wave 0) */
     size_t rc_rows = 0;
     long long rc_iters[2] = { 0, 0 };              /* loop iterations of the workgroups' wave 0 as of the last gsdf_raycast_counters */
+    /* gsdf_hint_next_depth_dev: the frame the NEXT gsdf_track_and_fuse_dev will be called with (set by the caller, consumed by the
+     * next frame entry), and the frame whose normals a fusion launch has already computed into set nrm_ready_set (0 / 1) */
+    const float* hint_next = nullptr;
+    const float* nrm_ready_depth = nullptr;
+    int nrm_ready_set = -1;
     float* depth_sampled = nullptr;                /* the compacted pixels of gsdf_track_sampled (sampling > 1), lazily allocated */
     void* scratch = nullptr;                       /* device scratch of gsdf_query / gsdf_get_voxels for small batches (GSDF_SCRATCH_BYTES) */
     bool occ_dirty = false;                        /* blocks may have been inserted since the raycaster's filters (gsdf_table::occ) were built */

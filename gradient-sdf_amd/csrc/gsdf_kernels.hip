@@ -161,7 +161,8 @@ __device__ __forceinline__ double ncache_moment(int m, int u, int v, double fx_i
     const double x = fx_inv * ((double)u - cx);                /* :94,98 */
     const double y = fy_inv * ((double)v - cy);                /* :96,100 */
     const double x_sq = x * x, y_sq = y * y;
-    const double n_sq = 1. + x_sq + y_sq;                      /* :104 */
+    const double n_sq = x_sq + (y_sq + 1.);                    /* :104 as cv::MatExpr evaluates `1. + x0_sq + y0_sq`: ONE addWeighted(x0_sq, 1,
+                                                                  y0_sq, 1, gamma = 1), OpenCV 4's loop v_fma(a, 1, v_fma(b, 1, gamma)) */
     const double ni = 1. / n_sq;                               /* :105 */
     switch (m) {                                               /* :106-114 */
     case 0: return x_sq * ni;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(64) void k_ncache_cols(int W, int H, double fx_inv,
         const double det_inv = 1. / det;                                                      /* :118 */
         const double x = fx_inv * ((double)u - cx);
         const double y = fy_inv * ((double)v - cy);
-        const double n_sq = 1. + x * x + y * y;
+        const double n_sq = x * x + (y * y + 1.);                                             /* :104, cv::MatExpr's order (see ncache_moment) */
         const double ni = 1. / n_sq;
         const size_t i = (size_t)v * W + u;
         out[0 * N + i] = (float)x;                                                            /* :128-132 */
@@ -1166,7 +1167,13 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
         if (ordered) {
             /* a record is 32 bytes, 32-byte aligned: two 16-byte agent-scope (sc1) accesses each way -- narrower
              * write-through stores cost one fabric write each (3 x 8 B measured 2x slower).  hipcc does not
-             * count asm memory operations: the wait statement below names every destination register. */
+             * count asm memory operations: the wait statement below names every destination register.
+             * FRAGILE (found in round 6, tools/experiments/k_fuse_flush_compact_r06.patch): because each load is issued under an
+             * `if`, its destination is merged with the zero it holds otherwise, and in a restructured flush the compiler placed
+             * that merge (v_mov copies of the destination) BETWEEN the load and the wait -- reading registers with a load in
+             * flight (memory fault on dense tiles).  This form compiles to loads followed by the wait with nothing in between
+             * (checked in the ISA: `global_load_dwordx4 ... sc1` x 2 NE, `s_waitcnt vmcnt(0)`); anyone who moves this code
+             * should look at the ISA again or issue loads and wait as ONE asm statement, as that patch does. */
             gsdf_u32x4 ra[NE], rb[NE];
             /* (the 2560-entry table with the normals role is at the register limit: its five entries per lane stay unpaired) */
             constexpr bool PAIRED = FUSE_PAIRED_IO && !(NE > 4 && NEXT_NORMALS);

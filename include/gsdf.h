@@ -141,6 +141,16 @@ int gsdf_set_pose(gsdf_ctx* c, const float pose7[7]);
 int gsdf_get_pose(gsdf_ctx* c, float pose7[7]);          /* synchronises */
 int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9],
                             int num_iterations, float conv_threshold, float damping);
+/* Optional, time only: names the frame the NEXT gsdf_track_and_fuse_dev will be called with, before the call for the CURRENT
+ * frame.  The current frame's fusion launch then computes NormalEstimator::compute of that next frame in its tail (its last
+ * workgroups: the fusion leaves a third of the chip's workgroup slots idle there, and they do not look at the convergence
+ * gate, so they also run when the current frame is not fused), and the next frame's tracker launches carry no normals tiles.
+ * The normals depend on the depth image alone (MapGradPixelSdf.cpp:60), so results do not: same poses, same map
+ * (tests/test_gpu_parity.py::test_next_depth_hint_is_invisible_except_in_time).  Contract: next_depth_dev already holds the
+ * next frame when the CURRENT frame's gsdf_track_and_fuse_dev is called, and stays unchanged until the next frame's call; a copy
+ * into it through gsdf_dev_upload* in between withdraws the hint, as does any other frame entry; a hint that does not match the
+ * next call's depth_dev is ignored.  One hint per frame; NULL withdraws it.  No device work, never an error for a mismatch. */
+int gsdf_hint_next_depth_dev(gsdf_ctx* c, const float* next_depth_dev);
 /* log rows = float[10]: pose7, converged, passes, n_hit (of the last pass) */
 int gsdf_read_frame_log(gsdf_ctx* c, float* rows10, int64_t max_rows, int64_t* n_rows);
 
@@ -167,7 +177,13 @@ int gsdf_export_vis(gsdf_ctx* c, int32_t* keys, uint32_t* words, int words_per_v
 /* PhotoBA -- class PhotometricOptimizer (ps_optimizer/PhotometricOptimizer.h:68-186, .cpp), coarse photometric
  * bundle adjustment of keyframe poses and voxel distances on the fused map.  Needs gsdf_enable_vis.
  * images: float32 BGR in [0,1], n x H x W x 3 (setImages, cv::Mat CV_32FC3); poses16: n row-major 4x4
- * camera->world (setPoses); frame_idx: integrated-frame index of each keyframe (setKeyframes), n <= 64.
+ * camera->world (setPoses); frame_idx: integrated-frame index of each keyframe (setKeyframes).
+ * LIMIT: 1 <= n <= 64 keyframes per set (GSDF_ERR_INVALID beyond).  The reference's frame_idx_ / poses_ / images_ are
+ * unbounded std::vectors (PhotometricOptimizer.h:68-186); here the pose sweep keeps one visibility bit per keyframe in a 64-bit
+ * word per voxel and its per-wave LDS accumulators are sized by n.  BASELINE configs[4] (50 keyframes) fits; a larger keyframe
+ * set has to be optimised in windows of <= 64 keyframes (the energy is a sum over voxels of terms that couple only the keyframes
+ * that see the voxel, so windows of neighbouring keyframes are the usual bundle-adjustment practice -- but it is NOT what the
+ * reference computes for n > 64, and no such windowing is done inside the library).
  * gsdf_ba_energy = getEnergy (:273-321), gsdf_ba_solve_pose = solvePose (:499-590), gsdf_ba_solve_dist =
  * solveDist (:326-388), gsdf_ba_optimize = optimize (:611-662): energies receives E0 and E after every pose
  * and distance step (<= 2*max_it+1 values), *converged = relative change < 5e-4. */

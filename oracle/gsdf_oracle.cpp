@@ -185,6 +185,7 @@ struct gsdfo {
     /* summation order of the box filters (see box_sum): the cached planes follow OpenCV's running sums, the per-frame
      * filters sum freshly (measured to give the same floats); the other settings exist for measuring the difference */
     int box_mode_cache = 1, box_mode_frame = 0;
+    int nsq_order = 2;           /* NormalEstimator.h:104 `1. + x0_sq + y0_sq` through cv::MatExpr: see gsdfo_set_nsq_order */
 
     /* Sdf::truncate -- Sdf.h:72-74 */
     float truncate(float sdf) const { return std::max(-T_, std::min(T_, sdf)); }
@@ -223,6 +224,18 @@ gsdfo* gsdfo_create(float voxel_size, float T) {
 void gsdfo_destroy(gsdfo* o) { delete o; }
 void gsdfo_set_zrange(gsdfo* o, float zmin, float zmax) { o->z_min_ = zmin; o->z_max_ = zmax; }
 void gsdfo_set_threads(gsdfo* o, int threads) { o->threads = threads > 0 ? threads : 1; }
+/* NormalEstimator.h:104 `n_sq = 1. + x0_sq + y0_sq` is a cv::MatExpr: OpenCV folds `(1. + A) + B` into ONE
+ * addWeighted(A, 1, B, 1, gamma = 1), whose scalar loop evaluates (A*1 + B*1) + gamma and whose SIMD loop (4.x, CV_SIMD_64F)
+ * fma(A, 1, fma(B, 1, gamma)) -- three candidate orders of two double additions, decided inside an absent, unpinned library:
+ *   0 (1 + x^2) + y^2   what the source line would mean for plain doubles; NOT what a lazy MatExpr evaluates
+ *   1 (x^2 + y^2) + 1   addWeighted, scalar loop (OpenCV <= 4.1, builds without CV_SIMD_64F, the last N % lanes elements)
+ *   2 x^2 + (y^2 + 1)   addWeighted, SIMD loop (OpenCV 4.2+: op_add_weighted<double>, v_fma(a, alpha, v_fma(b, beta, gamma));
+ *                       multiplying by 1 is exact, so a fused and an unfused v_fma give the same doubles) -- the DEFINITION
+ *                       (round 6; the reference's README asks for OpenCV 4 and its Docker image follows a current 4.x), also
+ *                       k_ncache_rows / k_ncache_cols on the GPU.  The choice decides last bits of Q = M^-1: 18 % of its floats,
+ *                       normals up to 1e-2, a few gate flips per frame (tests/test_oracle_known_answers.py measures all three).
+ * The vector loop's scalar tail (N % lanes elements in order 1) is not modelled: N is a multiple of 4 in every BASELINE config. */
+void gsdfo_set_nsq_order(gsdfo* o, int order) { o->nsq_order = order >= 0 && order <= 2 ? order : 2; }
 void gsdfo_set_box_mode(gsdfo* o, int cache_mode, int frame_mode) { o->box_mode_cache = cache_mode == 1; o->box_mode_frame = frame_mode == 1; }
 
 /* NormalEstimator::cache -- NormalEstimator.h:81-154 (all in double, then cast to float) */
@@ -242,7 +255,8 @@ int gsdfo_normals_init(gsdfo* o, int W, int H, const float K[9], int win) {
             const double x = fx_inv * ((double)u - cx);      /* :94,98 */
             const double y = fy_inv * ((double)v - cy);      /* :96,100 */
             const double x_sq = x * x, y_sq = y * y, xy = x * y;
-            const double n_sq = 1. + x_sq + y_sq;            /* :104 */
+            const double n_sq = o->nsq_order == 1 ? (x_sq + y_sq) + 1. : o->nsq_order == 2 ? x_sq + (y_sq + 1.)
+                                                                         : 1. + x_sq + y_sq;            /* :104 (gsdfo_set_nsq_order) */
             const double ni = 1. / n_sq;                     /* :105 */
             x0[i] = x; y0[i] = y; ninv[i] = ni;
             x0n[i] = x * ni; y0n[i] = y * ni;                /* :106-107 */

@@ -44,6 +44,10 @@ void   gsdfo_set_threads(gsdfo* o, int threads);
  * generic FilterEngine path), separately for the cached planes (default 1) and the per-frame filters (default 0, same
  * floats as 1 there).  For measuring the differences; takes effect at the next gsdfo_normals_init / _compute. */
 void   gsdfo_set_box_mode(gsdfo* o, int cache_mode, int frame_mode);
+/* order of the two double additions of NormalEstimator.h:104 (cv::MatExpr -> one addWeighted): 2 = OpenCV 4's SIMD loop,
+ * x^2 + (y^2 + 1) (the definition); 1 = its scalar loop, (x^2 + y^2) + 1; 0 = (1 + x^2) + y^2, the line read as plain doubles.
+ * 0 / 1 exist to measure what the choice changes.  Before gsdfo_normals_init. */
+void   gsdfo_set_nsq_order(gsdfo* o, int order);
 
 /* cv::NormalEstimator<float>(W, H, K, Size(win,win)) -> cache()  -- NormalEstimator.h:81-165 */
 int    gsdfo_normals_init(gsdfo* o, int W, int H, const float K[9], int win);

