@@ -165,8 +165,9 @@ def track_fuse(g, dev, i, last):
     next frame's tracker passes -- time only, same poses and map (tests/test_gpu_parity.py::test_next_depth_hint_is_invisible_except_in_time).
     `last`: the last frame index of the loop (no hint beyond it)."""
     if NEXT_HINT and i < last:
-        g.hint_next_depth(dev[i + 1])
-    g.track_and_fuse_dev(dev[i])
+        g.track_and_fuse_ahead_dev(dev[i], dev[i + 1])          # gsdf_hint_next_depth_dev + gsdf_track_and_fuse_dev in one call
+    else:
+        g.track_and_fuse_dev(dev[i])
 
 
 def quat_to_R(q):

@@ -112,6 +112,7 @@ def load(path=None):
         "gsdf_get_pose": (C.c_int, [vp, fp]),
         "gsdf_track_and_fuse_dev": (C.c_int, [vp, vp, fp, C.c_int, C.c_float, C.c_float]),
         "gsdf_hint_next_depth_dev": (C.c_int, [vp, vp]),
+        "gsdf_track_and_fuse_ahead_dev": (C.c_int, [vp, vp, vp, fp, C.c_int, C.c_float, C.c_float]),
         "gsdf_read_frame_log": (C.c_int, [vp, fp, C.c_int64, i64p]),
         "gsdf_sync": (C.c_int, [vp]),
         "gsdf_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
@@ -183,7 +184,7 @@ def load(path=None):
 ABI_SYMBOLS = [
     "gsdf_last_error", "gsdf_version", "gsdf_create", "gsdf_destroy", "gsdf_reset", "gsdf_set_zrange",
     "gsdf_normals_init", "gsdf_normals_cache", "gsdf_normals_compute", "gsdf_update", "gsdf_update_dev",
-    "gsdf_track", "gsdf_track_sampled", "gsdf_hint_next_depth_dev", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
+    "gsdf_track", "gsdf_track_sampled", "gsdf_hint_next_depth_dev", "gsdf_track_and_fuse_ahead_dev", "gsdf_set_pose", "gsdf_get_pose", "gsdf_track_and_fuse_dev", "gsdf_read_frame_log",
     "gsdf_sync", "gsdf_get_stats", "gsdf_count", "gsdf_export", "gsdf_enable_vis", "gsdf_export_vis",
     "gsdf_ba_setup", "gsdf_ba_set_loss", "gsdf_ba_energy", "gsdf_ba_solve_pose", "gsdf_ba_solve_dist", "gsdf_ba_optimize", "gsdf_ba_get_poses", "gsdf_ba_counters", "gsdf_grow", "gsdf_set_auto_grow", "gsdf_capacity", "gsdf_merge_from", "gsdf_create_shards", "gsdf_merge_prepare",
     "gsdf_merge_raw", "gsdf_export_raw_dev",
@@ -371,6 +372,11 @@ class GradSdf:
     def track_and_fuse_dev(self, depth_dev, iters=25, conv=1e-3, damping=1.0):
         self._chk(self.L.gsdf_track_and_fuse_dev(self.h, depth_dev, _fp(self.K), int(iters), np.float32(conv),
                                                  np.float32(damping)))
+
+    def track_and_fuse_ahead_dev(self, depth_dev, next_depth_dev, iters=25, conv=1e-3, damping=1.0):
+        """hint_next_depth(next_depth_dev) + track_and_fuse_dev(depth_dev) as ONE call (next_depth_dev may be None)"""
+        self._chk(self.L.gsdf_track_and_fuse_ahead_dev(self.h, depth_dev, next_depth_dev, _fp(self.K), int(iters), np.float32(conv),
+                                                       np.float32(damping)))
 
     def hint_next_depth(self, depth_dev):
         """the frame the NEXT track_and_fuse_dev will get (call before the current frame's): its normals are then computed in the

@@ -188,7 +188,7 @@ static uint32_t* stats_of(const gsdf_ctx* c, const float* nrm) {
 /* one k_fuse launch: depth + its normal planes `nrm` (3 x N floats) -> the map.  next_depth (nullable): the launch's extra
  * workgroups compute the normals of that frame into next_nrm */
 int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsdf_pose_arg& pose, int use_dev_pose,
-                const float* next_depth, float* next_nrm) {
+                const float* next_depth, float* next_nrm, const gsdf_fuse_head* head = nullptr, unsigned int next_token = 0u) {
     const size_t N = (size_t)c->W * c->H;
     c->occ_dirty = true;                                      /* new blocks: the raycaster's filters are rebuilt when it next runs */
     {
@@ -206,9 +206,9 @@ int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsd
                          c->progress && c->progress[2] > 8192u ? 1 : 0, c->progress ? c->progress_dev + 2 : nullptr,
                          /* many tiles did not fit the small LDS table lately (far geometry): the kernel with the larger one.
                           * Like the note above a hint that lags by a launch or two, never a condition for correctness. */
-                         fuse_far_table(c),
+                         fuse_far_table(c), head,
                          next_depth, next_nrm, next_nrm ? next_nrm + N : nullptr, next_nrm ? next_nrm + 2 * N : nullptr, c->win,
-                         stats_of(c, nrm), next_nrm ? stats_of(c, next_nrm) : nullptr);
+                         stats_of(c, nrm), next_nrm ? stats_of(c, next_nrm) : nullptr, next_token);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
@@ -217,7 +217,7 @@ int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsd
 
 /* normals (unless the frame's were computed beside its first tracker pass: normals_done) + fusion, in stream order */
 int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done, int set,
-                 const float* next_depth) {
+                 const float* next_depth, const gsdf_fuse_head* head, int next_set, unsigned int next_token) {
     const size_t N = (size_t)c->W * c->H;
     /* tracked frames: set 2, filled beside the first tracker passes -- or the set the PREVIOUS frame's fusion filled in its
      * tail (gsdf_hint_next_depth_dev) */
@@ -230,15 +230,10 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
         gsdf_launch_normals(c->stream, c->geom(), c->win, c->ncache(), depth_dev, nrm, nrm + N, nrm + 2 * N, nullptr, nullptr, stats_of(c, nrm));
         next_depth = nullptr;
     }
-    float* next_nrm = nullptr;
-    if (next_depth) {
-        /* gsdf_hint_next_depth_dev: this launch's last workgroups compute NormalEstimator::compute of the NEXT frame (they do
-         * not look at the gate), into whichever of sets 0 / 1 this fusion does not read */
-        const int next_set = set == 0 ? 1 : 0;
-        next_nrm = c->normals + (size_t)next_set * 3 * N;
-        c->nrm_ready_depth = next_depth; c->nrm_ready_set = next_set;
-    }
-    return launch_fuse(c, depth_dev, nrm, pose, use_dev_pose, next_depth, next_nrm);
+    /* gsdf_hint_next_depth_dev: the launch's last workgroups compute NormalEstimator::compute of the NEXT frame into set
+     * next_set -- if the launch's gate is open -- and leave next_token in st->nrm_token */
+    float* next_nrm = next_depth ? c->normals + (size_t)next_set * 3 * N : nullptr;
+    return launch_fuse(c, depth_dev, nrm, pose, use_dev_pose, next_depth, next_nrm, head, next_token);
 }
 
 /* RigidPointOptimizer::optimize_sampled as a chain of per-pass launches.  The convergence test, the pose update
@@ -253,7 +248,7 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
  * previous one.  Correctness never depends on what the host sees: a late or lost observation only costs empty
  * launches. */
 int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done, int set = 2,
-                 const float* next_depth = nullptr);
+                 const float* next_depth = nullptr, const gsdf_fuse_head* head = nullptr, int next_set = 0, unsigned int next_token = 0u);
 
 /* 1 = optimize() ended, 0 = the head of launch `last` ran and it has not ended, -1 = gave up waiting */
 int follow_progress(gsdf_ctx* c, unsigned int serial, int last) {
@@ -287,25 +282,51 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     gsdf_pose_arg unused;
     std::memset(&unused, 0, sizeof(unused));
     /* gsdf_hint_next_depth_dev: (1) this frame's normals may already lie in set 0 / 1 -- the previous frame's fusion computed them
-     * in its tail -- and then no normals tiles ride in this frame's tracker launches; (2) this frame's fusion (the first one
-     * queued) computes the hinted NEXT frame's.  Not in event-timed replays (gsdf_profile): there the fusion launch is the plain
-     * one, so that what bench.py quotes as k_fuse's duration is the fusion work alone. */
+     * in its tail IF IT RAN (a fusion whose gate stays closed does not: its tail is not idle, the tiles would run in the open);
+     * this frame's riders are queued as ever and leave at once when they find the frame's token in st->nrm_token; (2) every
+     * fusion launch of this frame carries the normals role for the hinted NEXT frame (at most one of them passes the gate).
+     * Not in event-timed replays (gsdf_profile): there the fusion launch is the plain one, so that what bench.py quotes as
+     * k_fuse's duration is the fusion work alone. */
     const bool pre = fuse_after && !c->profiling && c->nrm_ready_depth == depth_dev && c->nrm_ready_set >= 0 && iters > 0;
     const int fuse_set = pre ? c->nrm_ready_set : 2;
-    const float* hint = fuse_after && !c->profiling && iters > 0 ? c->hint_next : nullptr;
+    const unsigned int ride_token = pre ? c->nrm_ready_token : 0u;
+    /* Both round-6 steps -- the next frame's normals in the fusion's tail, the fusion launch standing in for the first batch's last
+     * tracker launch -- pay where optimize() ends within the first batch and the fusion RUNS behind it.  Frames that converge late or
+     * never come in stretches (the reference's tracker cycles on them), and there the extra workgroups only look at a closed gate
+     * and the stand-in's head is followed by a head-less launch anyway (measured: -1 ... -2 % on the bench's default window): the
+     * host takes the old route while the last tracked frame whose end it KNOWS needed more than the first batch (a hint for the
+     * hint: the progress word of that frame's heads, read without waiting -- in such a stretch the host has just waited for it). */
+    if (fuse_after && c->progress && c->prev_track_serial) {
+        const unsigned int w = c->progress[0];
+        if ((w >> 16) == c->prev_track_serial && (w & 0x8000u)) c->prev_slow = (int)(w & 0x7FFFu) > c->prev_first_last;
+    }
+    /* ... and not while the fusion uses the larger LDS table (far geometry): that instantiation with the normals role is at the
+     * register limit and moves its records unpaired, with the head it spills -- both cost more than the step saves */
+    const bool new_route = fuse_after && !c->profiling && iters > 0 && !c->prev_slow && !fuse_far_table(c);
+    const float* hint = new_route ? c->hint_next : nullptr;
     c->nrm_ready_depth = nullptr;        /* consumed (or not ours) */
     c->hint_next = nullptr;
     if (hint == depth_dev) hint = nullptr;
+    int next_set = 0;
+    unsigned int next_token = 0u;
+    if (hint) {
+        next_set = fuse_set == 0 ? 1 : 0;                     /* whichever of sets 0 / 1 this frame's fusion does not read */
+        if (++c->nrm_token_ctr == 0u) c->nrm_token_ctr = 1u;
+        next_token = c->nrm_token_ctr;
+        c->nrm_ready_depth = hint; c->nrm_ready_set = next_set; c->nrm_ready_token = next_token;
+    }
     if (iters <= 0) {
         gsdf_launch_track_none(c->stream, c->st);
         return fuse_after ? enqueue_fuse(c, depth_dev, unused, 1, false) : GSDF_OK;
     }
     if (iters > 0x7FFF) return fail(GSDF_ERR_INVALID, "num_iterations must be <= 32767");
     gsdf_normals_job nj;
-    if (fuse_after && !pre) {            /* the frame's normals ride along with its first passes */
+    std::memset(&nj, 0, sizeof(nj));
+    if (fuse_after) {                    /* the frame's normals ride along with its first passes (unless computed ahead: ride_token) */
         const size_t N = (size_t)c->W * c->H;
         nj.nc = c->ncache();
-        nj.nx = c->normals + 6 * N; nj.ny = c->normals + 7 * N; nj.nz = c->normals + 8 * N;          /* set 2 */
+        nj.nx = c->normals + (size_t)(3 * fuse_set) * N; nj.ny = nj.nx + N; nj.nz = nj.nx + 2 * N;    /* set 2, or the hinted one */
+        nj.token = ride_token;
         nj.deferred_count = c->deferred_count;
         nj.stats = stats_of(c, nj.nx);
         nj.r = c->win / 2; nj.ntx = 0;
@@ -319,10 +340,15 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     if (c->track_serial == 0) c->track_serial = 1;
     tp.serial = c->track_serial;
     const bool adaptive = c->adaptive && c->progress;
+    if (fuse_after) {                                        /* (the last launch index of this frame's first batch) */
+        c->prev_track_serial = tp.serial;
+        c->prev_first_last = std::min(iters, (adaptive ? c->first_batch : iters + 1) - 1);
+    }
     tp.progress = adaptive ? c->progress_dev : nullptr;
     tp.debug = c->debug >> 16;
     tp.n_track_blocks = c->track_blocks;
     tp.sampling = sampling;
+    tp.head_done = 0;
     if (sampling == 1 && c->persist && c->track_rows && c->track_blocks <= 2 * GSDF_TRACK_MAXBLK) {
         /* the whole optimize() as one launch; the frame's fusion, gated on the device by done && converged, right behind it */
         tp.pass_index = 0;
@@ -331,10 +357,10 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
         {
             prof_scope ps(c, 2);
             gsdf_launch_track_all(c->stream, g, depth_dev, c->tab, c->st, c->track_rows, c->track_abort, c->track_blocks, tp,
-                                  fuse_after && !pre ? &nj : nullptr);
+                                  fuse_after ? &nj : nullptr);
         }
         if (fuse_after) {
-            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint);   /* main_scan_3d.cpp:261-265 */
+            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint, nullptr, next_set, next_token);   /* main_scan_3d.cpp:261-265 */
             if (rc) return rc;
         }
         hipError_t e = hipGetLastError();
@@ -343,10 +369,21 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     }
     int k = 0, batch_no = 0;
     int batch = adaptive ? c->first_batch : iters + 1;
+    /* The frame's first fusion launch stands in for the LAST tracker launch of the first batch (k_fuse<.., HEAD>): that launch's
+     * head -- for the usual frame the closing one of optimize() -- runs in workgroup 0 of the fusion launch, which every other
+     * workgroup of it follows; a launch and a kernel boundary less per frame.  If optimize() has not ended with that head the
+     * next batch starts with a tracker launch of the same index that skips its head (head_done).  Not in event-timed replays:
+     * what bench.py quotes as k_fuse's duration is the fusion work alone. */
+    const bool fuse_head = new_route && adaptive && c->fuse_head;
+    bool headless = false;                                   /* the next launch's head was performed by a fusion launch */
     while (k <= iters) {
         const int last = std::min(iters, k + batch - 1);
+        const bool stand_in = fuse_head && batch_no == 0 && last >= 1;
         for (; k <= last; ++k) {
+            if (stand_in && k == last) continue;             /* its head is the fusion launch's */
             tp.pass_index = k;
+            tp.head_done = headless ? 1 : 0;
+            headless = false;
             tp.rot = c->track_rot;
             c->track_rot = (c->track_rot + 1u) % 3u;          /* kept in [0, 3): no discontinuity at wrap-around */
             /* The frame's normals tiles ride in its first launches: nrm_split per cent in launch 0, nrm_split2 in launch 1, the rest
@@ -355,10 +392,12 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
              * tiles; launch 0 has no head and ends early, so it takes the smallest one.  Tile 0 (it resets the frame's deferred list)
              * stays in launch 0. */
             const gsdf_normals_job* job = nullptr;
-            if (fuse_after && !pre && k <= 2) {
+            if (fuse_after && k <= 2) {
                 const int tiles = gsdf_normals_tiles(c->W, c->H);
-                const bool three = iters >= 2 && batch >= 3;
-                const int b1 = std::max(1, tiles * c->nrm_split / 100);
+                /* tracker launches of the first batch (the fusion launch may stand in for its last one: no riders there) */
+                const int nl = batch_no == 0 ? (stand_in ? last : last + 1) : 3;
+                const bool three = iters >= 2 && batch >= 3 && nl >= 3;
+                const int b1 = nl >= 2 ? std::max(1, tiles * c->nrm_split / 100) : tiles;
                 const int b2 = three ? std::min(tiles, std::max(b1, tiles * (c->nrm_split + c->nrm_split2) / 100)) : tiles;
                 const int lo = k == 0 ? 0 : k == 1 ? b1 : b2, hi = k == 0 ? b1 : k == 1 ? b2 : tiles;
                 if (hi > lo && (k < 2 || three)) { nj.tile_first = lo; nj.tile_count = hi - lo; job = &nj; }
@@ -372,9 +411,16 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
          * once the progress word says that optimize() has ended (the frame that converges late pays the host's look). */
         bool fuse_queued = false;
         if (fuse_after && (batch_no == 0 || last == iters || !c->lazy_fuse)) {
-            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint);   /* main_scan_3d.cpp:261-265 */
+            gsdf_fuse_head hd;
+            std::memset(&hd, 0, sizeof(hd));
+            if (stand_in) {
+                hd.k = last;
+                hd.rot_prev = (c->track_rot + 2u) % 3u;      /* the buffer the last launch issued (pass last - 1) accumulated into */
+                hd.conv_sq = tp.conv_sq; hd.damping = tp.damping; hd.max_passes = tp.max_passes;
+                hd.serial = tp.serial; hd.progress = tp.progress; hd.rows = c->partials; hd.debug = tp.debug;
+            }
+            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint, stand_in ? &hd : nullptr, next_set, next_token);   /* main_scan_3d.cpp:261-265 */
             if (rc) return rc;
-            hint = nullptr;                                  /* the first fusion launch of the frame carries the next frame's normals */
             fuse_queued = true;
         }
         ++batch_no;
@@ -389,12 +435,12 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
         }
         if (ended) {
             if (fuse_after && !fuse_queued) {
-                const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint);
+                const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint, nullptr, next_set, next_token);
                 if (rc) return rc;
-                hint = nullptr;
             }
             break;
         }
+        if (stand_in) { k = last; headless = true; }         /* launch `last` comes now, without the head the fusion launch performed */
         batch = c->next_batch;
     }
     hipError_t e = hipGetLastError();
@@ -596,6 +642,7 @@ static int create_impl(gsdf_ctx** out, float voxel_size, float trunc_dist, int c
         const char* env = getenv("GSDF_ADAPTIVE");
         if (env) c->adaptive = atoi(env);
         if ((env = getenv("GSDF_FIRST_BATCH")) && atoi(env) >= 2) c->first_batch = atoi(env);
+        if ((env = getenv("GSDF_FUSE_HEAD"))) c->fuse_head = atoi(env) != 0;   /* 0: the first batch's last launch is a tracker launch again */
         if ((env = getenv("GSDF_NRM_SPLIT"))) {            /* experiments: "a" or "a,b" = per cent of the normals tiles in launch 0 (and 1) */
             int a = -1, b = -1;
             const int n = sscanf(env, "%d,%d", &a, &b);
@@ -646,6 +693,7 @@ int gsdf_reset(gsdf_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     c->pending.valid = false;                              /* a fusion that was never launched is dropped with the map */
     c->hint_next = nullptr; c->nrm_ready_depth = nullptr;  /* (gsdf_hint_next_depth_dev: a new scan starts without them) */
+    c->prev_track_serial = 0; c->prev_slow = false;
     if (c->deferred_count) HIP_TRY(hipMemsetAsync(c->deferred_count, 0, sizeof(unsigned int), c->stream));
     gsdf_launch_table_clear(c->stream, c->tab, c->n_slots);
     if (c->vis) HIP_TRY(hipMemsetAsync(c->vis, 0, c->n_slots * (size_t)c->vis_words * sizeof(uint32_t), c->stream));
@@ -898,6 +946,13 @@ int gsdf_hint_next_depth_dev(gsdf_ctx* c, const float* next_depth_dev) {
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     c->hint_next = next_depth_dev;                       /* nullptr withdraws it; no device work, no flush */
     return GSDF_OK;
+}
+
+int gsdf_track_and_fuse_ahead_dev(gsdf_ctx* c, const float* depth_dev, const float* next_depth_dev, const float K[9],
+                                  int num_iterations, float conv_threshold, float damping) {
+    if (!c) return fail(GSDF_ERR_INVALID, "null context");
+    c->hint_next = next_depth_dev;
+    return gsdf_track_and_fuse_dev(c, depth_dev, K, num_iterations, conv_threshold, damping);
 }
 
 int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9], int num_iterations,

@@ -84,9 +84,12 @@ struct gsdf_ctx {
     long long rc_iters[2] = { 0, 0 };              /* loop iterations of the workgroups' wave 0 as of the last gsdf_raycast_counters */
     /* gsdf_hint_next_depth_dev: the frame the NEXT gsdf_track_and_fuse_dev will be called with (set by the caller, consumed by the
      * next frame entry), and the frame whose normals a fusion launch has already computed into set nrm_ready_set (0 / 1) */
+    bool fuse_head = true;                         /* the frame's first fusion launch performs the head of the first batch's last tracker launch (GSDF_FUSE_HEAD) */
     const float* hint_next = nullptr;
     const float* nrm_ready_depth = nullptr;
     int nrm_ready_set = -1;
+    unsigned int prev_track_serial = 0; int prev_first_last = 0; bool prev_slow = false;   /* the last tracked frame: did it need more than its first batch (as far as the host knows)? */
+    unsigned int nrm_ready_token = 0, nrm_token_ctr = 0;   /* what that fusion launch leaves in st->nrm_token when its gate was open */
     float* depth_sampled = nullptr;                /* the compacted pixels of gsdf_track_sampled (sampling > 1), lazily allocated */
     void* scratch = nullptr;                       /* device scratch of gsdf_query / gsdf_get_voxels for small batches (GSDF_SCRATCH_BYTES) */
     bool occ_dirty = false;                        /* blocks may have been inserted since the raycaster's filters (gsdf_table::occ) were built */

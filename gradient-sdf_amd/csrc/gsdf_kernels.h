@@ -56,6 +56,12 @@ struct gsdf_dev_state {
     long long frame_cur;          /* counter_ snapshot for the running update (k_normals -> k_fuse) */
     gsdf_trk_buf trk[2];
     unsigned long long dbg[24];   /* experiment counters (gsdf_debug_flags & 128), see tools/go_count.py */
+    /* The closing head of optimize() when a fusion launch performs it (k_fuse<.., HEAD>): three 16-byte chunks that workgroup 0
+     * writes and every other workgroup polls, each carrying the launch's tag, so a chunk with the right tag holds the right
+     * values and no ordering between data and flag is needed: {tag, done | converged << 1, tx, ty} {tag, tz, qx, qy}
+     * {tag, qz, qw, passes} */
+    unsigned int fh[12] __attribute__((aligned(16)));
+    unsigned int nrm_token;       /* gsdf_hint_next_depth_dev: token of the frame whose normals a fusion launch computed in its tail */
 };
 
 struct gsdf_frame_geom {
@@ -89,6 +95,18 @@ void gsdf_launch_normals(hipStream_t s, const gsdf_frame_geom& g, int win, const
                          unsigned int* deferred_count /* nullable: cleared for the k_fuse that follows */,
                          gsdf_dev_state* st_rw /* nullable: snapshot of the frame counter for k_fuse */,
                          uint32_t* tile_stats /* nullable: [gsdf_fuse_grid_blocks][4], the frame's tile statistics for its k_fuse */);
+/* The head of tracker launch k performed by a fusion launch instead (the frame's first gated fusion stands in for the last launch
+ * of the first batch): k = 0 none */
+struct gsdf_fuse_head {
+    int k;                        /* the tracker launch whose head this is: finishes pass k - 1 */
+    unsigned int rot_prev;        /* which of the three sum buffers pass k - 1 accumulated into */
+    float conv_sq, damping;
+    int max_passes;
+    unsigned int serial;
+    unsigned int* progress;       /* as gsdf_track_params::progress */
+    const double* rows;           /* the partial-sum buffers (3 x GSDF_TRACK_ROWSET) */
+    int debug;
+};
 /* use_dev_pose: take R,t from st->R / st->pose7 and skip the launch unless st->converged */
 void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
                       const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
@@ -105,10 +123,12 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       int resolve_follows /* also queue k_fuse_resolve (long deferred lists) */,
                       unsigned int* host_note /* nullable, 2 pinned host words: length of the deferred list, tiles too big for the small LDS table */,
                       int far_table /* use the kernel with the larger LDS table */,
+                      const gsdf_fuse_head* head /* nullable: also perform the closing head of optimize() (use_dev_pose only) */,
                       const float* next_depth /* nullable: the launch also computes the normals of this (the next) frame ... */,
                       float* next_nx, float* next_ny, float* next_nz /* ... into these planes */, int win,
                       const uint32_t* tile_stats /* this frame's tile statistics (written with its normals) */,
-                      uint32_t* next_tile_stats /* the next frame's, written by the launch's normals workgroups */);
+                      uint32_t* next_tile_stats /* the next frame's, written by the launch's normals workgroups */,
+                      unsigned int next_token /* tracked frames: left in st->nrm_token by the normals role when it ran */);
 int  gsdf_fuse_grid_blocks(int W, int H);
 void gsdf_fuse_tile_order(int W, int H, uint32_t* order_host /* [gsdf_fuse_grid_blocks] */);
 /* per-launch parameters of one Gauss-Newton pass (RigidOptimizer.h:57-62) */
@@ -122,6 +142,8 @@ struct gsdf_track_params {
     int n_track_blocks;           /* workgroups of the pass itself (set by the launcher); further ones compute normals tiles */
     int sampling;                 /* optimize_sampled's stride (RigidPointOptimizer.h:65); > 1: the geometry is the sampled grid, the
                                      depth image its compaction (gsdf_launch_subsample), no normals riders */
+    int head_done;                /* the head of this launch (finish pass pass_index - 1) was performed by the fusion launch queued in
+                                     front of it (gsdf_fuse_head): start from st->trk[pass_index & 1] */
 };
 /* NormalEstimator::compute of the frame being tracked, run by extra workgroups of its first pass (Scan3D loop) */
 struct gsdf_normals_job {
@@ -131,6 +153,7 @@ struct gsdf_normals_job {
     uint32_t* stats;              /* the frame's tile statistics for its k_fuse ([tiles of 16 x 16 pixels][4], see gsdf_kernels.hip) */
     int r, ntx;                   /* window radius; tiles per image row (set by the launcher) */
     int tile_first, tile_count;   /* the tiles this launch computes: [tile_first, tile_first + tile_count); count 0 = all the rest */
+    unsigned int token;           /* != 0: leave at once if st->nrm_token carries it (the frame's normals were computed ahead) */
 };
 void gsdf_launch_subsample(hipStream_t s, const float* depth, int W, int H, int sampling, float* out /* ceil(W/s) * ceil(H/s) */);
 int  gsdf_normals_tiles(int W, int H);       /* normals tiles of a frame (workgroups of k_normals / of the normals role) */

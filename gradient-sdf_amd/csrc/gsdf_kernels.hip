@@ -554,6 +554,8 @@ struct fuse_args {
     uint32_t* nrm_stats;                /* ... and its tile statistics (gsdf_tile_stats) */
     const uint32_t* tile_stats;         /* THIS frame's tile statistics, written with its normals */
     int nrm_r, nrm_ntx;                 /* window radius, normals tiles per image row */
+    gsdf_fuse_head hd;                  /* k_fuse<.., HEAD>: the closing head of optimize() this launch performs first (k = 0: none) */
+    unsigned int nrm_token;             /* tracked frames: what the normals role leaves in st->nrm_token when it ran (never 0) */
 };
 #define FUSE_RESOLVE_INLINE 8192u       /* deferred entries the last workgroup adds itself even when a resolve launch follows */
 
@@ -657,9 +659,110 @@ __device__ __forceinline__ void fuse_log_row(const fuse_args& a) {
     st->log_rows = r + 1;
 }
 
-/* NEXT_NORMALS: the instantiation whose launches carry the normals workgroups of the next frame (GT-pose runs).  The tracked
- * path uses the one without: the extra role costs the fusion code ~2 us per launch in register allocation (measured). */
-template <int LCAP, bool NEXT_NORMALS>
+/* (the tracker's head, defined with k_track_pass below) */
+__device__ __forceinline__ void trk_solve_update(const float* tot, float damping, float conv_sq, int passes, int max_passes,
+                                                 int no_solve, bool exact_solve, float pose[7], int* done, int* converged);
+
+/* k_fuse<.., HEAD>: the head of tracker launch a.hd.k (see k_fuse).  false: optimize() had ended before this launch, the state in
+ * a.st is final.  true: (pose, done, conv) are the head's result -- computed here by the `solver` wave (workgroup 0's first: it also
+ * publishes it), read from the tagged chunks it publishes by every other wave of the launch. */
+__device__ __forceinline__ bool fuse_head(const fuse_args& a, int tid, bool solver, float (&pose)[7], int& hdone, int& hconv) {
+    const gsdf_trk_buf& in = a.st->trk[(a.hd.k - 1) & 1];
+    if (in.done) return false;                                     /* optimize() ended in an earlier launch */
+    const int hlane = tid & 63;
+    int hpasses = 0;
+    bool have = false;
+    if (!solver) {
+        /* the three chunks, one per lane 0..2, until all carry this launch's tag (for workgroups of the later dispatch rounds
+         * they are there at the first look) */
+        const unsigned long long t0 = wall_clock64();
+        gsdf_u32x4 ch = { 0u, 0u, 0u, 0u };
+        for (;;) {
+            if (hlane < 3) {
+                const unsigned int* q = a.st->fh + 4 * hlane;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(ch) : "v"(q) : "memory");
+            }
+            if (__all(hlane >= 3 || ch.x == a.tag)) { have = true; break; }
+            if (wall_clock64() - t0 > 200000ull) break;              /* 2 ms at 100 MHz: do it yourself (never seen) */
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (have) {
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)ch.y, 0);
+            hdone = (int)(f & 1u); hconv = (int)((f >> 1) & 1u);
+            pose[0] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.z, 0));
+            pose[1] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.w, 0));
+            pose[2] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.y, 1));
+            pose[3] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.z, 1));
+            pose[4] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.w, 1));
+            pose[5] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.y, 2));
+            pose[6] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.z, 2));
+        }
+    }
+    if (!have) {
+        /* the head itself, as in k_track_pass: lane v < 29 adds the group sums of value v in increasing order, readlane hands the
+         * totals to every lane, the solve runs in every lane alike */
+        const double* acc_prev = a.hd.rows + (size_t)a.hd.rot_prev * GSDF_TRACK_ROWSET;
+        double gs = 0.0;
+        if (hlane < GSDF_TRACK_NSUM) {
+            double part[GSDF_TRACK_GROUPS];
+#pragma unroll
+            for (int grp = 0; grp < GSDF_TRACK_GROUPS; ++grp) part[grp] = acc_prev[grp * 32 + hlane];
+            gs = part[0];
+#pragma unroll
+            for (int grp = 1; grp < GSDF_TRACK_GROUPS; ++grp) gs += part[grp];
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose[i] = in.pose7[i];
+        hpasses = in.passes + 1;
+        const float totv = (float)gs;
+        float tot[GSDF_TRACK_NSUM];
+#pragma unroll
+        for (int i = 0; i < GSDF_TRACK_NSUM; ++i) tot[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(totv), i));
+        trk_solve_update(tot, a.hd.damping, a.hd.conv_sq, hpasses, a.hd.max_passes, GSDF_EXPERIMENT(a.hd.debug, 1),
+                         GSDF_EXPERIMENT(a.hd.debug, 4), pose, &hdone, &hconv);
+        if (solver && hlane == 0) {
+            /* published as k_track_pass's workgroup 0 publishes its head (see there) ... */
+            gsdf_dev_state* st = a.st;
+            gsdf_trk_buf& o = st->trk[a.hd.k & 1];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { o.pose7[i] = pose[i]; st->pose7[i] = pose[i]; }
+            o.done = hdone; o.converged = hconv; o.passes = hpasses;
+            if (hdone) st->trk[(a.hd.k - 1) & 1].done = 1;
+            gsdf_quat_to_R(pose + 3, st->R);
+            st->converged = hconv;
+            st->done = hdone;
+            st->passes = hpasses;
+            st->last_hits = tot[28];
+            st->n_hit += (unsigned long long)tot[28];
+            if (a.hd.progress)
+                __hip_atomic_store(&a.hd.progress[0], (a.hd.serial << 16) | (hdone ? 0x8000u : 0u) | (unsigned int)(hpasses & 0x7FFF),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            /* ... and for the other workgroups of THIS launch: the tagged chunks */
+            const gsdf_u32x4 c0 = { a.tag, (uint32_t)hdone | ((uint32_t)hconv << 1), __float_as_uint(pose[0]), __float_as_uint(pose[1]) };
+            const gsdf_u32x4 c1 = { a.tag, __float_as_uint(pose[2]), __float_as_uint(pose[3]), __float_as_uint(pose[4]) };
+            const gsdf_u32x4 c2 = { a.tag, __float_as_uint(pose[5]), __float_as_uint(pose[6]), (uint32_t)hpasses };
+            unsigned int* q = st->fh;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                         "global_store_dwordx4 %0, %3, off offset:32 sc1" :: "v"(q), "v"(c0), "v"(c1), "v"(c2) : "memory");
+            /* the plain stores above are read by the launch's LAST workgroup (frame log), possibly on another XCD */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+    }
+    return true;
+}
+
+/* NEXT_NORMALS: the instantiation whose launches carry the normals workgroups of the next frame (GT-pose runs, and tracked frames
+ * whose successor was named with gsdf_hint_next_depth_dev).
+ * HEAD (round 6): the frame's first gated fusion launch stands in for the LAST tracker launch of the first batch -- its head, which
+ * finishes pass hd.k - 1 (reduce the group sums, solve, stop test, pose update).  For the usual frame that head is the closing one
+ * of optimize(): a launch (~2 us) and a kernel boundary (1.4 us) less per frame.  Workgroup 0's first wave performs it -- the same
+ * arithmetic as k_track_pass's head, trk_solve_update -- and publishes the result as k_track_pass's workgroup 0 would (st->trk,
+ * st->pose7 / R / done / converged, the host's progress word) plus three tagged 16-byte chunks (gsdf_dev_state::fh); every other
+ * wave of the launch polls those chunks (agent scope; one look once they are there), so the solve runs once per launch and not
+ * once per workgroup.  Workgroup 0 is dispatched first and waits for nobody; the wait of the others is bounded, and a wave whose
+ * wait expires performs the head itself (bit-identical).  If optimize() has not ended with that head, every workgroup leaves,
+ * and the host's next batch starts with a tracker launch that skips its head (gsdf_track_params::head_done). */
+template <int LCAP, bool NEXT_NORMALS, bool HEAD>
 __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     __shared__ fuse_lds<LCAP> L;
     const int tid = threadIdx.x;
@@ -668,6 +771,19 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     if ((int)blockIdx.x >= a.n_tiles) {                       /* the next frame's normals, in the tail of this launch */
         static_assert(sizeof(nrm_lds) <= sizeof(fuse_lds<LCAP>), "the normals tile works in the fusion table's LDS");
         const int t = (int)blockIdx.x - a.n_tiles;
+        if (a.use_dev_pose) {
+            /* a tracked frame (gsdf_hint_next_depth_dev): only beside a fusion that RUNS -- there the tail is idle; a launch whose
+             * gate is closed would run these tiles alone, in the open (14-19 us, measured).  The next frame's tracker launches
+             * carry the tiles as riders as ever; they look at the token below and leave when the work is done. */
+            int gd = a.st->done, gc = a.st->converged;
+            if constexpr (HEAD) {
+                float pose[7];
+                int hd_ = 0, hc_ = 0;
+                if (fuse_head(a, tid, false, pose, hd_, hc_)) { gd = __builtin_amdgcn_readfirstlane(hd_); gc = __builtin_amdgcn_readfirstlane(hc_); }
+            }
+            if (!(gd && gc)) return;
+            if (t == 0 && tid == 0) a.st->nrm_token = a.nrm_token;
+        }
         normals_tile<FUSE_THREADS>(*reinterpret_cast<nrm_lds*>(&L), t % a.nrm_ntx, t / a.nrm_ntx, a.g.W, a.g.H, a.nrm_r, a.nc, a.nrm_depth, a.nrm_x,
                      a.nrm_y, a.nrm_z, gsdf_tile_stats{ a.nrm_stats, (a.g.W + 15) / 16, a.g.zmin, a.g.zmax });
         return;
@@ -679,13 +795,26 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     /* everything the prologue needs from memory is requested at once (one scalar round trip, not three in a row):
      * the gate, the device pose, the workgroup's tile */
     const gsdf_dev_state* st_in = a.st;
-    const int done = st_in->done, conv = st_in->converged;
+    int done = st_in->done, conv = st_in->converged;
     float R[9], t[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = st_in->R[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = st_in->pose7[i];
     const uint32_t tile_id = a.tile_order[blockIdx.x];
+    if constexpr (HEAD) {
+        float pose[7];
+        int hdone = 0, hconv = 0;
+        if (fuse_head(a, tid, blockIdx.x == 0 && tid < 64, pose, hdone, hconv)) {
+            done = __builtin_amdgcn_readfirstlane(hdone); conv = __builtin_amdgcn_readfirstlane(hconv);
+            float Rh[9];
+            gsdf_quat_to_R(pose + 3, Rh);                                /* st->R is computed the same way: identical bits */
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(Rh[i])));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) t[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pose[i])));
+        }
+    }
     if (a.use_dev_pose) {
         if (!(done && conv)) {
             if (done && blockIdx.x == 0 && tid == 0) fuse_log_row(a);
@@ -1417,8 +1546,9 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       gsdf_deferred* deferred, unsigned int* deferred_count, unsigned int deferred_cap,
                       unsigned int tag, unsigned int* tile_flags, const uint32_t* tile_order, float* log_rows,
                       long long max_rows, uint32_t* vis, int vis_words, int debug, unsigned int* ticket, int resolve_follows,
-                      unsigned int* host_note, int far_table, const float* next_depth, float* next_nx, float* next_ny, float* next_nz,
-                      int win, const uint32_t* tile_stats, uint32_t* next_tile_stats) {
+                      unsigned int* host_note, int far_table, const gsdf_fuse_head* head, const float* next_depth, float* next_nx,
+                      float* next_ny, float* next_nz, int win, const uint32_t* tile_stats, uint32_t* next_tile_stats,
+                      unsigned int next_token) {
     fuse_args a;
     a.tile_stats = tile_stats; a.nrm_stats = next_tile_stats;
     a.host_note = host_note;
@@ -1440,11 +1570,20 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
         gsdf_launch_normals(s, g, win, nc, next_depth, next_nx, next_ny, next_nz, nullptr, nullptr, next_tile_stats);
         extra = 0;
     }
-    if (extra) {
-        if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
-    } else if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, false>), dim3(n), dim3(FUSE_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, false>), dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(debug, 4096) ? 81920 : 0, s, a);   /* experiment: 1 workgroup per CU */
+    std::memset(&a.hd, 0, sizeof(a.hd));
+    a.nrm_token = next_token;
+    if (head && use_dev_pose && head->k > 0) {
+        a.hd = *head;
+        if (extra) {
+            if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, true, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
+            else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, true, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
+        } else if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, false, true>), dim3(n), dim3(FUSE_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, false, true>), dim3(n), dim3(FUSE_THREADS), 0, s, a);
+    } else if (extra) {
+        if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, true, false>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, true, false>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
+    } else if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, false, false>), dim3(n), dim3(FUSE_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, false, false>), dim3(n), dim3(FUSE_THREADS), GSDF_EXPERIMENT(debug, 4096) ? 81920 : 0, s, a);   /* experiment: 1 workgroup per CU */
     if (resolve_follows)
         hipLaunchKernelGGL(k_fuse_resolve, dim3(512), dim3(256), 0, s, deferred, deferred_count, deferred_cap, gate, st, ticket + 1);
 }
@@ -1790,6 +1929,9 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
      * dynamic LDS so that the later passes of the frame stay small. */
     if ((int)blockIdx.x >= tp.n_track_blocks) {
         extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+        /* (gsdf_hint_next_depth_dev: the previous frame's fusion launch computed these normals in its tail if it ran -- then it
+         * left this frame's token) */
+        if (nj.token && st->nrm_token == nj.token) return;
         const int t = (int)blockIdx.x - tp.n_track_blocks + nj.tile_first;
         if (t == 0 && threadIdx.x == 0) {
             *nj.deferred_count = 0u;                            /* fresh list for the k_fuse of this frame */
@@ -1842,7 +1984,14 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
         for (int i = threadIdx.x; i < GSDF_TRACK_ROWSET; i += GSDF_TRACK_BLOCK) nxt[i] = 0.0;
     }
 
-    if (k == 0) {
+    if (k > 0 && tp.head_done) {
+        /* the head of this launch was performed by the fusion launch in front of it (k_fuse<.., HEAD>, which found that optimize()
+         * had not ended): its result is in st->trk[k & 1], written in an earlier kernel */
+        const gsdf_trk_buf& cur = st->trk[k & 1];
+        if (cur.done) return;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose[i] = cur.pose7[i];
+    } else if (k == 0) {
         /* a new optimize(): the pose is RigidOptimizer::pose_ (kept in st->pose7 between frames) */
 #pragma unroll
         for (int i = 0; i < 7; ++i) pose[i] = st->pose7[i];

@@ -151,6 +151,11 @@ int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9
  * into it through gsdf_dev_upload* in between withdraws the hint, as does any other frame entry; a hint that does not match the
  * next call's depth_dev is ignored.  One hint per frame; NULL withdraws it.  No device work, never an error for a mismatch. */
 int gsdf_hint_next_depth_dev(gsdf_ctx* c, const float* next_depth_dev);
+/* both in one call: gsdf_hint_next_depth_dev(c, next_depth_dev) + gsdf_track_and_fuse_dev(c, depth_dev, ...) -- for hosts whose
+ * calls are not free (a ctypes call is ~1.5 us, 1 % of a frame, and the host is in the loop while a frame needs further batches
+ * of passes).  next_depth_dev may be NULL. */
+int gsdf_track_and_fuse_ahead_dev(gsdf_ctx* c, const float* depth_dev, const float* next_depth_dev, const float K[9],
+                                  int num_iterations, float conv_threshold, float damping);
 /* log rows = float[10]: pose7, converged, passes, n_hit (of the last pass) */
 int gsdf_read_frame_log(gsdf_ctx* c, float* rows10, int64_t max_rows, int64_t* n_rows);
 

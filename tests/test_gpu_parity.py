@@ -1272,3 +1272,63 @@ def test_next_depth_hint_is_invisible_except_in_time(pkg, O):
         assert np.abs(la[:, :7] - lb[:, :7]).max() <= 1e-6
         assert np.array_equal(ka, kb)
         assert np.abs(pa - pb).max() <= 1e-5 * max(1.0, float(np.abs(pa).max()))
+
+
+@pytest.mark.gpu
+def test_closing_head_inside_the_fusion_launch_is_invisible(pkg, O, monkeypatch):
+    """VERDICT r5 #2a: the frame's first gated fusion launch stands in for the last tracker launch of the first batch and performs
+    its head -- for the usual frame the closing one of optimize() -- in workgroup 0 (k_fuse<.., HEAD>; GSDF_FUSE_HEAD=1, the
+    default), or that launch is a tracker launch as before (0).  The arithmetic is the same function (trk_solve_update) on the
+    same sums, so pass counts, convergence flags, poses and the map must be IDENTICAL up to the float atomics of the deferred
+    lists -- with and without next-frame hints, with first batches of 2, 3 and 5 launches (the head then is the one of pass 0, 1
+    or 3: frames that are still running when the fusion launch comes continue with a head-less tracker launch), on a stretch of
+    the bench stream with frames that converge in 3-4 passes, late, and never."""
+    W, H = 640, 480
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=48, seed=0)
+    vs = np.float32(0.01)
+    frames = [seq.frame(i) for i in range(seq.n)]
+
+    def run(head, hint, first_batch):
+        monkeypatch.setenv("GSDF_FUSE_HEAD", head)
+        monkeypatch.setenv("GSDF_FIRST_BATCH", str(first_batch))
+        g = pkg.GradSdf(vs, np.float32(10) * vs, W, H, seq.K, capacity_log2=22)
+        d0, R0, t0 = frames[0]
+        p = pose7_from(O, R0, t0)
+        g.update(d0, O.quat_to_R(p[3:]), t0)
+        g.set_pose(p)
+        dev = [g.upload(f[0]) for f in frames]
+        for i in range(1, seq.n):
+            if hint and i + 1 < seq.n:
+                g.hint_next_depth(dev[i + 1])
+            g.track_and_fuse_dev(dev[i])
+        g.sync()
+        log = g.frame_log().copy()
+        keys, pay = g.export(sorted=True)
+        st = g.stats()
+        g.close()
+        return log, keys, pay, st
+
+    # The reference run of every first-batch size is the one WITHOUT the stand-in and without hints: the batch size itself is not
+    # invisible to the last bits (measured in round 6, also with the old code: the host waits at other moments, sees the fusion's
+    # "tiles too big for the small LDS table" note earlier or later, and a tile flushed in two bands instead of one adds its sums in
+    # two steps -- another last bit, which the frames that never converge amplify to ~5e-3 within their 25 passes; flags and pass
+    # counts still agree on all 47 frames).  Within one batch size everything is compared to the last bits.
+    bad = []
+    for fb in (5, 3, 2):
+        la, ka, pa, sa = run("0", False, fb)
+        conv = la[:, 7] != 0
+        assert 0 < conv.sum() < len(conv) and la[:, 8].max() == 25 and la[:, 8].min() <= 4
+        for head, hint in (("1", False), ("1", True), ("0", True)):
+            lb, kb, pb, sb = run(head, hint, fb)
+            same_flags = bool(np.array_equal(la[:, 7:10], lb[:, 7:10]))                    # converged, passes, hits of the last pass
+            dpose = float(np.abs(la[:, :7] - lb[:, :7]).max())
+            same_keys = bool(ka.shape == kb.shape and np.array_equal(ka, kb))
+            dpay = float(np.abs(pa - pb).max()) if same_keys else float("nan")
+            print("MEASURED first_batch %d, head %s hint %d against head 0 hint 0: flags / passes / hits equal %s, pose diff max %.2e, keys equal %s, "
+                  "sums diff %.2e, frames %d / %d, n_upd equal %s" % (fb, head, hint, same_flags, dpose, same_keys, dpay, sa["frames"], sb["frames"],
+                                                                      sa["n_upd"] == sb["n_upd"]))
+            # (not bit for bit between two RUNS: the handful of deferred contributions of a launch are float atomics, whose order is free)
+            if not (same_flags and dpose <= 1e-6 and same_keys and dpay <= 1e-5 * max(1.0, float(np.abs(pa).max())) and
+                    sa["frames"] == sb["frames"] and sa["n_upd"] == sb["n_upd"]):
+                bad.append((fb, head, hint))
+    assert not bad, bad
