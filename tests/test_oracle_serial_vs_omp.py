@@ -9,9 +9,14 @@ OMP-structured variant go through the SAME lockstep harness as the GPU engine (t
 the number of frames whose stop test falls differently ("flips") between the reference's own two builds is the yardstick the
 GPU is held to -- GPU-vs-serial flips <= serial-vs-OMP flips + 1, per stream.
 
-Measured (profiles/r05_serial_vs_omp.txt; `python tools/serial_vs_omp.py bench|c1`):
-  C1 (30 sphere frames, 640x480):   1 flip  (0 on short frames, 1 on a frame that runs > 6 passes), 1 long frame
-  bench stream (48 frames, 640x480): 2 flips (1 short: |xi|^2 = 1.012e-6 at the threshold; 1 long: 25 passes vs 12), 12 long frames
+Measured (`python tools/serial_vs_omp.py bench|c1`):
+  round 5 (profiles/r05_serial_vs_omp.txt):
+    C1 (30 sphere frames, 640x480):   1 flip  (0 on short frames, 1 on a frame that runs > 6 passes), 1 long frame
+    bench stream (48 frames, 640x480): 2 flips (1 short: |xi|^2 = 1.012e-6 at the threshold; 1 long: 25 passes vs 12), 12 long frames
+  round 6, after tsdf() and n_sq were restated (profiles/r06_serial_vs_omp.txt):
+    C1: 2 flips (1 short: |xi|^2 = 9.18e-7; 1 long: 11 passes vs 9), 2 long frames
+    bench stream: 2 flips (1 short: 1.018e-6; 1 long: 25 passes vs 24), 12 long frames
+  The limits below keep the SMALLER of the two measurements per stream (C1: 1), so the GPU is held to <= 2 / <= 3 flips.
 The fused maps of the two builds keep identical key sets; dist differs by <= 4e-8 (the running mean's order)."""
 import os
 
