@@ -556,6 +556,8 @@ struct fuse_args {
     int nrm_r, nrm_ntx;                 /* window radius, normals tiles per image row */
     gsdf_fuse_head hd;                  /* k_fuse<.., HEAD>: the closing head of optimize() this launch performs first (k = 0: none) */
     unsigned int nrm_token;             /* tracked frames: what the normals role leaves in st->nrm_token when it ran (never 0) */
+    int p0_first;                       /* k_fuse<.., P0>: first workgroup of the pass-0 role (behind the tiles and the normals tiles) */
+    gsdf_fuse_pass0 p0;
 };
 #define FUSE_RESOLVE_INLINE 8192u       /* deferred entries the last workgroup adds itself even when a resolve launch follows */
 
@@ -663,19 +665,26 @@ __device__ __forceinline__ void fuse_log_row(const fuse_args& a) {
 __device__ __forceinline__ void trk_solve_update(const float* tot, float damping, float conv_sq, int passes, int max_passes,
                                                  int no_solve, bool exact_solve, float pose[7], int* done, int* converged);
 
-/* k_fuse<.., HEAD>: the head of tracker launch a.hd.k (see k_fuse).  false: optimize() had ended before this launch, the state in
- * a.st is final.  true: (pose, done, conv) are the head's result -- computed here by the `solver` wave (workgroup 0's first: it also
- * publishes it), read from the tagged chunks it publishes by every other wave of the launch. */
-__device__ __forceinline__ bool fuse_head(const fuse_args& a, int tid, bool solver, float (&pose)[7], int& hdone, int& hconv) {
+/* k_fuse<.., HEAD>: the head of tracker launch a.hd.k (see k_fuse).  On return (pose, done, conv) are the state behind that head:
+ * computed by the `solver` wave (workgroup 0's first) -- or, when optimize() had ended in an earlier launch, read by it from a.st,
+ * which nobody has written since -- and taken from the three tagged chunks the solver publishes by EVERY other wave of the launch.
+ *
+ * Round 6, found by the eight-process exchange test (a frame without its log row, 1 run in 3): the non-solver waves used to look
+ * at st->trk[(k - 1) & 1].done with a plain load first ("ended before this launch: the state in a.st is final") and then trusted
+ * the plain loads of st->done / converged / R / pose7 from the top of the kernel.  But the solver itself sets that `done` word
+ * (sticky, for launches queued beyond the end) and rewrites st->done / pose7 in THIS launch, and the per-XCD L2s are not coherent
+ * for plain accesses: a workgroup of a later dispatch round could see the NEW `done` word (its line re-fetched) beside the OLD
+ * st->done = 0 (its line still cached from an earlier workgroup of the same XCD) and leave without fusing its tile -- no ticket, no
+ * last workgroup, no log row.  Now nothing that the solver writes is read plainly by anybody else in the launch. */
+__device__ __forceinline__ void fuse_head(const fuse_args& a, int tid, bool solver, float (&pose)[7], int& hdone, int& hconv) {
     const gsdf_trk_buf& in = a.st->trk[(a.hd.k - 1) & 1];
-    if (in.done) return false;                                     /* optimize() ended in an earlier launch */
     const int hlane = tid & 63;
     int hpasses = 0;
     bool have = false;
     if (!solver) {
         /* the three chunks, one per lane 0..2, until all carry this launch's tag (for workgroups of the later dispatch rounds
          * they are there at the first look) */
-        const unsigned long long t0 = wall_clock64();
+        unsigned long long t0 = wall_clock64();
         gsdf_u32x4 ch = { 0u, 0u, 0u, 0u };
         for (;;) {
             if (hlane < 3) {
@@ -683,7 +692,13 @@ __device__ __forceinline__ bool fuse_head(const fuse_args& a, int tid, bool solv
                 asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(ch) : "v"(q) : "memory");
             }
             if (__all(hlane >= 3 || ch.x == a.tag)) { have = true; break; }
-            if (wall_clock64() - t0 > 200000ull) break;              /* 2 ms at 100 MHz: do it yourself (never seen) */
+            if (wall_clock64() - t0 > 200000ull) {
+                /* 2 ms at 100 MHz without the solver's chunks (a GPU shared with other processes): perform the head here -- unless
+                 * the `done` word of the input state is set: then optimize() ended earlier or the solver has just ended it, and in
+                 * both cases its chunks are the only consistent statement of the result: keep polling */
+                if (!__hip_atomic_load(const_cast<int*>(&in.done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                t0 = wall_clock64();
+            }
             __builtin_amdgcn_s_sleep(4);
         }
         if (have) {
@@ -696,11 +711,20 @@ __device__ __forceinline__ bool fuse_head(const fuse_args& a, int tid, bool solv
             pose[4] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.w, 1));
             pose[5] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.y, 2));
             pose[6] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)ch.z, 2));
+            return;
         }
     }
-    if (!have) {
+    /* (the solver wave is the first of the launch: whatever it reads plainly was written by earlier kernels) */
+    const bool ended_before = solver && in.done != 0;
+    if (ended_before) {
+        gsdf_dev_state* st = a.st;
+        hdone = st->done; hconv = st->converged; hpasses = st->passes;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pose[i] = st->pose7[i];
+    } else {
         /* the head itself, as in k_track_pass: lane v < 29 adds the group sums of value v in increasing order, readlane hands the
-         * totals to every lane, the solve runs in every lane alike */
+         * totals to every lane, the solve runs in every lane alike.  (A wave whose wait expired: rows, in.pose7 and in.passes are
+         * not written in this launch.) */
         const double* acc_prev = a.hd.rows + (size_t)a.hd.rot_prev * GSDF_TRACK_ROWSET;
         double gs = 0.0;
         if (hlane < GSDF_TRACK_NSUM) {
@@ -727,7 +751,7 @@ __device__ __forceinline__ bool fuse_head(const fuse_args& a, int tid, bool solv
 #pragma unroll
             for (int i = 0; i < 7; ++i) { o.pose7[i] = pose[i]; st->pose7[i] = pose[i]; }
             o.done = hdone; o.converged = hconv; o.passes = hpasses;
-            if (hdone) st->trk[(a.hd.k - 1) & 1].done = 1;
+            if (hdone) __hip_atomic_store(&st->trk[(a.hd.k - 1) & 1].done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             gsdf_quat_to_R(pose + 3, st->R);
             st->converged = hconv;
             st->done = hdone;
@@ -737,18 +761,19 @@ __device__ __forceinline__ bool fuse_head(const fuse_args& a, int tid, bool solv
             if (a.hd.progress)
                 __hip_atomic_store(&a.hd.progress[0], (a.hd.serial << 16) | (hdone ? 0x8000u : 0u) | (unsigned int)(hpasses & 0x7FFF),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            /* ... and for the other workgroups of THIS launch: the tagged chunks */
-            const gsdf_u32x4 c0 = { a.tag, (uint32_t)hdone | ((uint32_t)hconv << 1), __float_as_uint(pose[0]), __float_as_uint(pose[1]) };
-            const gsdf_u32x4 c1 = { a.tag, __float_as_uint(pose[2]), __float_as_uint(pose[3]), __float_as_uint(pose[4]) };
-            const gsdf_u32x4 c2 = { a.tag, __float_as_uint(pose[5]), __float_as_uint(pose[6]), (uint32_t)hpasses };
-            unsigned int* q = st->fh;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
-                         "global_store_dwordx4 %0, %3, off offset:32 sc1" :: "v"(q), "v"(c0), "v"(c1), "v"(c2) : "memory");
-            /* the plain stores above are read by the launch's LAST workgroup (frame log), possibly on another XCD */
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         }
     }
-    return true;
+    if (solver && hlane == 0) {
+        /* ... and for every other wave of THIS launch: the tagged chunks (also when optimize() had ended before the launch) */
+        const gsdf_u32x4 c0 = { a.tag, (uint32_t)hdone | ((uint32_t)hconv << 1), __float_as_uint(pose[0]), __float_as_uint(pose[1]) };
+        const gsdf_u32x4 c1 = { a.tag, __float_as_uint(pose[2]), __float_as_uint(pose[3]), __float_as_uint(pose[4]) };
+        const gsdf_u32x4 c2 = { a.tag, __float_as_uint(pose[5]), __float_as_uint(pose[6]), (uint32_t)hpasses };
+        unsigned int* q = a.st->fh;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                     "global_store_dwordx4 %0, %3, off offset:32 sc1" :: "v"(q), "v"(c0), "v"(c1), "v"(c2) : "memory");
+        /* the plain stores above are read by the launch's LAST workgroup (frame log), possibly on another XCD */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
 }
 
 /* NEXT_NORMALS: the instantiation whose launches carry the normals workgroups of the next frame (GT-pose runs, and tracked frames
@@ -762,11 +787,32 @@ __device__ __forceinline__ bool fuse_head(const fuse_args& a, int tid, bool solv
  * once per workgroup.  Workgroup 0 is dispatched first and waits for nobody; the wait of the others is bounded, and a wave whose
  * wait expires performs the head itself (bit-identical).  If optimize() has not ended with that head, every workgroup leaves,
  * and the host's next batch starts with a tracker launch that skips its head (gsdf_track_params::head_done). */
-template <int LCAP, bool NEXT_NORMALS, bool HEAD>
+/* P0 (round 6, VERDICT r5 #2c): further workgroups behind the normals tiles perform launch 0 of the NEXT frame's optimize() -- the
+ * gather and the 29 sums of its first Gauss-Newton pass (no head), which starts from the pose this fusion uses.  They load their
+ * pixels' depth, then wait until the launch's last workgroup has added the deferred list (st->map_ready == tag: the map is the
+ * reference's map after update()), acquire, gather and add their sums to the buffer launch 0 would have used.  They are the last
+ * workgroups of the grid: every tile has been dispatched before the first of them, so they wait for nobody who waits for a slot.
+ * The next frame's host code then starts with launch 1 (its head finishes this pass); it knows whether the role ran (the fusion's
+ * gate = the closing head's result, which it follows anyway).  Saves the next frame a launch and a kernel boundary, and the
+ * depth round trip of that launch hides under the fusion's tail. */
+__device__ __forceinline__ void fuse_pass0(const fuse_args& a, float (*wsum)[32], int b, const float (&pose)[7]);
+
+template <int LCAP, bool NEXT_NORMALS, bool HEAD, bool P0 = false>
 __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     __shared__ fuse_lds<LCAP> L;
     const int tid = threadIdx.x;
     FUSE_SETPRIO(FUSE_PRIO_START);
+    if constexpr (P0) {
+        static_assert(NEXT_NORMALS && HEAD, "the pass-0 role rides on the launch that performs the closing head and the next frame's normals");
+        if ((int)blockIdx.x >= a.p0_first) {
+            float pose[7];
+            int hd_ = 0, hc_ = 0;
+            fuse_head(a, tid, false, pose, hd_, hc_);
+            if (!(__builtin_amdgcn_readfirstlane(hd_) && __builtin_amdgcn_readfirstlane(hc_))) return;     /* no fusion, no new map: launch 0 is queued as ever */
+            fuse_pass0(a, reinterpret_cast<float(*)[32]>(&L), (int)blockIdx.x - a.p0_first, pose);
+            return;
+        }
+    }
     if constexpr (NEXT_NORMALS && FUSE_CARRIES_NORMALS) {
     if ((int)blockIdx.x >= a.n_tiles) {                       /* the next frame's normals, in the tail of this launch */
         static_assert(sizeof(nrm_lds) <= sizeof(fuse_lds<LCAP>), "the normals tile works in the fusion table's LDS");
@@ -779,7 +825,8 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             if constexpr (HEAD) {
                 float pose[7];
                 int hd_ = 0, hc_ = 0;
-                if (fuse_head(a, tid, false, pose, hd_, hc_)) { gd = __builtin_amdgcn_readfirstlane(hd_); gc = __builtin_amdgcn_readfirstlane(hc_); }
+                fuse_head(a, tid, false, pose, hd_, hc_);
+                gd = __builtin_amdgcn_readfirstlane(hd_); gc = __builtin_amdgcn_readfirstlane(hc_);
             }
             if (!(gd && gc)) return;
             if (t == 0 && tid == 0) a.st->nrm_token = a.nrm_token;
@@ -805,15 +852,15 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     if constexpr (HEAD) {
         float pose[7];
         int hdone = 0, hconv = 0;
-        if (fuse_head(a, tid, blockIdx.x == 0 && tid < 64, pose, hdone, hconv)) {
-            done = __builtin_amdgcn_readfirstlane(hdone); conv = __builtin_amdgcn_readfirstlane(hconv);
-            float Rh[9];
-            gsdf_quat_to_R(pose + 3, Rh);                                /* st->R is computed the same way: identical bits */
+        fuse_head(a, tid, blockIdx.x == 0 && tid < 64, pose, hdone, hconv);
+        /* (done, conv, R, t) of this launch are the head's statement, never the plain loads above: see fuse_head */
+        done = __builtin_amdgcn_readfirstlane(hdone); conv = __builtin_amdgcn_readfirstlane(hconv);
+        float Rh[9];
+        gsdf_quat_to_R(pose + 3, Rh);                                    /* st->R is computed the same way: identical bits */
 #pragma unroll
-            for (int i = 0; i < 9; ++i) R[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(Rh[i])));
+        for (int i = 0; i < 9; ++i) R[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(Rh[i])));
 #pragma unroll
-            for (int i = 0; i < 3; ++i) t[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pose[i])));
-        }
+        for (int i = 0; i < 3; ++i) t[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pose[i])));
     }
     if (a.use_dev_pose) {
         if (!(done && conv)) {
@@ -1495,6 +1542,13 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             unsafeAtomicAdd(&d.p->gy, d.gy);
             unsafeAtomicAdd(&d.p->gz, d.gz);
         }
+    if constexpr (P0) {
+        /* the map is final (the host attaches the pass-0 role only to launches without a k_fuse_resolve behind them: mine == true):
+         * every lane releases its atomics, then one store tells the riders */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid == 0 && mine) __hip_atomic_store(&a.st->map_ready, a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (tid == 0) {
         if (mine) { a.st->n_deferred += n; __hip_atomic_store(a.deferred_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         a.st->last_deferred = n;
@@ -1548,7 +1602,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       long long max_rows, uint32_t* vis, int vis_words, int debug, unsigned int* ticket, int resolve_follows,
                       unsigned int* host_note, int far_table, const gsdf_fuse_head* head, const float* next_depth, float* next_nx,
                       float* next_ny, float* next_nz, int win, const uint32_t* tile_stats, uint32_t* next_tile_stats,
-                      unsigned int next_token) {
+                      unsigned int next_token, const gsdf_fuse_pass0* pass0) {
     fuse_args a;
     a.tile_stats = tile_stats; a.nrm_stats = next_tile_stats;
     a.host_note = host_note;
@@ -1572,9 +1626,14 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     }
     std::memset(&a.hd, 0, sizeof(a.hd));
     a.nrm_token = next_token;
+    a.p0_first = n + extra;
+    std::memset(&a.p0, 0, sizeof(a.p0));
     if (head && use_dev_pose && head->k > 0) {
         a.hd = *head;
-        if (extra) {
+        if (extra && pass0 && pass0->n_blocks > 0 && !far_table && !resolve_follows && FUSE_THREADS == GSDF_TRACK_BLOCK) {
+            a.p0 = *pass0;
+            hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, true, true, true>), dim3(n + extra + pass0->n_blocks), dim3(FUSE_THREADS), 0, s, a);
+        } else if (extra) {
             if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, true, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
             else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, true, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
         } else if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, false, true>), dim3(n), dim3(FUSE_THREADS), 0, s, a);
@@ -1915,6 +1974,81 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
     }
 }
 
+/* k_fuse<.., P0>: launch 0 of the next frame's optimize() (see k_fuse).  Pixels -> lanes, buffers and the reduction are those of
+ * k_track_pass with pass_index 0 and rot = a.p0.rot; the depth image is the next frame's (a.nrm_depth), the pose the one this
+ * fusion launch uses (the closing head's). */
+__device__ __forceinline__ void fuse_pass0(const fuse_args& a, float (*wsum)[32], int b, const float (&pose_in)[7]) {
+    static_assert(FUSE_THREADS == GSDF_TRACK_BLOCK || !(FUSE_T == 16 && FUSE_TH == 16), "the pass-0 role runs in tracker-sized workgroups");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const gsdf_frame_geom& g = a.g;
+    const float* __restrict__ depth = a.nrm_depth;
+    const bool heavy = wave < GSDF_TRACK_BLOCK / 128;
+    const int pix0 = b * TRK_CHUNK + (heavy ? wave * (64 * TRK_PPT) : (GSDF_TRACK_BLOCK / 128) * 64 * TRK_PPT + (wave - GSDF_TRACK_BLOCK / 128) * (64 * (TRK_PPT - 1))) + lane;
+    const int batch = a.p0.n_blocks * TRK_CHUNK;
+    float z_pre[TRK_PPT];
+    {
+        const int N = g.W * g.H;
+#pragma unroll
+        for (int j = 0; j < TRK_PPT; ++j) {
+            const int pix = pix0 + j * 64;
+            z_pre[j] = (pix < N && (heavy || j < TRK_PPT - 1)) ? depth[pix] : 0.f;
+        }
+    }
+    double* acc_cur = a.p0.rows + (size_t)(a.p0.rot % 3u) * GSDF_TRACK_ROWSET;
+    if (b == 0) {
+        double* nxt = a.p0.rows + (size_t)((a.p0.rot + 1u) % 3u) * GSDF_TRACK_ROWSET;
+        for (int i = tid; i < GSDF_TRACK_ROWSET; i += GSDF_TRACK_BLOCK) nxt[i] = 0.0;
+    }
+    float pose[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) pose[i] = pose_in[i];
+    /* the fusion's last workgroup: every tile flushed, the deferred list added.  100 ms at 100 MHz bound the wait (never seen; a
+     * wave that gives up contributes nothing and says so: GSDF_STATUS_RIDER_TIMEOUT fails the next synchronising call) */
+    bool ok = true;
+    {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&a.st->map_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.tag) {
+            if (wall_clock64() - t0 > 10000000ull) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        ok = __all(ok);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float acc[GSDF_TRACK_NSUM];
+#pragma unroll
+    for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
+    if (ok) {
+        if (heavy) trk_gather<TRK_PPT>(g, a.tab, depth, z_pre, pose, pix0, 64, batch, acc);
+        else trk_gather<TRK_PPT - 1>(g, a.tab, depth, z_pre, pose, pix0, 64, batch, acc);
+    } else if (lane == 0) {
+        atomicAdd(&a.st->p0_expired, 1u);
+        atomicOr(&a.st->status, GSDF_STATUS_RIDER_TIMEOUT);
+    }
+    wave_sum_to_lane63(acc);
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < GSDF_TRACK_NSUM; ++i) wsum[wave][i] = acc[i];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float v = 0.f;
+        if (tid < GSDF_TRACK_NSUM) {
+            v = wsum[0][tid];
+#pragma unroll
+            for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
+        }
+        if (tid < GSDF_TRACK_NSUM) unsafeAtomicAdd(&acc_cur[(b % GSDF_TRACK_GROUPS) * 32 + tid], (double)v);
+    }
+    if (b == 0 && tid == 0) {
+        /* what launch 0 leaves for the head of launch 1 (st->done / converged / passes stay the finished frame's: this launch's last
+         * workgroup still logs them, and every head of the next optimize() rewrites them before a gate reads them) */
+        gsdf_trk_buf& o = a.st->trk[0];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) o.pose7[i] = pose[i];
+        o.done = 0; o.converged = 0; o.passes = 0;
+    }
+}
+
 static_assert(GSDF_TRACK_BLOCK == NRM_THREADS, "the normals tiles of the first pass run in tracker-sized workgroups");
 /* SAMPLED: optimize_sampled(depth, K, sampling > 1) -- the public stride argument of RigidPointOptimizer.h:65.  g.W x g.H is
  * the grid of sampled pixels (ceil(W / s) x ceil(H / s)), `depth` its compacted image (k_subsample), tp.sampling the stride.
@@ -2100,16 +2234,19 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
     if (trk_tr && threadIdx.x == 0) trk_tr[3] = wall_clock64();
 }
 int gsdf_normals_tiles(int W, int H) { return ((W + NRM_TX - 1) / NRM_TX) * ((H + NRM_TY - 1) / NRM_TY); }
+/* one chunk of TRK_CHUNK pixels per workgroup while the grid allows it (640 x 480: 240 workgroups), more by looping -- and then the
+ * same number of chunks for every workgroup (1280 x 960: 480 x 2, not 512 x 1.9) */
+int gsdf_track_pass_blocks(int W, int H, int cap) {
+    const int chunks = std::max(1, (W * H + TRK_CHUNK - 1) / TRK_CHUNK);
+    cap = std::max(1, cap);
+    const int per = (chunks + cap - 1) / cap;
+    return (chunks + per - 1) / per;
+}
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
                             gsdf_dev_state* st, double* partials, int n_blocks, const gsdf_track_params& tp_in,
                             const gsdf_normals_job* normals) {
     gsdf_track_params tp = tp_in;
-    /* one chunk of TRK_CHUNK pixels per workgroup while the grid allows it (640 x 480: 240 workgroups), more by looping */
-    {                                   /* ... and then the same number of chunks for every workgroup (1280 x 960: 480 x 2, not 512 x 1.9) */
-        const int chunks = std::max(1, (g.W * g.H + TRK_CHUNK - 1) / TRK_CHUNK), cap = std::max(1, n_blocks);
-        const int per = (chunks + cap - 1) / cap;
-        n_blocks = (chunks + per - 1) / per;
-    }
+    n_blocks = gsdf_track_pass_blocks(g.W, g.H, n_blocks);
     /* the launch behind the last pass only finishes it (head: reduce, solve, publish): one workgroup does -- workgroup 0 is the
      * one that publishes; the others would solve the same system and return */
     if (tp.pass_index >= tp.max_passes && !normals) n_blocks = 1;

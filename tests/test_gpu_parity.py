@@ -1332,3 +1332,63 @@ def test_closing_head_inside_the_fusion_launch_is_invisible(pkg, O, monkeypatch)
                     sa["frames"] == sb["frames"] and sa["n_upd"] == sb["n_upd"]):
                 bad.append((fb, head, hint))
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_no_frame_is_lost_when_contexts_share_the_gpu(pkg, O):
+    """Round 6, found by test_bench_gpus_8_end_to_end_over_the_rccl_double (1 run in 3): in a k_fuse<.., HEAD> launch a workgroup of a
+    later dispatch round could take the solver's sticky `done` word (fresh) for "optimize() ended before this launch" and then use a
+    STALE st->done = 0 from its XCD's L2 -- it left without fusing its tile and without its ticket, so the launch had no last
+    workgroup: no frame-log row, the deferred list never added.  The window opens when lines of the state block are evicted between
+    two dispatch rounds, i.e. when other work shares the GPU.  Here: four contexts in four host threads run the hinted frame loop
+    over the same 30 frames (all converge within the first batch: every fusion launch is a HEAD launch that runs), five times each;
+    every context must log every frame, fuse every frame (Sdf::counter_) with every tile (n_upd: a lost tile is ~4 000 updates), and
+    end with the poses and the map of a context that ran alone -- up to the last bits the float atomics of the deferred lists and
+    the host's timing leave open (see test_closing_head_inside_the_fusion_launch_is_invisible)."""
+    import threading
+    W, H = 640, 480
+    n = 30
+    seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=0)
+    vs = np.float32(0.01)
+    frames = [seq.frame(i) for i in range(n)]
+
+    def run(out, idx, reps):
+        g = pkg.GradSdf(vs, np.float32(10) * vs, W, H, seq.K, capacity_log2=22)
+        d0, R0, t0 = frames[0]
+        p = pose7_from(O, R0, t0)
+        dev = [g.upload(f[0]) for f in frames]
+        res = []
+        for _ in range(reps):
+            g.reset()
+            g.update(d0, O.quat_to_R(p[3:]), t0)
+            g.set_pose(p)
+            for i in range(1, n):
+                if i + 1 < n:
+                    g.hint_next_depth(dev[i + 1])
+                g.track_and_fuse_dev(dev[i])
+            g.sync()
+            log = g.frame_log().copy()
+            st = g.stats()
+            keys, pay = g.export(sorted=True)
+            res.append((log, st["frames"], st["n_upd"], keys, pay))
+        g.close()
+        out[idx] = res
+
+    alone = [None]
+    run(alone, 0, 1)
+    log_a, frames_a, n_upd_a, keys_a, pay_a = alone[0][0]
+    assert len(log_a) == n - 1 and frames_a == 1 + int(log_a[:, 7].sum())
+    out = [None] * 4
+    th = [threading.Thread(target=run, args=(out, i, 5)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for res in out:
+        assert res is not None and len(res) == 5
+        for log, n_frames, n_upd, keys, pay in res:
+            assert len(log) == n - 1, "a frame has no log row: its fusion launch had no last workgroup"
+            assert np.array_equal(log[:, 7:9], log_a[:, 7:9])                       # converged flags, pass counts
+            assert n_frames == frames_a and abs(int(n_upd) - int(n_upd_a)) <= 500   # every converged frame fused, every tile of it
+            assert np.abs(log[:, :7] - log_a[:, :7]).max() <= 1e-5
+            assert abs(len(keys) - len(keys_a)) <= 1e-4 * len(keys_a)
