@@ -2002,25 +2002,32 @@ __device__ __forceinline__ void fuse_pass0(const fuse_args& a, float (*wsum)[32]
     float pose[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) pose[i] = pose_in[i];
-    /* the fusion's last workgroup: every tile flushed, the deferred list added.  100 ms at 100 MHz bound the wait (never seen; a
-     * wave that gives up contributes nothing and says so: GSDF_STATUS_RIDER_TIMEOUT fails the next synchronising call) */
-    bool ok = true;
-    {
+    /* the fusion's last workgroup: every tile flushed, the deferred list added.  ONE wave per workgroup watches the word (1920
+     * waves polling one address with agent-scope loads, and as many L2 invalidations behind it, cost the launch 10 us: measured)
+     * and acquires for the workgroup -- the vector L1 belongs to the CU, the L2 to the XCD --, the others meet it at a barrier.
+     * 100 ms at 100 MHz bound the wait (never seen; a workgroup that gives up contributes nothing and says so:
+     * GSDF_STATUS_RIDER_TIMEOUT fails the next synchronising call) */
+    int* ok_flag = reinterpret_cast<int*>(&wsum[GSDF_TRACK_BLOCK / 64][0]);
+    if (wave == 0) {
+        bool ready = true;
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(&a.st->map_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.tag) {
-            if (wall_clock64() - t0 > 10000000ull) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 10000000ull) { ready = false; break; }
+            __builtin_amdgcn_s_sleep(16);
         }
-        ok = __all(ok);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) *ok_flag = ready ? 1 : 0;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const bool ok = *ok_flag != 0;
+    __syncthreads();                                     /* (wsum is written below) */
     float acc[GSDF_TRACK_NSUM];
 #pragma unroll
     for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
     if (ok) {
         if (heavy) trk_gather<TRK_PPT>(g, a.tab, depth, z_pre, pose, pix0, 64, batch, acc);
         else trk_gather<TRK_PPT - 1>(g, a.tab, depth, z_pre, pose, pix0, 64, batch, acc);
-    } else if (lane == 0) {
+    } else if (tid == 0) {
         atomicAdd(&a.st->p0_expired, 1u);
         atomicOr(&a.st->status, GSDF_STATUS_RIDER_TIMEOUT);
     }
