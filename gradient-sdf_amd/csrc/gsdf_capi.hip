@@ -188,19 +188,9 @@ static uint32_t* stats_of(const gsdf_ctx* c, const float* nrm) {
 /* one k_fuse launch: depth + its normal planes `nrm` (3 x N floats) -> the map.  next_depth (nullable): the launch's extra
  * workgroups compute the normals of that frame into next_nrm */
 int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsdf_pose_arg& pose, int use_dev_pose,
-                const float* next_depth, float* next_nrm, const gsdf_fuse_head* head = nullptr, unsigned int next_token = 0u,
-                const gsdf_fuse_pass0* pass0 = nullptr, bool* pass0_attached = nullptr) {
+                const float* next_depth, float* next_nrm, const gsdf_fuse_head* head = nullptr, unsigned int next_token = 0u) {
     const size_t N = (size_t)c->W * c->H;
     c->occ_dirty = true;                                      /* new blocks: the raycaster's filters are rebuilt when it next runs */
-    /* long deferred lists lately (the note lags by a launch or two: a hint, not a condition) */
-    const int resolve_follows = c->progress && c->progress[2] > 8192u ? 1 : 0;
-    /* many tiles did not fit the small LDS table lately (far geometry): the kernel with the larger one.
-     * Like the note above a hint that lags by a launch or two, never a condition for correctness. */
-    const int far_table = fuse_far_table(c);
-    /* the pass-0 role (k_fuse<.., P0>) needs the launch that performs the closing head and the next frame's normals, the small
-     * table's instantiation, and a map that is final when the launch's last workgroup has added the deferred list */
-    if (pass0 && !(head && head->k > 0 && use_dev_pose && next_depth && next_nrm && !resolve_follows && !far_table && pass0->n_blocks > 0)) pass0 = nullptr;
-    if (pass0_attached) *pass0_attached = pass0 != nullptr;
     {
         prof_scope ps(c, 1);
         c->fuse_tag += 1;
@@ -212,10 +202,13 @@ int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsd
                          use_dev_pose, c->tab, c->st, c->blk_counters, c->deferred, c->deferred_count,
                          c->deferred_cap, c->fuse_tag, c->tile_flags, c->tile_order, c->frame_log, c->frame_log_cap, c->vis, c->vis_words,
                          c->debug & 0xFFFF, c->fuse_ticket,
-                         resolve_follows, c->progress ? c->progress_dev + 2 : nullptr,
-                         far_table, head,
+                         /* long deferred lists lately (the note lags by a launch or two: a hint, not a condition) */
+                         c->progress && c->progress[2] > 8192u ? 1 : 0, c->progress ? c->progress_dev + 2 : nullptr,
+                         /* many tiles did not fit the small LDS table lately (far geometry): the kernel with the larger one.
+                          * Like the note above a hint that lags by a launch or two, never a condition for correctness. */
+                         fuse_far_table(c), head,
                          next_depth, next_nrm, next_nrm ? next_nrm + N : nullptr, next_nrm ? next_nrm + 2 * N : nullptr, c->win,
-                         stats_of(c, nrm), next_nrm ? stats_of(c, next_nrm) : nullptr, next_token, pass0);
+                         stats_of(c, nrm), next_nrm ? stats_of(c, next_nrm) : nullptr, next_token);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GSDF_ERR_HIP, std::string("fusion launch: ") + hipGetErrorString(e));
@@ -224,9 +217,7 @@ int launch_fuse(gsdf_ctx* c, const float* depth_dev, const float* nrm, const gsd
 
 /* normals (unless the frame's were computed beside its first tracker pass: normals_done) + fusion, in stream order */
 int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done, int set,
-                 const float* next_depth, const gsdf_fuse_head* head, int next_set, unsigned int next_token,
-                 const gsdf_fuse_pass0* pass0, bool* pass0_attached) {
-    if (pass0_attached) *pass0_attached = false;
+                 const float* next_depth, const gsdf_fuse_head* head, int next_set, unsigned int next_token) {
     const size_t N = (size_t)c->W * c->H;
     /* tracked frames: set 2, filled beside the first tracker passes -- or the set the PREVIOUS frame's fusion filled in its
      * tail (gsdf_hint_next_depth_dev) */
@@ -242,7 +233,7 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
     /* gsdf_hint_next_depth_dev: the launch's last workgroups compute NormalEstimator::compute of the NEXT frame into set
      * next_set -- if the launch's gate is open -- and leave next_token in st->nrm_token */
     float* next_nrm = next_depth ? c->normals + (size_t)next_set * 3 * N : nullptr;
-    return launch_fuse(c, depth_dev, nrm, pose, use_dev_pose, next_depth, next_nrm, head, next_token, next_depth ? pass0 : nullptr, pass0_attached);
+    return launch_fuse(c, depth_dev, nrm, pose, use_dev_pose, next_depth, next_nrm, head, next_token);
 }
 
 /* RigidPointOptimizer::optimize_sampled as a chain of per-pass launches.  The convergence test, the pose update
@@ -257,8 +248,7 @@ int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose,
  * previous one.  Correctness never depends on what the host sees: a late or lost observation only costs empty
  * launches. */
 int enqueue_fuse(gsdf_ctx* c, const float* depth_dev, const gsdf_pose_arg& pose, int use_dev_pose, bool normals_done, int set = 2,
-                 const float* next_depth = nullptr, const gsdf_fuse_head* head = nullptr, int next_set = 0, unsigned int next_token = 0u,
-                 const gsdf_fuse_pass0* pass0 = nullptr, bool* pass0_attached = nullptr);
+                 const float* next_depth = nullptr, const gsdf_fuse_head* head = nullptr, int next_set = 0, unsigned int next_token = 0u);
 
 /* 1 = optimize() ended, 0 = the head of launch `last` ran and it has not ended, -1 = gave up waiting */
 int follow_progress(gsdf_ctx* c, unsigned int serial, int last) {
@@ -313,13 +303,6 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     /* ... and not while the fusion uses the larger LDS table (far geometry): that instantiation with the normals role is at the
      * register limit and moves its records unpaired, with the head it spills -- both cost more than the step saves */
     const bool new_route = fuse_after && !c->profiling && iters > 0 && !c->prev_slow && !fuse_far_table(c);
-    /* k_fuse<.., P0>: launch 0 of THIS optimize() -- the gather and the sums of its first pass -- was performed in the tail of the
-     * previous frame's fusion launch (with the pose and the map that launch left, on this depth image): the frame starts with
-     * launch 1, whose head finishes that pass.  Otherwise sums the role left are void. */
-    const bool per_pass = !(sampling == 1 && c->persist && c->track_rows && c->track_blocks <= 2 * GSDF_TRACK_MAXBLK);
-    const bool p0_here = c->p0_ran && c->p0_depth == depth_dev && pre && sampling == 1 && per_pass && c->adaptive && c->progress;
-    if (!p0_here) gsdf_p0_cancel(c);
-    c->p0_ran = false; c->p0_depth = nullptr;
     const float* hint = new_route ? c->hint_next : nullptr;
     c->nrm_ready_depth = nullptr;        /* consumed (or not ours) */
     c->hint_next = nullptr;
@@ -386,10 +369,6 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     }
     int k = 0, batch_no = 0;
     int batch = adaptive ? c->first_batch : iters + 1;
-    if (p0_here) {                                           /* launch 0 has been performed: counted as issued */
-        c->track_rot = (c->track_rot + 1u) % 3u;
-        k = 1;
-    }
     /* The frame's first fusion launch stands in for the LAST tracker launch of the first batch (k_fuse<.., HEAD>): that launch's
      * head -- for the usual frame the closing one of optimize() -- runs in workgroup 0 of the fusion launch, which every other
      * workgroup of it follows; a launch and a kernel boundary less per frame.  If optimize() has not ended with that head the
@@ -398,7 +377,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
     const bool fuse_head = new_route && adaptive && c->fuse_head;
     bool headless = false;                                   /* the next launch's head was performed by a fusion launch */
     while (k <= iters) {
-        const int last = std::min(iters, (batch_no == 0 ? 0 : k) + batch - 1);   /* (the first batch ends with launch batch - 1 also when it starts with launch 1) */
+        const int last = std::min(iters, k + batch - 1);
         const bool stand_in = fuse_head && batch_no == 0 && last >= 1;
         for (; k <= last; ++k) {
             if (stand_in && k == last) continue;             /* its head is the fusion launch's */
@@ -413,7 +392,7 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
              * tiles; launch 0 has no head and ends early, so it takes the smallest one.  Tile 0 (it resets the frame's deferred list)
              * stays in launch 0. */
             const gsdf_normals_job* job = nullptr;
-            if (fuse_after && k <= 2 && !p0_here) {              /* (p0_here: the launch that performed pass 0 computed the normals too) */
+            if (fuse_after && k <= 2) {
                 const int tiles = gsdf_normals_tiles(c->W, c->H);
                 /* tracker launches of the first batch (the fusion launch may stand in for its last one: no riders there) */
                 const int nl = batch_no == 0 ? (stand_in ? last : last + 1) : 3;
@@ -431,44 +410,29 @@ int enqueue_track(gsdf_ctx* c, const float* depth_dev, int iters, float conv, fl
          * that finds optimize() still running -- 3 us each, 3 per frame that never converges -- so there it is queued only
          * once the progress word says that optimize() has ended (the frame that converges late pays the host's look). */
         bool fuse_queued = false;
-        bool p0_attached = false;
         if (fuse_after && (batch_no == 0 || last == iters || !c->lazy_fuse)) {
             gsdf_fuse_head hd;
             std::memset(&hd, 0, sizeof(hd));
-            gsdf_fuse_pass0 p0;
-            std::memset(&p0, 0, sizeof(p0));
             if (stand_in) {
                 hd.k = last;
                 hd.rot_prev = (c->track_rot + 2u) % 3u;      /* the buffer the last launch issued (pass last - 1) accumulated into */
                 hd.conv_sq = tp.conv_sq; hd.damping = tp.damping; hd.max_passes = tp.max_passes;
                 hd.serial = tp.serial; hd.progress = tp.progress; hd.rows = c->partials; hd.debug = tp.debug;
-                /* ... and, with a hinted successor, launch 0 of ITS optimize() (k_fuse<.., P0>): the launch the next frame would issue
-                 * first if this one ends here -- which the host learns below, before it issues anything else */
-                if (hint && c->p0_riders && last < iters) {
-                    p0.n_blocks = gsdf_track_pass_blocks(c->W, c->H, c->track_blocks);
-                    p0.rot = c->track_rot; p0.rows = c->partials; p0.debug = tp.debug;
-                }
             }
-            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint, stand_in ? &hd : nullptr, next_set, next_token,
-                                        p0.n_blocks ? &p0 : nullptr, &p0_attached);   /* main_scan_3d.cpp:261-265 */
+            const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint, stand_in ? &hd : nullptr, next_set, next_token);   /* main_scan_3d.cpp:261-265 */
             if (rc) return rc;
             fuse_queued = true;
         }
         ++batch_no;
         if (last == iters) break;                            /* the head-only launch always ends optimize() */
         int ended = follow_progress(c, tp.serial, last);
-        int ended_passes = ended > 0 ? (int)(c->progress[0] & 0x7FFFu) : 0;
         if (ended < 0) {                                     /* the device is far behind: wait for it properly */
             gsdf_dev_state s;
             if (hipMemcpyAsync(&s, c->st, sizeof(s), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                 hipStreamSynchronize(c->stream) != hipSuccess)
                 return fail(GSDF_ERR_HIP, "tracking: device state read failed");
             ended = s.done;
-            ended_passes = s.passes;
         }
-        /* the pass-0 role ran iff its launch's gate was open: optimize() ended with the head that launch performed (or earlier) AND
-         * converged -- an end before the last allowed pass is a converged one (RigidPointOptimizer.cpp:88-98) */
-        if (p0_attached && ended && ended_passes < iters) { c->p0_ran = true; c->p0_depth = hint; }
         if (ended) {
             if (fuse_after && !fuse_queued) {
                 const int rc = enqueue_fuse(c, depth_dev, unused, 1, true, fuse_set, hint, nullptr, next_set, next_token);
@@ -500,10 +464,7 @@ int gsdf_flush_pending(gsdf_ctx* c) {
     const size_t N = (size_t)c->W * c->H;
     return launch_fuse(c, c->pending.depth, c->normals + (size_t)c->pending.set * 3 * N, c->pending.pose, 0, nullptr, nullptr);
 }
-#define GSDF_FLUSH_ONLY(c) do { if ((c) && (c)->pending.valid) { const int rc_ = gsdf_flush_pending(c); if (rc_) return rc_; } } while (0)
-/* ... and, by default, an entry voids the pass-0 sums a fusion launch left for the next optimize() (gsdf_p0_cancel): only the entries
- * of the frame loop itself and the read-only ones a caller places between two frames (GSDF_FLUSH_ONLY) keep them */
-#define GSDF_FLUSH(c) do { GSDF_FLUSH_ONLY(c); gsdf_p0_cancel(c); } while (0)
+#define GSDF_FLUSH(c) do { if ((c) && (c)->pending.valid) { const int rc_ = gsdf_flush_pending(c); if (rc_) return rc_; } } while (0)
 /* The staging entries (gsdf_dev_upload*) write device memory the caller names.  A GT-pose fusion that still waits for its
  * successor reads its depth image when it is LAUNCHED, so a copy into that image has to come behind the launch: the pattern
  * upload(buf) -> update_dev(buf) -> upload(buf) -> update_dev(buf) on ONE staging buffer is correct by stream order only if
@@ -516,11 +477,6 @@ static int flush_if_overlaps(gsdf_ctx* c, const void* dst, int64_t bytes) {
         const size_t fb = (size_t)c->W * c->H * sizeof(float);
         for (const float** q : { &c->nrm_ready_depth, &c->hint_next })
             if (*q) { const uintptr_t b0 = (uintptr_t)*q; if (a0 < b0 + fb && b0 < a1) *q = nullptr; }
-    }
-    if (c && c->p0_depth) {                                  /* ... likewise the first pass a fusion launch performed on the old contents */
-        const uintptr_t a0 = (uintptr_t)dst, a1 = a0 + (uintptr_t)std::max<int64_t>(bytes, 0);
-        const uintptr_t b0 = (uintptr_t)c->p0_depth, fb = (size_t)c->W * c->H * sizeof(float);
-        if (a0 < b0 + fb && b0 < a1) gsdf_p0_cancel(c);
     }
     if (!c || !c->pending.valid) return GSDF_OK;
     const uintptr_t a0 = (uintptr_t)dst, a1 = a0 + (uintptr_t)std::max<int64_t>(bytes, 0);
@@ -591,7 +547,7 @@ int gsdf_debug_get_tile_order(gsdf_ctx* c, uint32_t* order, int* n) {
     return GSDF_OK;
 }
 int gsdf_debug_read(gsdf_ctx* c, unsigned long long out[24]) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c || !out) return GSDF_ERR_INVALID;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return GSDF_ERR_HIP;
     gsdf_dev_state h;
@@ -687,7 +643,6 @@ static int create_impl(gsdf_ctx** out, float voxel_size, float trunc_dist, int c
         if (env) c->adaptive = atoi(env);
         if ((env = getenv("GSDF_FIRST_BATCH")) && atoi(env) >= 2) c->first_batch = atoi(env);
         if ((env = getenv("GSDF_FUSE_HEAD"))) c->fuse_head = atoi(env) != 0;   /* 0: the first batch's last launch is a tracker launch again */
-        if ((env = getenv("GSDF_P0_RIDERS"))) c->p0_riders = atoi(env) != 0;   /* 0: every optimize() starts with its own launch 0 */
         if ((env = getenv("GSDF_NRM_SPLIT"))) {            /* experiments: "a" or "a,b" = per cent of the normals tiles in launch 0 (and 1) */
             int a = -1, b = -1;
             const int n = sscanf(env, "%d,%d", &a, &b);
@@ -738,7 +693,6 @@ int gsdf_reset(gsdf_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     c->pending.valid = false;                              /* a fusion that was never launched is dropped with the map */
     c->hint_next = nullptr; c->nrm_ready_depth = nullptr;  /* (gsdf_hint_next_depth_dev: a new scan starts without them) */
-    gsdf_p0_cancel(c);
     c->prev_track_serial = 0; c->prev_slow = false;
     if (c->deferred_count) HIP_TRY(hipMemsetAsync(c->deferred_count, 0, sizeof(unsigned int), c->stream));
     gsdf_launch_table_clear(c->stream, c->tab, c->n_slots);
@@ -892,7 +846,6 @@ int gsdf_update_dev(gsdf_ctx* c, const float* depth_dev, const float R[9], const
     if (rc) return rc;
     if (!depth_dev || !R || !t) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    gsdf_p0_cancel(c);                                     /* a GT-pose fusion changes the map a pass-0 role has looked at */
     if ((rc = auto_grow_step(c))) return rc;
     gsdf_pose_arg pose;
     std::memcpy(pose.R, R, sizeof(pose.R));
@@ -949,7 +902,7 @@ int gsdf_set_pose(gsdf_ctx* c, const float pose7[7]) {
 }
 
 int gsdf_get_pose(gsdf_ctx* c, float pose7[7]) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c || !pose7) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     gsdf_dev_state s;
@@ -1004,7 +957,7 @@ int gsdf_track_and_fuse_ahead_dev(gsdf_ctx* c, const float* depth_dev, const flo
 
 int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9], int num_iterations,
                             float conv_threshold, float damping) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     if (!depth_dev || !K) return fail(GSDF_ERR_INVALID, "null argument");
@@ -1020,7 +973,7 @@ int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9
 }
 
 int gsdf_read_frame_log(gsdf_ctx* c, float* rows10, int64_t max_rows, int64_t* n_rows) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     int rc = require_frame(c);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -1038,7 +991,7 @@ int gsdf_read_frame_log(gsdf_ctx* c, float* rows10, int64_t max_rows, int64_t* n
 }
 
 int gsdf_sync(gsdf_ctx* c) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     gsdf_dev_state s;
@@ -1049,7 +1002,7 @@ int gsdf_sync(gsdf_ctx* c) {
 }
 
 int gsdf_get_stats(gsdf_ctx* c, gsdf_stats* out) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c || !out) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     gsdf_dev_state s;
@@ -1074,7 +1027,7 @@ int gsdf_get_stats(gsdf_ctx* c, gsdf_stats* out) {
 }
 
 int gsdf_count(gsdf_ctx* c, int64_t* n) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c || !n) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->counter, 0, sizeof(unsigned long long), c->stream));
@@ -1670,7 +1623,7 @@ int gsdf_dev_alloc(gsdf_ctx* c, void** dev_ptr, int64_t bytes) {
     return GSDF_OK;
 }
 int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1678,7 +1631,7 @@ int gsdf_dev_free(gsdf_ctx* c, void* dev_ptr) {
     return GSDF_OK;
 }
 int gsdf_dev_download(gsdf_ctx* c, void* host_dst, const void* dev_src, int64_t bytes) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c || !host_dst || !dev_src || bytes < 0) return fail(GSDF_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(host_dst, dev_src, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1715,7 +1668,7 @@ int gsdf_dev_upload_async(gsdf_ctx* c, void* dev_dst, const void* host_src, int6
     return GSDF_OK;
 }
 int gsdf_mark(gsdf_ctx* c, int64_t* mark) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c || !mark) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     /* a mark says "the stream has passed this point" -- what a staging slot's recycling needs -- and nothing about device
@@ -1770,10 +1723,6 @@ int gsdf_dev_upload_ahead(gsdf_ctx* c, void* dev_dst, const void* host_src, int6
             const uintptr_t a0 = (uintptr_t)dev_dst, b0 = (uintptr_t)*q;
             if (a0 < b0 + (size_t)c->W * c->H * sizeof(float) && b0 < a0 + (uintptr_t)bytes) *q = nullptr;
         }
-    if (c->p0_depth) {                                                   /* ... and a first pass performed ahead on them */
-        const uintptr_t a0 = (uintptr_t)dev_dst, b0 = (uintptr_t)c->p0_depth;
-        if (a0 < b0 + (size_t)c->W * c->H * sizeof(float) && b0 < a0 + (uintptr_t)bytes) gsdf_p0_cancel(c);
-    }
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, c->copy_stream));
     hipEvent_t e = nullptr;                                      /* (a pool of their own: these keep the default fences) */
@@ -1798,14 +1747,14 @@ int gsdf_upload_wait(gsdf_ctx* c, int64_t upload) {
 }
 
 int gsdf_timer_start(gsdf_ctx* c) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c) return fail(GSDF_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     return GSDF_OK;
 }
 int gsdf_timer_stop_ms(gsdf_ctx* c, float* ms) {
-    GSDF_FLUSH_ONLY(c);
+    GSDF_FLUSH(c);
     if (!c || !ms) return fail(GSDF_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));

@@ -90,13 +90,6 @@ struct gsdf_ctx {
     int nrm_ready_set = -1;
     unsigned int prev_track_serial = 0; int prev_first_last = 0; bool prev_slow = false;   /* the last tracked frame: did it need more than its first batch (as far as the host knows)? */
     unsigned int nrm_ready_token = 0, nrm_token_ctr = 0;   /* what that fusion launch leaves in st->nrm_token when its gate was open */
-    /* k_fuse<.., P0> (round 6): the frame whose first Gauss-Newton pass (launch 0 of its optimize()) the last tracked frame's fusion
-     * launch has performed in its tail -- known to have RUN (p0_ran: that frame converged within its first batch, so the launch's
-     * gate was open) -- with the pose and the map that launch left.  Consumed by the next gsdf_track_and_fuse_dev on that depth
-     * image; every entry that changes the pose, the map or the geometry in between cancels it (gsdf_p0_cancel). */
-    bool p0_riders = false;                        /* GSDF_P0_RIDERS */
-    bool p0_ran = false;
-    const float* p0_depth = nullptr;
     float* depth_sampled = nullptr;                /* the compacted pixels of gsdf_track_sampled (sampling > 1), lazily allocated */
     void* scratch = nullptr;                       /* device scratch of gsdf_query / gsdf_get_voxels for small batches (GSDF_SCRATCH_BYTES) */
     bool occ_dirty = false;                        /* blocks may have been inserted since the raycaster's filters (gsdf_table::occ) were built */
@@ -179,15 +172,5 @@ struct gsdf_ctx {
         return nc;
     }
 };
-
-/* The sums a fusion launch's pass-0 role left for the next optimize() are void (another pose, another map, another frame): the
- * buffer they lie in is skipped -- launch j accumulates into buffer j % 3 and expects it cleared by launch j - 1; the role acted as
- * one launch (it also cleared the following buffer), so counting it as issued keeps the rotation consistent. */
-inline void gsdf_p0_cancel(gsdf_ctx* c) {
-    if (!c) return;
-    if (c->p0_ran) c->track_rot = (c->track_rot + 1u) % 3u;
-    c->p0_ran = false;
-    c->p0_depth = nullptr;
-}
 
 #endif /* GSDF_CTX_H_ */

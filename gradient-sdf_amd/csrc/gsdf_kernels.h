@@ -11,7 +11,6 @@
 
 #define GSDF_STATUS_TABLE_FULL 1
 #define GSDF_STATUS_KEY_RANGE  2
-#define GSDF_STATUS_RIDER_TIMEOUT 8  /* k_fuse<.., P0>: a pass-0 rider gave up waiting for the end of the fusion it rides on; the next optimize() started from incomplete sums */
 #define GSDF_STATUS_TRACK_ABORT 4   /* k_track_all: the workgroups of the one-launch optimize() were not co-resident (GPU shared with another process) */
 
 #ifndef GSDF_TRACK_BLOCK
@@ -63,9 +62,6 @@ struct gsdf_dev_state {
      * {tag, qz, qw, passes} */
     unsigned int fh[12] __attribute__((aligned(16)));
     unsigned int nrm_token;       /* gsdf_hint_next_depth_dev: token of the frame whose normals a fusion launch computed in its tail */
-    unsigned int map_ready;       /* tag of the newest fusion launch whose last workgroup has added the launch's deferred list: from then on
-                                     the map is the reference's map after update() (what the pass-0 riders of that launch wait for) */
-    unsigned int p0_expired;      /* pass-0 rider workgroups whose wait for map_ready expired (never seen; GSDF_STATUS_RIDER_TIMEOUT) */
 };
 
 struct gsdf_frame_geom {
@@ -112,14 +108,6 @@ struct gsdf_fuse_head {
     int debug;
 };
 /* use_dev_pose: take R,t from st->R / st->pose7 and skip the launch unless st->converged */
-/* The NEXT frame's first Gauss-Newton pass (launch 0 of its optimize(): gather + sums, no head) performed by extra workgroups at
- * the end of THIS frame's fusion launch (k_fuse<.., P0>, round 6): n_blocks = 0 none */
-struct gsdf_fuse_pass0 {
-    int n_blocks;                 /* tracker workgroups (as gsdf_launch_track_pass would launch for this geometry) */
-    unsigned int rot;             /* gsdf_track_params::rot of the launch they stand in for */
-    double* rows;                 /* the partial-sum buffers */
-    int debug;
-};
 void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache& nc, const float* depth,
                       const float* nx, const float* ny, const float* nz, const gsdf_pose_arg& pose,
                       int use_dev_pose, gsdf_table tab, gsdf_dev_state* st,
@@ -140,9 +128,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       float* next_nx, float* next_ny, float* next_nz /* ... into these planes */, int win,
                       const uint32_t* tile_stats /* this frame's tile statistics (written with its normals) */,
                       uint32_t* next_tile_stats /* the next frame's, written by the launch's normals workgroups */,
-                      unsigned int next_token /* tracked frames: left in st->nrm_token by the normals role when it ran */,
-                      const gsdf_fuse_pass0* pass0 = nullptr /* nullable: pass 0 of optimize(next_depth) too (needs head, next_depth, no resolve) */);
-int gsdf_track_pass_blocks(int W, int H, int cap);   /* workgroups gsdf_launch_track_pass uses for a pass over W x H pixels */
+                      unsigned int next_token /* tracked frames: left in st->nrm_token by the normals role when it ran */);
 int  gsdf_fuse_grid_blocks(int W, int H);
 void gsdf_fuse_tile_order(int W, int H, uint32_t* order_host /* [gsdf_fuse_grid_blocks] */);
 /* per-launch parameters of one Gauss-Newton pass (RigidOptimizer.h:57-62) */

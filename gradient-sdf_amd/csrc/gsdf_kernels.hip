@@ -556,8 +556,6 @@ struct fuse_args {
     int nrm_r, nrm_ntx;                 /* window radius, normals tiles per image row */
     gsdf_fuse_head hd;                  /* k_fuse<.., HEAD>: the closing head of optimize() this launch performs first (k = 0: none) */
     unsigned int nrm_token;             /* tracked frames: what the normals role leaves in st->nrm_token when it ran (never 0) */
-    int p0_first;                       /* k_fuse<.., P0>: first workgroup of the pass-0 role (behind the tiles and the normals tiles) */
-    gsdf_fuse_pass0 p0;
 };
 #define FUSE_RESOLVE_INLINE 8192u       /* deferred entries the last workgroup adds itself even when a resolve launch follows */
 
@@ -787,32 +785,11 @@ __device__ __forceinline__ void fuse_head(const fuse_args& a, int tid, bool solv
  * once per workgroup.  Workgroup 0 is dispatched first and waits for nobody; the wait of the others is bounded, and a wave whose
  * wait expires performs the head itself (bit-identical).  If optimize() has not ended with that head, every workgroup leaves,
  * and the host's next batch starts with a tracker launch that skips its head (gsdf_track_params::head_done). */
-/* P0 (round 6, VERDICT r5 #2c): further workgroups behind the normals tiles perform launch 0 of the NEXT frame's optimize() -- the
- * gather and the 29 sums of its first Gauss-Newton pass (no head), which starts from the pose this fusion uses.  They load their
- * pixels' depth, then wait until the launch's last workgroup has added the deferred list (st->map_ready == tag: the map is the
- * reference's map after update()), acquire, gather and add their sums to the buffer launch 0 would have used.  They are the last
- * workgroups of the grid: every tile has been dispatched before the first of them, so they wait for nobody who waits for a slot.
- * The next frame's host code then starts with launch 1 (its head finishes this pass); it knows whether the role ran (the fusion's
- * gate = the closing head's result, which it follows anyway).  Saves the next frame a launch and a kernel boundary, and the
- * depth round trip of that launch hides under the fusion's tail. */
-__device__ __forceinline__ void fuse_pass0(const fuse_args& a, float (*wsum)[32], int b, const float (&pose)[7]);
-
-template <int LCAP, bool NEXT_NORMALS, bool HEAD, bool P0 = false>
+template <int LCAP, bool NEXT_NORMALS, bool HEAD>
 __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
     __shared__ fuse_lds<LCAP> L;
     const int tid = threadIdx.x;
     FUSE_SETPRIO(FUSE_PRIO_START);
-    if constexpr (P0) {
-        static_assert(NEXT_NORMALS && HEAD, "the pass-0 role rides on the launch that performs the closing head and the next frame's normals");
-        if ((int)blockIdx.x >= a.p0_first) {
-            float pose[7];
-            int hd_ = 0, hc_ = 0;
-            fuse_head(a, tid, false, pose, hd_, hc_);
-            if (!(__builtin_amdgcn_readfirstlane(hd_) && __builtin_amdgcn_readfirstlane(hc_))) return;     /* no fusion, no new map: launch 0 is queued as ever */
-            fuse_pass0(a, reinterpret_cast<float(*)[32]>(&L), (int)blockIdx.x - a.p0_first, pose);
-            return;
-        }
-    }
     if constexpr (NEXT_NORMALS && FUSE_CARRIES_NORMALS) {
     if ((int)blockIdx.x >= a.n_tiles) {                       /* the next frame's normals, in the tail of this launch */
         static_assert(sizeof(nrm_lds) <= sizeof(fuse_lds<LCAP>), "the normals tile works in the fusion table's LDS");
@@ -1542,13 +1519,6 @@ __global__ FUSE_BOUNDS void k_fuse(fuse_args a) {
             unsafeAtomicAdd(&d.p->gy, d.gy);
             unsafeAtomicAdd(&d.p->gz, d.gz);
         }
-    if constexpr (P0) {
-        /* the map is final (the host attaches the pass-0 role only to launches without a k_fuse_resolve behind them: mine == true):
-         * every lane releases its atomics, then one store tells the riders */
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid == 0 && mine) __hip_atomic_store(&a.st->map_ready, a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (tid == 0) {
         if (mine) { a.st->n_deferred += n; __hip_atomic_store(a.deferred_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         a.st->last_deferred = n;
@@ -1602,7 +1572,7 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
                       long long max_rows, uint32_t* vis, int vis_words, int debug, unsigned int* ticket, int resolve_follows,
                       unsigned int* host_note, int far_table, const gsdf_fuse_head* head, const float* next_depth, float* next_nx,
                       float* next_ny, float* next_nz, int win, const uint32_t* tile_stats, uint32_t* next_tile_stats,
-                      unsigned int next_token, const gsdf_fuse_pass0* pass0) {
+                      unsigned int next_token) {
     fuse_args a;
     a.tile_stats = tile_stats; a.nrm_stats = next_tile_stats;
     a.host_note = host_note;
@@ -1626,14 +1596,9 @@ void gsdf_launch_fuse(hipStream_t s, const gsdf_frame_geom& g, const gsdf_ncache
     }
     std::memset(&a.hd, 0, sizeof(a.hd));
     a.nrm_token = next_token;
-    a.p0_first = n + extra;
-    std::memset(&a.p0, 0, sizeof(a.p0));
     if (head && use_dev_pose && head->k > 0) {
         a.hd = *head;
-        if (extra && pass0 && pass0->n_blocks > 0 && !far_table && !resolve_follows && FUSE_THREADS == GSDF_TRACK_BLOCK) {
-            a.p0 = *pass0;
-            hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, true, true, true>), dim3(n + extra + pass0->n_blocks), dim3(FUSE_THREADS), 0, s, a);
-        } else if (extra) {
+        if (extra) {
             if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, true, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
             else hipLaunchKernelGGL((k_fuse<FUSE_LCAP_NEAR, true, true>), dim3(n + extra), dim3(FUSE_THREADS), 0, s, a);
         } else if (far_table) hipLaunchKernelGGL((k_fuse<FUSE_LCAP_FAR, false, true>), dim3(n), dim3(FUSE_THREADS), 0, s, a);
@@ -1974,88 +1939,6 @@ __device__ __forceinline__ void trk_gather(const gsdf_frame_geom& g, const gsdf_
     }
 }
 
-/* k_fuse<.., P0>: launch 0 of the next frame's optimize() (see k_fuse).  Pixels -> lanes, buffers and the reduction are those of
- * k_track_pass with pass_index 0 and rot = a.p0.rot; the depth image is the next frame's (a.nrm_depth), the pose the one this
- * fusion launch uses (the closing head's). */
-__device__ __forceinline__ void fuse_pass0(const fuse_args& a, float (*wsum)[32], int b, const float (&pose_in)[7]) {
-    static_assert(FUSE_THREADS == GSDF_TRACK_BLOCK || !(FUSE_T == 16 && FUSE_TH == 16), "the pass-0 role runs in tracker-sized workgroups");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const gsdf_frame_geom& g = a.g;
-    const float* __restrict__ depth = a.nrm_depth;
-    const bool heavy = wave < GSDF_TRACK_BLOCK / 128;
-    const int pix0 = b * TRK_CHUNK + (heavy ? wave * (64 * TRK_PPT) : (GSDF_TRACK_BLOCK / 128) * 64 * TRK_PPT + (wave - GSDF_TRACK_BLOCK / 128) * (64 * (TRK_PPT - 1))) + lane;
-    const int batch = a.p0.n_blocks * TRK_CHUNK;
-    float z_pre[TRK_PPT];
-    {
-        const int N = g.W * g.H;
-#pragma unroll
-        for (int j = 0; j < TRK_PPT; ++j) {
-            const int pix = pix0 + j * 64;
-            z_pre[j] = (pix < N && (heavy || j < TRK_PPT - 1)) ? depth[pix] : 0.f;
-        }
-    }
-    double* acc_cur = a.p0.rows + (size_t)(a.p0.rot % 3u) * GSDF_TRACK_ROWSET;
-    if (b == 0) {
-        double* nxt = a.p0.rows + (size_t)((a.p0.rot + 1u) % 3u) * GSDF_TRACK_ROWSET;
-        for (int i = tid; i < GSDF_TRACK_ROWSET; i += GSDF_TRACK_BLOCK) nxt[i] = 0.0;
-    }
-    float pose[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) pose[i] = pose_in[i];
-    /* the fusion's last workgroup: every tile flushed, the deferred list added.  ONE wave per workgroup watches the word (1920
-     * waves polling one address with agent-scope loads, and as many L2 invalidations behind it, cost the launch 10 us: measured)
-     * and acquires for the workgroup -- the vector L1 belongs to the CU, the L2 to the XCD --, the others meet it at a barrier.
-     * 100 ms at 100 MHz bound the wait (never seen; a workgroup that gives up contributes nothing and says so:
-     * GSDF_STATUS_RIDER_TIMEOUT fails the next synchronising call) */
-    int* ok_flag = reinterpret_cast<int*>(&wsum[GSDF_TRACK_BLOCK / 64][0]);
-    if (wave == 0) {
-        bool ready = true;
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(&a.st->map_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.tag) {
-            if (wall_clock64() - t0 > 10000000ull) { ready = false; break; }
-            __builtin_amdgcn_s_sleep(16);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (lane == 0) *ok_flag = ready ? 1 : 0;
-    }
-    __syncthreads();
-    const bool ok = *ok_flag != 0;
-    __syncthreads();                                     /* (wsum is written below) */
-    float acc[GSDF_TRACK_NSUM];
-#pragma unroll
-    for (int i = 0; i < GSDF_TRACK_NSUM; ++i) acc[i] = 0.f;
-    if (ok) {
-        if (heavy) trk_gather<TRK_PPT>(g, a.tab, depth, z_pre, pose, pix0, 64, batch, acc);
-        else trk_gather<TRK_PPT - 1>(g, a.tab, depth, z_pre, pose, pix0, 64, batch, acc);
-    } else if (tid == 0) {
-        atomicAdd(&a.st->p0_expired, 1u);
-        atomicOr(&a.st->status, GSDF_STATUS_RIDER_TIMEOUT);
-    }
-    wave_sum_to_lane63(acc);
-    if (lane == 63) {
-#pragma unroll
-        for (int i = 0; i < GSDF_TRACK_NSUM; ++i) wsum[wave][i] = acc[i];
-    }
-    __syncthreads();
-    if (tid < 32) {
-        float v = 0.f;
-        if (tid < GSDF_TRACK_NSUM) {
-            v = wsum[0][tid];
-#pragma unroll
-            for (int w = 1; w < GSDF_TRACK_BLOCK / 64; ++w) v += wsum[w][tid];
-        }
-        if (tid < GSDF_TRACK_NSUM) unsafeAtomicAdd(&acc_cur[(b % GSDF_TRACK_GROUPS) * 32 + tid], (double)v);
-    }
-    if (b == 0 && tid == 0) {
-        /* what launch 0 leaves for the head of launch 1 (st->done / converged / passes stay the finished frame's: this launch's last
-         * workgroup still logs them, and every head of the next optimize() rewrites them before a gate reads them) */
-        gsdf_trk_buf& o = a.st->trk[0];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) o.pose7[i] = pose[i];
-        o.done = 0; o.converged = 0; o.passes = 0;
-    }
-}
-
 static_assert(GSDF_TRACK_BLOCK == NRM_THREADS, "the normals tiles of the first pass run in tracker-sized workgroups");
 /* SAMPLED: optimize_sampled(depth, K, sampling > 1) -- the public stride argument of RigidPointOptimizer.h:65.  g.W x g.H is
  * the grid of sampled pixels (ceil(W / s) x ceil(H / s)), `depth` its compacted image (k_subsample), tp.sampling the stride.
@@ -2241,19 +2124,16 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
     if (trk_tr && threadIdx.x == 0) trk_tr[3] = wall_clock64();
 }
 int gsdf_normals_tiles(int W, int H) { return ((W + NRM_TX - 1) / NRM_TX) * ((H + NRM_TY - 1) / NRM_TY); }
-/* one chunk of TRK_CHUNK pixels per workgroup while the grid allows it (640 x 480: 240 workgroups), more by looping -- and then the
- * same number of chunks for every workgroup (1280 x 960: 480 x 2, not 512 x 1.9) */
-int gsdf_track_pass_blocks(int W, int H, int cap) {
-    const int chunks = std::max(1, (W * H + TRK_CHUNK - 1) / TRK_CHUNK);
-    cap = std::max(1, cap);
-    const int per = (chunks + cap - 1) / cap;
-    return (chunks + per - 1) / per;
-}
 void gsdf_launch_track_pass(hipStream_t s, const gsdf_frame_geom& g, const float* depth, gsdf_table tab,
                             gsdf_dev_state* st, double* partials, int n_blocks, const gsdf_track_params& tp_in,
                             const gsdf_normals_job* normals) {
     gsdf_track_params tp = tp_in;
-    n_blocks = gsdf_track_pass_blocks(g.W, g.H, n_blocks);
+    /* one chunk of TRK_CHUNK pixels per workgroup while the grid allows it (640 x 480: 240 workgroups), more by looping */
+    {                                   /* ... and then the same number of chunks for every workgroup (1280 x 960: 480 x 2, not 512 x 1.9) */
+        const int chunks = std::max(1, (g.W * g.H + TRK_CHUNK - 1) / TRK_CHUNK), cap = std::max(1, n_blocks);
+        const int per = (chunks + cap - 1) / cap;
+        n_blocks = (chunks + per - 1) / per;
+    }
     /* the launch behind the last pass only finishes it (head: reduce, solve, publish): one workgroup does -- workgroup 0 is the
      * one that publishes; the others would solve the same system and return */
     if (tp.pass_index >= tp.max_passes && !normals) n_blocks = 1;

@@ -229,7 +229,6 @@ unsigned long long random_token(const gsdf_ctx* c) {
 int merge_impl(gsdf_ctx* c, transport& tr, int64_t* n_blocks_out, int64_t* bytes_out) {
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = gsdf_flush_pending(c)) return rc;            /* the last frame's fusion may still wait for a successor (gsdf_update_dev) */
-    gsdf_p0_cancel(c);                                        /* (the map changes under a first pass performed ahead) */
     if (c->merged && tr.nranks > 1)
         return gsdf_fail(GSDF_ERR_INVALID, "gsdf_merge_allreduce: this map already holds the sum of all ranks (the exchange is one-shot: "
                                            "a second one would count every rank's frames again); gsdf_reset starts over");
@@ -582,7 +581,6 @@ int gsdf_merge_from(gsdf_ctx* dst, gsdf_ctx* src) {
     HIP_TRY(hipSetDevice(dst->device));
     if (int rc = gsdf_flush_pending(src)) return rc;
     if (int rc = gsdf_flush_pending(dst)) return rc;
-    gsdf_p0_cancel(dst);
     /* the blocks both maps hold, counted behind everything queued on their streams and read with the state words */
     gsdf_dev_state ss, ds;
     unsigned long long n_src = 0, n_dst = 0;

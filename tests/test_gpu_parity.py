@@ -1392,77 +1392,3 @@ def test_no_frame_is_lost_when_contexts_share_the_gpu(pkg, O):
             assert n_frames == frames_a and abs(int(n_upd) - int(n_upd_a)) <= 500   # every converged frame fused, every tile of it
             assert np.abs(log[:, :7] - log_a[:, :7]).max() <= 1e-5
             assert abs(len(keys) - len(keys_a)) <= 1e-4 * len(keys_a)
-
-
-@pytest.mark.gpu
-def test_first_pass_inside_the_previous_fusion_launch_is_invisible(pkg, O, monkeypatch):
-    """VERDICT r5 #2c (round 6): with a hinted successor the frame's first gated fusion launch also performs launch 0 of the NEXT
-    optimize() -- the gather and the 29 sums of its first pass, by extra workgroups that wait for the launch's last workgroup
-    (k_fuse<.., P0>; GSDF_P0_RIDERS=1) -- and the next frame starts with launch 1.  Same function (trk_gather) on the same pose, map
-    and depth image, so pass counts, flags, poses and the map must be what they are without it (GSDF_P0_RIDERS=0), on a stretch with
-    frames that converge in 3-4 passes, late, and never -- and whatever the caller does between two frames: nothing; the hint
-    withdrawn; another frame than the hinted one; the pose set anew; a GT-pose update in between; a plain optimize() in between;
-    the hinted image overwritten."""
-    W, H = 640, 480
-    n = 48
-    seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=0)
-    vs = np.float32(0.01)
-    frames = [seq.frame(i) for i in range(n)]
-
-    def run(p0, script):
-        monkeypatch.setenv("GSDF_P0_RIDERS", p0)
-        g = pkg.GradSdf(vs, np.float32(10) * vs, W, H, seq.K, capacity_log2=22)
-        d0, R0, t0 = frames[0]
-        p = pose7_from(O, R0, t0)
-        g.update(d0, O.quat_to_R(p[3:]), t0)
-        g.set_pose(p)
-        dev = [g.upload(f[0]) for f in frames]
-        spare = g.upload(frames[5][0])
-        extra = []
-        for i in range(1, n):
-            nxt = dev[i + 1] if i + 1 < n else None
-            what = script.get(i, "")
-            if nxt is not None and what != "nohint":
-                g.hint_next_depth(dev[2] if what == "wronghint" else nxt)
-            g.track_and_fuse_dev(dev[i])
-            if what == "withdraw":
-                g.hint_next_depth(None)
-            elif what == "setpose":
-                g.sync()
-                g.set_pose(g.get_pose())                       # the same pose: results stay comparable, the role's sums are void
-            elif what == "update":
-                gt = frames[i]
-                g.update_dev(spare, gt[1], gt[2])              # a GT-pose fusion between two tracked frames
-            elif what == "track":
-                c, pz, ps = g.track(frames[i][0], g.get_pose(), iters=2)     # a plain optimize() (it moves the pose: set it back)
-                extra.append((c, ps))
-            elif what == "overwrite" and nxt is not None:
-                nxt_host = np.ascontiguousarray(frames[i + 1][0], np.float32)      # same contents, but the library cannot know
-                g._chk(g.L.gsdf_dev_upload(g.h, nxt, nxt_host.ctypes.data_as(ctypes.c_void_p), nxt_host.nbytes))
-        g.sync()
-        log = g.frame_log().copy()
-        keys, pay = g.export(sorted=True)
-        st = g.stats()
-        g.close()
-        return log, keys, pay, st, extra
-
-    scripts = {
-        "plain": {},
-        "disturbed": {3: "withdraw", 5: "wronghint", 7: "setpose", 9: "update", 12: "overwrite", 14: "nohint", 16: "track", 20: "setpose", 30: "update"},
-    }
-    bad = []
-    for name, script in scripts.items():
-        la, ka, pa, sa, ea = run("0", script)
-        conv = la[:, 7] != 0
-        assert 0 < conv.sum() < len(conv) and la[:, 8].max() == 25 and la[:, 8].min() <= 4
-        lb, kb, pb, sb, eb = run("1", script)
-        same_flags = bool(la.shape == lb.shape and np.array_equal(la[:, 7:10], lb[:, 7:10]))
-        dpose = float(np.abs(la[:, :7] - lb[:, :7]).max()) if la.shape == lb.shape else float("nan")
-        same_keys = bool(ka.shape == kb.shape and np.array_equal(ka, kb))
-        dpay = float(np.abs(pa - pb).max()) if same_keys else float("nan")
-        print("MEASURED %s: flags / passes / hits equal %s, pose diff max %.2e, keys equal %s, sums diff %.2e, frames %d / %d, n_upd equal %s"
-              % (name, same_flags, dpose, same_keys, dpay, sa["frames"], sb["frames"], sa["n_upd"] == sb["n_upd"]))
-        if not (same_flags and dpose <= 1e-6 and same_keys and dpay <= 1e-5 * max(1.0, float(np.abs(pa).max())) and
-                sa["frames"] == sb["frames"] and sa["n_upd"] == sb["n_upd"] and ea == eb):
-            bad.append(name)
-    assert not bad, bad
