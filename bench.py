@@ -395,8 +395,17 @@ def main():
                 start_uploads(j + AHEAD, stt)
                 tb = time.perf_counter()
                 g._chk(Lb.gsdf_upload_wait(g.h, ids.pop(j)))
+                # the next frame's copy was started AHEAD - 1 frames ago: once it is known to be over (a host-side look, normally no
+                # wait) the frame can be named ahead like a resident one (gsdf_hint_next_depth_dev's contract: the image is in place)
+                nxt_dev = None
+                if NEXT_HINT and j + 1 < K and (j + 1) in ids:
+                    g._chk(Lb.gsdf_upload_wait(g.h, ids[j + 1]))
+                    nxt_dev = slots[(j + 1) % S_SLOTS]
                 tc = time.perf_counter()
-                g.track_and_fuse_dev(slots[j % S_SLOTS])
+                if nxt_dev is not None:
+                    g.track_and_fuse_ahead_dev(slots[j % S_SLOTS], nxt_dev)
+                else:
+                    g.track_and_fuse_dev(slots[j % S_SLOTS])
                 td = time.perf_counter()
                 # A mark is an event on the kernels' stream -- a packet between this frame's fusion and the next frame's first
                 # tracker pass -- so one is recorded every MARK_EVERY frames only and releases all the slots submitted since the

@@ -155,6 +155,18 @@ const float* FramePipeline::next(size_t* index) {
     last_slot_ = (long)(f % slots_.size());
     ++next_deliver_;
     if (index) *index = f;
+    /* the successor, if its copy has been started (it then is at most microseconds from done: the copy stream runs ahead) */
+    next_ready_ = nullptr;
+    if (f + 1 < entries_.size()) {
+        int64_t up = 0;
+        const float* d = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            const Slot& n = slots_[(f + 1) % slots_.size()];
+            if (n.state == UPLOADING && n.frame == f + 1) { up = n.upload; d = n.dev; }
+        }
+        if (d && gsdf_upload_wait(ctx_, up) == GSDF_OK) next_ready_ = d;
+    }
     return s.dev;
 }
 

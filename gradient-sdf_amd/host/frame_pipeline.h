@@ -37,6 +37,10 @@ public:
     /* Next frame: waits for its decode, enqueues the host->HBM copy, returns the DEVICE pointer of its depth image
      * (nullptr: no more frames, or the frame could not be read -- error() tells).  index = position in `entries`. */
     const float* next(size_t* index);
+    /* The frame AFTER the one the last next() returned, if its copy into HBM is known to be over (it was started frames ago; a
+     * host-side look, no wait) -- else nullptr.  What gsdf_hint_next_depth_dev / gsdf_track_and_fuse_ahead_dev want to be told:
+     * the current frame's fusion launch then computes that frame's normals in its tail.  Stays valid until the next next(). */
+    const float* next_ready() const { return next_ready_; }
     /* The kernels that read the frame returned by the last next() have been enqueued: its slot may be recycled once the
      * stream has passed this point. */
     bool submitted();
@@ -65,6 +69,7 @@ private:
     size_t next_upload_ = 0;     /* next frame whose copy has not been started */
     int64_t last_upload_ = 0;    /* id of the copy started last */
     long last_slot_ = -1;
+    const float* next_ready_ = nullptr;
     bool stop_ = false;
     std::string error_;          /* written and read by the consumer thread only (decode errors wait in their slot) */
 };

@@ -382,7 +382,8 @@ int run(int, char**, Options& opt) {
                     rc = gsdf_update_dev(ctx, d, R.data(), t.data());                                  /* :242-243, :252 */
                     if (lead) T.toc("Integrate depth data into Sdf");
                 } else {
-                    rc = gsdf_track_and_fuse_dev(ctx, d, K.data(), pOpt->num_iterations(), pOpt->conv_threshold(), pOpt->damping());   /* :258-265 */
+                    /* :258-265; the successor is named when its image is already in HBM (normals in this frame's fusion tail) */
+                    rc = gsdf_track_and_fuse_ahead_dev(ctx, d, pipe.next_ready(), K.data(), pOpt->num_iterations(), pOpt->conv_threshold(), pOpt->damping());
                     if (lead) T.toc("Point optimization + integration (enqueued)");
                 }
                 if (rc != GSDF_OK || !pipe.submitted()) { std::cerr << "frame " << i << ": " << gsdf_last_error() << std::endl; return 1; }
