@@ -2035,6 +2035,22 @@ __global__ __launch_bounds__(GSDF_TRACK_BLOCK, 4) void k_track_pass(gsdf_frame_g
          * them, and is rare), `v_readlane` hands the 29 totals to every lane, the solve runs without an LDS stage; the
          * other waves meet it at ONE barrier (two LDS stages behind three barriers before). */
         const gsdf_trk_buf& in = st->trk[(k - 1) & 1];
+        if (GSDF_EXPERIMENT(tp.debug, 8) && wave != 0) {
+            /* experiment (test build, tracker debug bit 8; tools/track_waves.py warm): while wave 0 solves, the other waves run the
+             * gather of their pixels with the OLD pose and throw the sums away -- a pass moves the pose by a fraction of a voxel, so
+             * the key-array entries and most record lines of the real gather are then in this XCD's L2 (every launch starts with the
+             * L2 invalidated: FETCH ~ algorithmic bytes).  Does the real gather get shorter? */
+            float pose_old[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) pose_old[i] = in.pose7[i];
+            float dummy[GSDF_TRACK_NSUM];
+#pragma unroll
+            for (int i = 0; i < GSDF_TRACK_NSUM; ++i) dummy[i] = 0.f;
+            const int xy_scale_w = SAMPLED ? tp.sampling : 1;
+            if (trk_heavy) trk_gather<TRK_PPT>(g, tab, depth, z_pre, pose_old, trk_pix0, 64, trk_batch, dummy, nullptr, xy_scale_w);
+            else trk_gather<TRK_PPT - 1>(g, tab, depth, z_pre, pose_old, trk_pix0, 64, trk_batch, dummy, nullptr, xy_scale_w);
+            if (dummy[28] == -1.f) st->dbg[20] = 1ull;                    /* (never: a count; keeps the loads alive) */
+        }
         if (wave == 0) {
             double gs = 0.0;
             if (lane < GSDF_TRACK_NSUM) {

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Per-WAVE gather times of the tracker passes of one frame (test build, tracker debug bit 64): which waves are slow, and
 whether that goes with their pixels (valid / hit counts), their place in the image or the block lookups.
-usage: track_waves.py [frame (default 20)]"""
+usage: track_waves.py [frame (default 20)] [warm]      warm: tracker debug bit 8 -- waves 1-7 run their gather with the old pose under
+the head's solve (an L2 warm-up experiment of round 6); the per-wave-index medians show whether the real gather gets shorter"""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as G
 pkg = G.package()
 last = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+warm = len(sys.argv) > 2 and sys.argv[2] == "warm"
 n = last + 1
 seq = pkg.synth.Sequence("tum", 640, 480, n_frames=n, seed=0)
 vs = np.float32(0.01); T = np.float32(10) * vs
@@ -21,7 +23,7 @@ g.set_pose(np.concatenate([t0, pkg.synth.R_to_quat_np(R0)]).astype(np.float32))
 for i in range(1, n - 1):
     g.track_and_fuse_dev(dev[i])
 g.sync()
-g.debug_flags(64 | (64 << 16))
+g.debug_flags(64 | ((64 | (8 if warm else 0)) << 16))
 g.track_and_fuse_dev(dev[n - 1])
 g.sync()
 NW = 8192
@@ -51,6 +53,9 @@ for p in range(1, 4):
     heavy = np.tile(np.arange(8) < 4, NWG)
     print("        waves 0-3 (3 pixels per lane) %.2f med / %.2f p95 / %.2f max, waves 4-7 (2 pixels per lane) %.2f med / %.2f p95 / %.2f max" % (
         np.median(tot[heavy]), np.percentile(tot[heavy], 95), tot[heavy].max(), np.median(tot[~heavy]), np.percentile(tot[~heavy], 95), tot[~heavy].max()))
+    by_wave = tot.reshape(NWG, 8)
+    print("        median gather by wave index 0..7: %s us; launch: head done -> last gather done (thread 0 stamps) %.2f us median over workgroups" % (
+        np.median(by_wave, axis=0).round(2).tolist(), float(np.median((rows[:, 2].astype(np.float64) - rows[:, 1].astype(np.float64)) / 100.0))))
     per_wg_max = tot.reshape(NWG, 8).max(axis=1)
     print("        slowest wave per workgroup: %.2f med / %.2f max; workgroups whose slowest wave is > 1.3x their median wave: %d" % (
         np.median(per_wg_max), per_wg_max.max(), int((per_wg_max > 1.3 * np.median(tot.reshape(NWG, 8), axis=1)).sum())))
