@@ -79,7 +79,11 @@ struct ba_args {
     float trunc_sq;
     const uint32_t* gate_list;      /* nullable: slots of the voxels with |dist| <= vs, in slot order (gsdf_ba_compact) */
     const unsigned long long* gate_count;
+    void* mean_cache;               /* nullable: ba_mean per entry of gate_list (see gsdf_ba_dev) */
 };
+/* what the first loop of getEnergy / solvePose finds for a voxel: the mean intensity over the keyframes it is seen in (already
+ * scaled by 1 / Nj), their number and their set */
+struct __attribute__((aligned(8))) ba_mean { float mx, my, mz; int nj; unsigned long long seen; };
 static_assert(sizeof(ba_args) == sizeof(gsdf_ba_dev), "ba_args mirrors gsdf_ba_dev (the launchers memcpy one into the other)");
 
 struct ba_voxel { float dist, w; gsdf_v3 grad, gn, c; };
@@ -196,36 +200,44 @@ __device__ __forceinline__ void ba_wave_sum_to_lane63(float (&v)[N]) {
 /* ---- getEnergy ---- */
 /* block_E: [3][gridDim.x] -- the workgroup's energy, its voxels that took part (|dist| <= vs, seen by >= 1 keyframe) and their
  * observations (voxel x keyframe pairs that project into the image): the counts are the units of the sweep's algorithmic bytes */
+template <bool WRITE_MEAN>
 __global__ __launch_bounds__(256) void k_ba_energy(ba_args a, double* block_E) {
     __shared__ double red[3][4];
     double E = 0.0;
     unsigned int n_act = 0u, n_obs = 0u;
     const size_t stride = (size_t)gridDim.x * 256;
     const size_t n_items = a.gate_list ? (size_t)*a.gate_count : a.n_slots;
+    ba_mean* const mc = WRITE_MEAN ? static_cast<ba_mean*>(a.mean_cache) : nullptr;      /* (WRITE_MEAN: the gate list is in use) */
     for (size_t item = (size_t)blockIdx.x * 256 + threadIdx.x; item < n_items; item += stride) {
         const size_t slot = a.gate_list ? (size_t)a.gate_list[item] : item;
         ba_voxel v;
-        if (!ba_load_voxel(a, slot, &v)) continue;
-        if (fabsf(v.dist) > a.vs) continue;                                   /* :285 */
+        bool ok = ba_load_voxel(a, slot, &v);
+        ok = ok && !(fabsf(v.dist) > a.vs);                                   /* :285 */
         gsdf_v3 mean = { 0.f, 0.f, 0.f };
         int Nj = 0;
-        for (int i = 0; i < a.n; ++i) {
-            if (!ba_visible(a, slot, i)) continue;
-            gsdf_v3 p; float m, n;
-            if (!ba_project(a, v, i, &p, &m, &n)) continue;
-            const ba_img im = { a.W, a.H, a.images + (size_t)i * a.W * a.H * 3 };
-            const gsdf_v3 A = ba_interp(n, m, im);
-            mean = gsdf_v3{ mean.x + A.x, mean.y + A.y, mean.z + A.z };
-            ++Nj;
+        unsigned long long seen = 0ull;
+        if (ok)
+            for (int i = 0; i < a.n; ++i) {
+                if (!ba_visible(a, slot, i)) continue;
+                gsdf_v3 p; float m, n;
+                if (!ba_project(a, v, i, &p, &m, &n)) continue;
+                const ba_img im = { a.W, a.H, a.images + (size_t)i * a.W * a.H * 3 };
+                const gsdf_v3 A = ba_interp(n, m, im);
+                mean = gsdf_v3{ mean.x + A.x, mean.y + A.y, mean.z + A.z };
+                ++Nj;
+                seen |= 1ull << (i & 63);
+            }
+        if (Nj) {
+            const float inv = (float)(1. / (double)(float)Nj);
+            mean = gsdf_v3{ inv * mean.x, inv * mean.y, inv * mean.z };
         }
+        if (WRITE_MEAN) mc[item] = ba_mean{ mean.x, mean.y, mean.z, Nj, seen };
         if (!Nj) continue;
         n_act += 1u; n_obs += (unsigned int)Nj;
-        const float inv = (float)(1. / (double)(float)Nj);
-        mean = gsdf_v3{ inv * mean.x, inv * mean.y, inv * mean.z };
         for (int i = 0; i < a.n; ++i) {                                        /* second sweep: same samples */
-            if (!ba_visible(a, slot, i)) continue;
+            if (!((seen >> (i & 63)) & 1ull)) continue;
             gsdf_v3 p; float m, n;
-            if (!ba_project(a, v, i, &p, &m, &n)) continue;
+            ba_project(a, v, i, &p, &m, &n);
             const ba_img im = { a.W, a.H, a.images + (size_t)i * a.W * a.H * 3 };
             const gsdf_v3 A = ba_interp(n, m, im);
             const gsdf_v3 r = { A.x - mean.x, A.y - mean.y, A.z - mean.z };
@@ -310,6 +322,13 @@ __global__ __launch_bounds__(BA_DIST_THREADS) void k_ba_dist(ba_args a, float da
 #ifndef BA_POSE_SLICES
 #define BA_POSE_SLICES 2
 #endif
+/* CACHED (round 6): the first loop -- the voxel's mean intensity over its keyframes, their number and set -- is what the energy
+ * sweep in front of this one computed at the very same state (gsdf_ba_optimize: getEnergy always precedes solvePose; no truncating
+ * loss): read from ba_mean instead of being repeated by every slice, which also lifts what kept the slice count at two. */
+#ifndef BA_POSE_SLICES_CACHED
+#define BA_POSE_SLICES_CACHED 4
+#endif
+template <bool CACHED, int SLICES>
 __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /* [gridDim.x][n][BA_NV] */) {
     const int slice = (int)blockIdx.y;
     /* one accumulator set per WAVE, [4][n][BA_NV]: lane 63 adds its wave's 27 sums of a keyframe with plain LDS read-modify-
@@ -332,7 +351,12 @@ __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /*
         gsdf_v3 mean = { 0.f, 0.f, 0.f };
         int Nj = 0;
         unsigned long long seen = 0ull;                                        /* keyframes (<= 64) this voxel contributes to */
-        if (ok)
+        if (CACHED) {
+            if (ok && item < n_items) {
+                const ba_mean e = static_cast<const ba_mean*>(a.mean_cache)[item];
+                mean = gsdf_v3{ e.mx, e.my, e.mz }; Nj = e.nj; seen = e.seen;     /* (the mean is stored scaled by 1 / Nj) */
+            }
+        } else if (ok)
             for (int i = 0; i < a.n; ++i) {
                 if (!ba_visible(a, slot, i)) continue;
                 gsdf_v3 p; float m, n;
@@ -345,8 +369,8 @@ __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /*
                 seen |= 1ull << (i & 63);
             }
         const float inv_Nj = Nj ? (float)(1. / (double)(float)Nj) : 0.f;
-        mean = gsdf_v3{ inv_Nj * mean.x, inv_Nj * mean.y, inv_Nj * mean.z };
-        for (int i = slice; i < a.n; i += BA_POSE_SLICES) {
+        if (!CACHED) mean = gsdf_v3{ inv_Nj * mean.x, inv_Nj * mean.y, inv_Nj * mean.z };
+        for (int i = slice; i < a.n; i += SLICES) {
             const bool mine = ok && Nj && ((seen >> (i & 63)) & 1ull);
             if (!__any(mine)) continue;                                        /* wave-uniform skip */
             float val[BA_NV];
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(256) void k_ba_pose(ba_args a, float* block_part /*
     __syncthreads();
     const int nv = a.n * BA_NV;
     for (int i = threadIdx.x; i < nv; i += 256)
-        if ((i / BA_NV) % BA_POSE_SLICES == slice)                                                   /* this slice's keyframes */
+        if ((i / BA_NV) % SLICES == slice)                                                           /* this slice's keyframes */
             block_part[(size_t)blockIdx.x * nv + i] = (acc[i] + acc[nv + i]) + (acc[2 * nv + i] + acc[3 * nv + i]);
 }
 /* one WAVE per value: lane l adds the partials of workgroups l, l + 64, ... in that order, the 64 lane sums are then added in a
@@ -423,17 +447,21 @@ hipError_t gsdf_ba_compact(hipStream_t s, const gsdf_ba_dev& d, uint32_t* list_o
 }
 
 #define BA_BLOCKS 512
-void gsdf_launch_ba_energy(hipStream_t s, const gsdf_ba_dev& d, double* block_E) {
+void gsdf_launch_ba_energy(hipStream_t s, const gsdf_ba_dev& d, double* block_E, bool write_mean_cache) {
     ba_args a; std::memcpy(&a, &d, sizeof(a));
-    hipLaunchKernelGGL(k_ba_energy, dim3(BA_BLOCKS), dim3(256), 0, s, a, block_E);
+    if (write_mean_cache && a.gate_list && a.mean_cache) hipLaunchKernelGGL(k_ba_energy<true>, dim3(BA_BLOCKS), dim3(256), 0, s, a, block_E);
+    else hipLaunchKernelGGL(k_ba_energy<false>, dim3(BA_BLOCKS), dim3(256), 0, s, a, block_E);
 }
 void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping, double* block_cnt) {
     ba_args a; std::memcpy(&a, &d, sizeof(a));
     hipLaunchKernelGGL(k_ba_dist, dim3(BA_BLOCKS), dim3(BA_DIST_THREADS), 0, s, a, damping, block_cnt);
 }
-void gsdf_launch_ba_pose(hipStream_t s, const gsdf_ba_dev& d, float* block_part, float* out) {
+void gsdf_launch_ba_pose(hipStream_t s, const gsdf_ba_dev& d, float* block_part, float* out, bool use_mean_cache) {
     ba_args a; std::memcpy(&a, &d, sizeof(a));
-    hipLaunchKernelGGL(k_ba_pose, dim3(BA_BLOCKS, BA_POSE_SLICES), dim3(256), (size_t)4 * a.n * BA_NV * sizeof(float), s, a, block_part);
+    if (use_mean_cache && a.gate_list && a.mean_cache && a.trunc_sq < 0.f)
+        hipLaunchKernelGGL((k_ba_pose<true, BA_POSE_SLICES_CACHED>), dim3(BA_BLOCKS, BA_POSE_SLICES_CACHED), dim3(256), (size_t)4 * a.n * BA_NV * sizeof(float), s, a, block_part);
+    else
+        hipLaunchKernelGGL((k_ba_pose<false, BA_POSE_SLICES>), dim3(BA_BLOCKS, BA_POSE_SLICES), dim3(256), (size_t)4 * a.n * BA_NV * sizeof(float), s, a, block_part);
     const int n_vals = a.n * BA_NV;
     hipLaunchKernelGGL(k_ba_pose_reduce, dim3((n_vals + 3) / 4), dim3(256), 0, s, block_part, BA_BLOCKS, n_vals, out);
 }

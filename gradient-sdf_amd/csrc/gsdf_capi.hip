@@ -678,7 +678,7 @@ void gsdf_destroy(gsdf_ctx* c) {
     for (auto& m : c->marks) (void)hipEventDestroy(m.second);
     void* ptrs[] = { c->depth_sampled, c->tile_stats, c->grow_scratch, c->scratch, c->track_rows, c->track_abort, c->rc_counts, c->tab.vox, c->tab.bkeys, c->tab.occ, c->st, c->counter, c->planes, c->depth_stage, c->normals, c->partials,
                      c->blk_counters, c->frame_log, c->deferred, c->deferred_count, c->fuse_ticket, c->tile_flags, c->tile_order, c->vis, c->ba_images, c->ba_Rt,
-                     c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb, c->ba_gate_list, c->ba_gate_tmp, c->counter2 };
+                     c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb, c->ba_gate_list, c->ba_gate_tmp, c->counter2, c->ba_mean };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& b : c->mx) if (b.p) (void)hipFree(b.p);
     if (c->progress) (void)hipHostFree((void*)c->progress);
@@ -1178,6 +1178,7 @@ static gsdf_ba_dev ba_dev(gsdf_ctx* c) {
     d.trunc_sq = c->ba_trunc_sq;
     d.gate_list = c->ba_gate_fresh ? c->ba_gate_list : nullptr;
     d.gate_count = c->counter2;
+    d.mean_cache = c->ba_mean;
     return d;
 }
 /* (re)builds the list of the voxels inside the |dist| <= vs gate, if the distances may have changed since it was made.  Enqueue
@@ -1217,9 +1218,10 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
     if (n <= 0 || n > 64 || !images_bgr_host || !poses16_host || !frame_idx) return fail(GSDF_ERR_INVALID, "bad argument (1..64 keyframes)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    void* old[] = { c->ba_images, c->ba_Rt, c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb, c->ba_gate_list, c->ba_gate_tmp, c->counter2 };
+    void* old[] = { c->ba_images, c->ba_Rt, c->ba_frame_idx, c->ba_block_E, c->ba_block_part, c->ba_Hb, c->ba_gate_list, c->ba_gate_tmp, c->counter2, c->ba_mean };
     for (void* p : old) if (p) (void)hipFree(p);
     c->ba_gate_list = nullptr; c->ba_gate_tmp = nullptr; c->counter2 = nullptr; c->ba_gate_fresh = false;
+    c->ba_mean = nullptr; c->ba_mean_valid = false;
     c->ba_images = nullptr; c->ba_Rt = nullptr; c->ba_frame_idx = nullptr; c->ba_block_E = nullptr; c->ba_block_part = nullptr; c->ba_Hb = nullptr;
     c->ba_n = n; c->ba_reg = reg_weight;
     const size_t img_bytes = (size_t)n * c->W * c->H * 3 * sizeof(float);
@@ -1238,6 +1240,8 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
             hipMalloc((void**)&c->ba_gate_list, c->n_slots * sizeof(uint32_t)) == hipSuccess &&
             hipMalloc(&c->ba_gate_tmp, bytes ? bytes : 8) == hipSuccess && hipMalloc((void**)&c->counter2, sizeof(unsigned long long)) == hipSuccess) {
             c->ba_gate_tmp_bytes = bytes;
+            /* optional on top: 24 B per possible list entry for what the energy sweep hands to the pose sweep (100 MB at 2^22 records) */
+            if (hipMalloc(&c->ba_mean, c->n_slots * 24) != hipSuccess) { (void)hipGetLastError(); c->ba_mean = nullptr; }
         } else {
             (void)hipGetLastError();
             if (c->ba_gate_list) { (void)hipFree(c->ba_gate_list); c->ba_gate_list = nullptr; }
@@ -1252,13 +1256,18 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
             for (int k = 0; k < 3; ++k) c->ba_R[9 * i + 3 * r + k] = poses16_host[16 * i + 4 * r + k];
             c->ba_t[3 * i + r] = poses16_host[16 * i + 4 * r + 3];
         }
+    c->ba_mean_valid = false;
     return ba_upload_poses(c);
 }
 
 /* the energy sweep enqueued into set `which` of the per-workgroup sums; ba_energy_sum adds a set up in the fixed order */
-static int ba_energy_enqueue(gsdf_ctx* c, int which) {
+static int ba_energy_enqueue(gsdf_ctx* c, int which, bool pose_sweep_follows = true) {
     ba_refresh_gate(c);
-    gsdf_launch_ba_energy(c->stream, ba_dev(c), c->ba_block_E + (size_t)which * 3 * gsdf_ba_blocks());
+    const gsdf_ba_dev d = ba_dev(c);
+    /* the sweep leaves every gated voxel's mean intensity / keyframe set behind for a pose sweep at this same state */
+    const bool write_mean = pose_sweep_follows && d.gate_list && d.mean_cache && c->ba_trunc_sq < 0.f;
+    gsdf_launch_ba_energy(c->stream, d, c->ba_block_E + (size_t)which * 3 * gsdf_ba_blocks(), write_mean);
+    c->ba_mean_valid = write_mean;
     HIP_TRY(hipGetLastError());
     return GSDF_OK;
 }
@@ -1294,6 +1303,7 @@ int gsdf_ba_counters(gsdf_ctx* c, int64_t* voxels, int64_t* observations) {
 static int ba_dist_enqueue(gsdf_ctx* c, float damping, double* block_cnt = nullptr) {
     gsdf_launch_ba_dist(c->stream, ba_dev(c), damping, block_cnt);
     c->ba_gate_fresh = false;                                 /* the distances moved: voxels may have crossed the gate */
+    c->ba_mean_valid = false;
     HIP_TRY(hipGetLastError());
     return GSDF_OK;
 }
@@ -1318,8 +1328,11 @@ int gsdf_ba_solve_dist(gsdf_ctx* c, float damping) {
  * or leave the copy queued in front of whatever the caller enqueues next (gsdf_ba_optimize) */
 static int ba_solve_pose(gsdf_ctx* c, bool wait_upload) {
     const int n = c->ba_n;
+    const bool list_was_fresh = c->ba_gate_fresh;
     ba_refresh_gate(c);
-    gsdf_launch_ba_pose(c->stream, ba_dev(c), c->ba_block_part, c->ba_Hb);
+    /* (the cache belongs to the list the energy sweep walked: a list rebuilt since then has other entries) */
+    gsdf_launch_ba_pose(c->stream, ba_dev(c), c->ba_block_part, c->ba_Hb, c->ba_mean_valid && list_was_fresh);
+    c->ba_mean_valid = false;                                 /* the poses move */
     std::vector<float> hb((size_t)n * 27);
     HIP_TRY(hipMemcpyAsync(hb.data(), c->ba_Hb, hb.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));                 /* the 6x6 systems are solved on the host (:577-589) */
@@ -1355,6 +1368,7 @@ int gsdf_ba_solve_pose(gsdf_ctx* c, float damping) {
     int rc = ba_require(c);
     if (rc) return rc;
     c->ba_gate_fresh = false;                                 /* the map may have changed since the last BA call */
+    c->ba_mean_valid = false;
     HIP_TRY(hipSetDevice(c->device));
     return ba_solve_pose(c, true);
 }
@@ -1378,7 +1392,7 @@ int gsdf_ba_optimize(gsdf_ctx* c, int max_it, float* energies, int* n_energies, 
     std::vector<double> h(2 * set);
     for (int iter = 0; iter < max_it; ++iter) {               /* :621-657 */
         if ((rc = ba_solve_pose(c, false))) return rc;
-        if ((rc = ba_energy_enqueue(c, 0))) return rc;
+        if ((rc = ba_energy_enqueue(c, 0, false))) return rc;  /* (the distance sweep follows: nobody reads its means) */
         if ((rc = ba_dist_enqueue(c, 1.0f))) return rc;
         if ((rc = ba_energy_enqueue(c, 1))) return rc;
         HIP_TRY(hipMemcpyAsync(h.data(), c->ba_block_E, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -124,6 +124,8 @@ struct gsdf_ctx {
     size_t ba_gate_tmp_bytes = 0;
     unsigned long long* counter2 = nullptr;        /* device word: entries of ba_gate_list */
     bool ba_gate_fresh = false;                    /* the list matches the distances in the table */
+    void* ba_mean = nullptr;                       /* per entry of ba_gate_list: what the last energy sweep's first loop found (24 B each; gsdf_ba_dev::mean_cache) */
+    bool ba_mean_valid = false;                    /* ... at the very state (poses, distances, gate list) the next pose sweep will see */
     long long ba_last_voxels = 0, ba_last_obs = 0; /* what the last energy sweep read back counted (gsdf_ba_counters) */
     unsigned int track_serial = 0;                 /* optimize() call counter */
     volatile unsigned int* progress = nullptr;     /* pinned host words written by the tracker epilogue */

@@ -233,13 +233,17 @@ struct gsdf_ba_dev {
      * surface map: without it 92 % of their lanes look at a record and leave) */
     const uint32_t* gate_list;
     const unsigned long long* gate_count;
+    /* nullable: per entry of gate_list what getEnergy's first loop found for that voxel -- mean intensity over its keyframes, their
+     * number, their set (24 B) -- written by the energy sweep, read by the pose sweep that follows it at the same state instead
+     * of repeating that loop (solvePose :520-560 computes exactly getEnergy's :287-311 unless the loss truncates) */
+    void* mean_cache;
 };
 /* the list above: ordered compaction of the table's slots (rocPRIM select over a counting iterator; tmp == nullptr: only
  * *tmp_bytes is set) */
 hipError_t gsdf_ba_compact(hipStream_t s, const gsdf_ba_dev& d, uint32_t* list_out, unsigned long long* count_out, void* tmp, size_t* tmp_bytes);
-void gsdf_launch_ba_energy(hipStream_t s, const gsdf_ba_dev& d, double* block_E);
+void gsdf_launch_ba_energy(hipStream_t s, const gsdf_ba_dev& d, double* block_E, bool write_mean_cache = false /* needs gate_list and mean_cache */);
 void gsdf_launch_ba_dist(hipStream_t s, const gsdf_ba_dev& d, float damping, double* block_cnt /* nullable: [2][gsdf_ba_blocks()] voxels, observations */);
-void gsdf_launch_ba_pose(hipStream_t s, const gsdf_ba_dev& d, float* block_part, float* out);
+void gsdf_launch_ba_pose(hipStream_t s, const gsdf_ba_dev& d, float* block_part, float* out, bool use_mean_cache = false /* written by an energy sweep at this very state */);
 int  gsdf_ba_blocks(void);
 
 #endif /* GSDF_KERNELS_H_ */

@@ -524,7 +524,8 @@ int gsdf_grow_impl(gsdf_ctx* c, int new_capacity_log2) {
     c->occ_dirty = true;                                       /* the raycaster's filters are rebuilt from the keys when it next runs */
     /* PhotoBA's gate list was sized for the old table: the sweeps fall back to the whole table until the next gsdf_ba_setup */
     if (c->ba_gate_list) { (void)hipFree(c->ba_gate_list); c->ba_gate_list = nullptr; }
-    c->ba_gate_fresh = false;
+    if (c->ba_mean) { (void)hipFree(c->ba_mean); c->ba_mean = nullptr; }
+    c->ba_gate_fresh = false; c->ba_mean_valid = false;
     c->grow_forget = true;                                     /* auto-grow: the counts in flight describe the old table */
     return GSDF_OK;
 }
