@@ -1241,7 +1241,11 @@ int gsdf_ba_setup(gsdf_ctx* c, int n, const float* images_bgr_host, const float*
             hipMalloc(&c->ba_gate_tmp, bytes ? bytes : 8) == hipSuccess && hipMalloc((void**)&c->counter2, sizeof(unsigned long long)) == hipSuccess) {
             c->ba_gate_tmp_bytes = bytes;
             /* optional on top: 24 B per possible list entry for what the energy sweep hands to the pose sweep (100 MB at 2^22 records) */
-            if (hipMalloc(&c->ba_mean, c->n_slots * 24) != hipSuccess) { (void)hipGetLastError(); c->ba_mean = nullptr; }
+            /* GSDF_BA_MEAN_CACHE (read here, so that a test can switch within one context): 0 the pose sweep computes its means
+             * itself; 2 (tests only) the stand-alone gsdf_ba_solve_pose trusts that nothing changed since the last energy sweep */
+            const char* env = getenv("GSDF_BA_MEAN_CACHE");
+            c->ba_mean_on = env ? atoi(env) : 1;
+            if (!c->ba_mean_on || hipMalloc(&c->ba_mean, c->n_slots * 24) != hipSuccess) { (void)hipGetLastError(); c->ba_mean = nullptr; }
         } else {
             (void)hipGetLastError();
             if (c->ba_gate_list) { (void)hipFree(c->ba_gate_list); c->ba_gate_list = nullptr; }
@@ -1367,8 +1371,10 @@ int gsdf_ba_solve_pose(gsdf_ctx* c, float damping) {
     (void)damping;                                            /* unused by the reference as well (:499) */
     int rc = ba_require(c);
     if (rc) return rc;
-    c->ba_gate_fresh = false;                                 /* the map may have changed since the last BA call */
-    c->ba_mean_valid = false;
+    if (c->ba_mean_on != 2) {
+        c->ba_gate_fresh = false;                             /* the map may have changed since the last BA call */
+        c->ba_mean_valid = false;
+    }
     HIP_TRY(hipSetDevice(c->device));
     return ba_solve_pose(c, true);
 }

@@ -125,6 +125,7 @@ struct gsdf_ctx {
     unsigned long long* counter2 = nullptr;        /* device word: entries of ba_gate_list */
     bool ba_gate_fresh = false;                    /* the list matches the distances in the table */
     void* ba_mean = nullptr;                       /* per entry of ba_gate_list: what the last energy sweep's first loop found (24 B each; gsdf_ba_dev::mean_cache) */
+    int ba_mean_on = 1;                            /* GSDF_BA_MEAN_CACHE (read by gsdf_ba_setup) */
     bool ba_mean_valid = false;                    /* ... at the very state (poses, distances, gate list) the next pose sweep will see */
     long long ba_last_voxels = 0, ba_last_obs = 0; /* what the last energy sweep read back counted (gsdf_ba_counters) */
     unsigned int track_serial = 0;                 /* optimize() call counter */

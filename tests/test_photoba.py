@@ -190,6 +190,28 @@ def test_gpu_photoba_optimize_matches_oracle(pkg, O):
 
 
 @pytest.mark.gpu
+def test_gpu_photoba_pose_sweep_with_the_energy_sweeps_means_is_bit_identical(pkg, O, monkeypatch):
+    """Round 6: inside optimize() the pose sweep reads every gated voxel's mean intensity / keyframe set from what the energy sweep
+    in front of it left behind (k_ba_energy<true> -> k_ba_pose<true, 4>) instead of repeating that loop.  Same arithmetic in the
+    same order: the pose step must be the one of GSDF_BA_MEAN_CACHE=0 bit for bit.  Compared on ONE table (another copy of the
+    same map numbers its slots differently, and the sweeps add in slot order): energy + pose step with the cache (mode 2 lets the
+    stand-alone gsdf_ba_solve_pose use what the energy sweep just wrote), poses set back by a second gsdf_ba_setup -- a pose step
+    does not touch the map --, energy + pose step without it."""
+    seq, g, o, imgs, P, Pp = _gpu_and_oracle_on_the_same_map(pkg, O, n=6)
+    out = []
+    for mode in ("2", "0", "2"):
+        monkeypatch.setenv("GSDF_BA_MEAN_CACHE", mode)
+        g.ba_setup(imgs, Pp, np.arange(6))
+        e0 = g.ba_energy()
+        g.ba_solve_pose()
+        out.append((np.float32(e0), g.ba_poses().copy(), np.float32(g.ba_energy())))
+    g.close()
+    assert np.abs(out[0][1] - Pp).max() > 1e-4                                  # the step is real
+    for a, b in ((out[0], out[1]), (out[0], out[2])):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+@pytest.mark.gpu
 def test_photometric_optimizer_cpp_facade_executed(pkg, O, tmp_path):
     """host/PhotometricOptimizer.h (the facade for ps_optimizer/PhotometricOptimizer.h:68-186) EXECUTED from C++ --
     host/photoba_selftest fuses the frames through MapGradPixelSdf::update (vis_ on), then setImages / setPoses / setKeyframes,
