@@ -143,8 +143,10 @@ int gsdf_track_and_fuse_dev(gsdf_ctx* c, const float* depth_dev, const float K[9
                             int num_iterations, float conv_threshold, float damping);
 /* Optional, time only: names the frame the NEXT gsdf_track_and_fuse_dev will be called with, before the call for the CURRENT
  * frame.  The current frame's fusion launch then computes NormalEstimator::compute of that next frame in its tail (its last
- * workgroups: the fusion leaves a third of the chip's workgroup slots idle there, and they do not look at the convergence
- * gate, so they also run when the current frame is not fused), and the next frame's tracker launches carry no normals tiles.
+ * workgroups: the fusion leaves a third of the chip's workgroup slots idle there) -- when that fusion runs, i.e. the current
+ * frame converged; it leaves a token, and the next frame's tracker launches, which carry the normals tiles as ever, skip them
+ * when they find it.  The same launch also performs the closing head of the current frame's optimize() (reduce, solve, stop
+ * test of the first batch's last pass) instead of a tracker launch of its own.
  * The normals depend on the depth image alone (MapGradPixelSdf.cpp:60), so results do not: same poses, same map
  * (tests/test_gpu_parity.py::test_next_depth_hint_is_invisible_except_in_time).  Contract: next_depth_dev already holds the
  * next frame when the CURRENT frame's gsdf_track_and_fuse_dev is called, and stays unchanged until the next frame's call; a copy
