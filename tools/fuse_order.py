@@ -8,8 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as G
 pkg = G.package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 26
+scene = sys.argv[2] if len(sys.argv) > 2 else "tum"          # "spheres": the object-scan scene of C1 / C4 (four fifths of the tiles background)
 W, H = 640, 480
-seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=0)
+seq = pkg.synth.Sequence("tum", W, H, n_frames=n, seed=0) if scene == "tum" else pkg.synth.Sequence(scene, W, H, n_frames=n, seed=0, step_deg=360.0 * 4 / 2000)
 vs = np.float32(0.01); T = np.float32(10) * vs
 frames = [seq.frame(i) for i in range(n)]
 L = pkg.binding.load_test_lib()
@@ -51,6 +52,16 @@ def run(mode):
                 for j in np.argsort(-cost, kind="stable"):
                     emit(int(tx[j]), int(ty[j]))
                 order = np.array(out, dtype=np.uint32)
+            elif mode == "band_first":
+                # round 6: within every residue class of the launch position (b % 8 = the XCD, = the image stripe) the tiles that had
+                # something to fuse in the previous frame first, the others behind them, both in the static (colour-major) order:
+                # a launch of 1200 workgroups takes ~20 us to DISPATCH, and a band tile at the end of it starts that late
+                order = base.copy()
+                for r in range(8):
+                    pos = np.arange(r, NT, 8)
+                    ent = base[pos]
+                    band = cost[pos] > 0
+                    order[pos] = np.concatenate([ent[band], ent[~band]])
             elif mode == "desc_stripe":
                 # longest first within each of the 8 image stripes of a colour, stripes interleaved like the static order
                 order = []
@@ -87,10 +98,10 @@ def run(mode):
     return np.array(times), k, p
 
 ref = None
-for mode in ("static", "desc", "desc_stripe", "static", "desc", "desc_stripe"):
+for mode in (("static", "band_first", "static", "band_first") if scene != "tum" or os.environ.get("BAND_FIRST") else ("static", "desc", "desc_stripe", "static", "desc", "desc_stripe")):
     t, k, p = run(mode)
     if ref is None:
         ref = (k, p)
     same = np.array_equal(k, ref[0]) and np.abs(p - ref[1]).max() < 1e-3
-    print("%-6s: k_fuse mean of frames 6..%d %.2f us (median %.2f, min %.2f, max %.2f); map equal to the static order's: %s" % (
+    print("%-10s: k_fuse mean of frames 6..%d %.2f us (median %.2f, min %.2f, max %.2f); map equal to the static order's: %s" % (
         mode, n - 1, t[6:].mean(), np.median(t[6:]), t[6:].min(), t[6:].max(), same))

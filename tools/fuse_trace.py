@@ -10,7 +10,8 @@ pkg = G.package()
 last = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 extra = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 n = last + 1
-seq = pkg.synth.Sequence("tum", 640, 480, n_frames=n, seed=0)
+scene = sys.argv[3] if len(sys.argv) > 3 else "tum"          # "spheres": the object-scan scene of C1 / C4 (most tiles background)
+seq = pkg.synth.Sequence(scene, 640, 480, n_frames=n, seed=0) if scene == "tum" else pkg.synth.Sequence(scene, 640, 480, n_frames=n, seed=0, step_deg=360.0 * 4 / 2000)
 vs = np.float32(0.01); T = np.float32(10) * vs
 frames = [seq.frame(i) for i in range(n)]
 L = pkg.binding.load_test_lib()
@@ -35,6 +36,15 @@ hw = t[:, 14] & 0xFFFFFFFF
 npass = t[:, 13]
 single = npass == 1
 print("launch span %.1f us; workgroups %d, single band %d; per XCC: %s" % (ts[:, 10].max(), NW, single.sum(), np.bincount(xcc.astype(int), minlength=8).tolist()))
+empty = npass == 0
+if empty.any():
+    life = ts[empty, 10] - ts[empty, 0]
+    print("tiles without a band: %d; their lives %.2f us median / %.2f p90 / %.2f max; slot time %.0f us of %.0f us (all workgroups); the last of them starts at %.1f us" % (
+        empty.sum(), np.median(life), np.percentile(life, 90), life.max(), life.sum(), (ts[:, 10] - ts[:, 0]).sum(), ts[empty, 0].max()))
+    band = ~empty
+    print("tiles with a band: %d; lives %.1f us median / %.1f p90 / %.1f max; first starts %.1f, last starts %.1f, last ends %.1f us" % (
+        band.sum(), np.median(ts[band, 10] - ts[band, 0]), np.percentile(ts[band, 10] - ts[band, 0], 90), (ts[band, 10] - ts[band, 0]).max(),
+        ts[band, 0].min(), ts[band, 0].max(), ts[band, 10].max()))
 names = ["prologue", "walk", "keys", "wait", "lookup(w0)", "lookup(all)", "rec loads", "stores", "drain+flag", "tail"]
 d = np.diff(ts[:, :11], axis=1)
 print("phase durations, us (mean | median | p90) over single-band workgroups")
