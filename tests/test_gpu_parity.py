@@ -1341,7 +1341,7 @@ def test_no_frame_is_lost_when_contexts_share_the_gpu(pkg, O):
     STALE st->done = 0 from its XCD's L2 -- it left without fusing its tile and without its ticket, so the launch had no last
     workgroup: no frame-log row, the deferred list never added.  The window opens when lines of the state block are evicted between
     two dispatch rounds, i.e. when other work shares the GPU.  Here: four contexts in four host threads run the hinted frame loop
-    over the same 30 frames (all converge within the first batch: every fusion launch is a HEAD launch that runs), five times each;
+    over the same 30 frames (all converge within the first batch: every fusion launch is a HEAD launch that runs), twenty times each;
     every context must log every frame, fuse every frame (Sdf::counter_) with every tile (n_upd: a lost tile is ~4 000 updates), and
     end with the poses and the map of a context that ran alone -- up to the last bits the float atomics of the deferred lists and
     the host's timing leave open (see test_closing_head_inside_the_fusion_launch_is_invisible)."""
@@ -1379,13 +1379,13 @@ def test_no_frame_is_lost_when_contexts_share_the_gpu(pkg, O):
     log_a, frames_a, n_upd_a, keys_a, pay_a = alone[0][0]
     assert len(log_a) == n - 1 and frames_a == 1 + int(log_a[:, 7].sum())
     out = [None] * 4
-    th = [threading.Thread(target=run, args=(out, i, 5)) for i in range(4)]
+    th = [threading.Thread(target=run, args=(out, i, 20)) for i in range(4)]
     for t in th:
         t.start()
     for t in th:
         t.join()
     for res in out:
-        assert res is not None and len(res) == 5
+        assert res is not None and len(res) == 20
         for log, n_frames, n_upd, keys, pay in res:
             assert len(log) == n - 1, "a frame has no log row: its fusion launch had no last workgroup"
             assert np.array_equal(log[:, 7:9], log_a[:, 7:9])                       # converged flags, pass counts
